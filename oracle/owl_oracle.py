@@ -1,0 +1,289 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.
+
+CPU (torch fp32) restatement of the reference hot path: ``OwlViT.forward`` ->
+``PushPullLoss.forward`` (-> ``HungarianMatcher.forward``) -> backward.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this file; the product
+package never does (it must fail loudly when the HIP library is missing instead).
+
+Self-contained: torch + numpy + the C solver in ``oracle/lsap.c`` -- no ``transformers``, no
+``/root/reference`` import, so it travels to the GPU box.  Pinned against the reference itself by
+``tests/golden/make_golden.py`` (run in the build container, where ``/root/reference`` and
+``transformers`` exist): fixtures F1-F5 under ``tests/golden`` hold reference outputs for weights /
+inputs this repo regenerates bit-identically from a seed; ``tests/test_oracle_golden.py`` checks this
+file against them.  Version note: the reference pins transformers==4.30.2; the container has 5.15.0
+(eager attention forced) -- mathematically identical arithmetic for this path.
+
+Citations: ``ref:`` = path under /root/reference ; ``HF5:`` = transformers 5.15.0
+``models/owlvit/modeling_owlvit.py``.
+"""
+import ctypes
+import math
+import os
+import subprocess
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LSAP = None
+
+
+# ------------------------------------------------------------------------------------------------
+# Hungarian (scipy `_lsap` restated in C, oracle/lsap.c)
+# ------------------------------------------------------------------------------------------------
+def build_lsap(force: bool = False) -> str:
+    so = os.path.join(_HERE, "liboracle_lsap.so")
+    src = os.path.join(_HERE, "lsap.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", so, src, "-lm"])
+    return so
+
+
+def _lsap_lib():
+    global _LSAP
+    if _LSAP is None:
+        lib = ctypes.CDLL(build_lsap())
+        lib.oracle_lsap.restype = ctypes.c_int
+        lib.oracle_lsap.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        _LSAP = lib
+    return _LSAP
+
+
+def linear_sum_assignment(cost) -> "tuple[np.ndarray, np.ndarray]":
+    """ref: src/matcher.py:136 (scipy call).  cost: [nr, nc] array-like; solved in float64."""
+    c = np.ascontiguousarray(np.asarray(cost, dtype=np.float64))
+    nr, nc = c.shape
+    k = min(nr, nc)
+    a = np.empty(k, dtype=np.int64)
+    b = np.empty(k, dtype=np.int64)
+    rc = _lsap_lib().oracle_lsap(nr, nc, c.ctypes.data, a.ctypes.data, b.ctypes.data)
+    if rc != 0:
+        raise ValueError("cost matrix is infeasible" if rc == -1 else "matrix contains invalid numeric entries")
+    return a, b
+
+
+# ------------------------------------------------------------------------------------------------
+# Model forward (ref: src/models.py:98-119 and the HF modules it wraps)
+# ------------------------------------------------------------------------------------------------
+def quick_gelu(x):
+    """transformers activations.py:122-123."""
+    return x * torch.sigmoid(1.702 * x)
+
+
+def box_bias(grid: int) -> torch.Tensor:
+    """HF5:1071-1104 `compute_box_bias` for a square grid; [P,4] f32, p = y*W + x."""
+    coords = torch.arange(1, grid + 1, dtype=torch.float32)
+    xx, yy = torch.meshgrid(coords, coords, indexing="xy")
+    bc = torch.stack((xx, yy), dim=-1)
+    bc[..., 0] /= grid
+    bc[..., 1] /= grid
+    bc = bc.view(-1, 2)
+    bc = torch.clip(bc, 0.0, 1.0)
+    coord_bias = torch.log(bc + 1e-4) - torch.log1p(-bc + 1e-4)
+    size = torch.full_like(coord_bias, 1.0)
+    size[..., 0] /= grid
+    size[..., 1] /= grid
+    size_bias = torch.log(size + 1e-4) - torch.log1p(-size + 1e-4)
+    return torch.cat([coord_bias, size_bias], dim=-1)
+
+
+def encoder_layer(x, w, pre, heads, eps, taps=None):
+    """HF5:488-509 (layer), HF5:428-459 + HF5:377-402 (eager attention), HF5:463-475 (MLP)."""
+    B, T, D = x.shape
+    dh = D // heads
+    h = F.layer_norm(x, (D,), w[pre + "layer_norm1.weight"], w[pre + "layer_norm1.bias"], eps)
+    q = F.linear(h, w[pre + "self_attn.q_proj.weight"], w[pre + "self_attn.q_proj.bias"]).view(B, T, heads, dh).transpose(1, 2)
+    k = F.linear(h, w[pre + "self_attn.k_proj.weight"], w[pre + "self_attn.k_proj.bias"]).view(B, T, heads, dh).transpose(1, 2)
+    v = F.linear(h, w[pre + "self_attn.v_proj.weight"], w[pre + "self_attn.v_proj.bias"]).view(B, T, heads, dh).transpose(1, 2)
+    att = torch.matmul(q, k.transpose(2, 3)) * (dh ** -0.5)
+    att = torch.softmax(att, dim=-1)
+    o = torch.matmul(att, v).transpose(1, 2).reshape(B, T, D)
+    if taps is not None:
+        taps[pre + "ln1"] = h
+        taps[pre + "attn"] = o
+    x = x + F.linear(o, w[pre + "self_attn.out_proj.weight"], w[pre + "self_attn.out_proj.bias"])
+    h2 = F.layer_norm(x, (D,), w[pre + "layer_norm2.weight"], w[pre + "layer_norm2.bias"], eps)
+    g = quick_gelu(F.linear(h2, w[pre + "mlp.fc1.weight"], w[pre + "mlp.fc1.bias"]))
+    x = x + F.linear(g, w[pre + "mlp.fc2.weight"], w[pre + "mlp.fc2.bias"])
+    if taps is not None:
+        taps[pre + "out"] = x
+    return x
+
+
+def model_forward(cfg, w, image, taps=None):
+    """ref: src/models.py:98-119.  ``w``: name -> f32 tensor (reference parameter names).
+    Returns (pred_boxes [B,P,4] xyxy, pred_sims [B,P,C])."""
+    D, eps, g = cfg.hidden, cfg.ln_eps, cfg.grid
+    B = image.shape[0]
+    # embeddings: HF5:334-344 (conv k=s=patch, no bias; class token first; learned positions)
+    pe = F.conv2d(image, w["backbone.embeddings.patch_embedding.weight"], stride=cfg.patch_size)
+    pe = pe.flatten(2).transpose(1, 2)
+    cls = w["backbone.embeddings.class_embedding"].expand(B, 1, -1)
+    x = torch.cat([cls, pe], dim=1) + w["backbone.embeddings.position_embedding.weight"].unsqueeze(0)
+    if taps is not None:
+        taps["embed"] = x
+    x = F.layer_norm(x, (D,), w["backbone.pre_layernorm.weight"], w["backbone.pre_layernorm.bias"], eps)  # HF5:742
+    if taps is not None:
+        taps["pre_ln"] = x
+    for i in range(cfg.layers):
+        x = encoder_layer(x, w, f"backbone.encoder.layers.{i}.", cfg.heads, eps, taps)
+    # ref: src/models.py:80-86 -- post_layernorm on ALL tokens, class-token merge, second LN
+    x = F.layer_norm(x, (D,), w["backbone.post_layernorm.weight"], w["backbone.post_layernorm.bias"], eps)
+    x = x[:, 1:, :] * x[:, :1, :]
+    feats = F.layer_norm(x, (D,), w["post_post_layernorm.weight"], w["post_post_layernorm.bias"], eps)
+    if taps is not None:
+        taps["feats"] = feats
+    # box head: HF5:983-999 (erf GELU) + bias + sigmoid + center_to_corners (ref: src/models.py:65-73)
+    b = F.gelu(F.linear(feats, w["box_head.dense0.weight"], w["box_head.dense0.bias"]))
+    b = F.gelu(F.linear(b, w["box_head.dense1.weight"], w["box_head.dense1.bias"]))
+    b = F.linear(b, w["box_head.dense2.weight"], w["box_head.dense2.bias"])
+    b = torch.sigmoid(b + box_bias(g).to(b.dtype))
+    cx, cy, bw, bh = b.unbind(-1)
+    pred_boxes = torch.stack([cx - 0.5 * bw, cy - 0.5 * bh, cx + 0.5 * bw, cy + 0.5 * bh], dim=-1)
+    # class head: ref: src/models.py:24-38 (eps placement reproduced literally)
+    e = F.linear(feats, w["class_predictor.dense0.weight"], w["class_predictor.dense0.bias"])
+    e = e / (torch.linalg.norm(e, dim=-1, keepdim=True) + 1e-6)
+    q = w["queries"] / torch.linalg.norm(w["queries"], dim=-1, keepdim=True) + 1e-6
+    sims = e @ q.transpose(1, 2)
+    pred_sims = F.max_pool1d(sims, kernel_size=3, stride=3)
+    return pred_boxes, pred_sims
+
+
+# ------------------------------------------------------------------------------------------------
+# Box ops / matcher / loss (ref: src/matcher.py, src/losses.py)
+# ------------------------------------------------------------------------------------------------
+def box_area(b):
+    return (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+
+
+def box_iou(boxes1, boxes2):
+    """ref: src/matcher.py:8-21."""
+    area1, area2 = box_area(boxes1), box_area(boxes2)
+    lt = torch.max(boxes1[:, None, :2], boxes2[:, :2])
+    rb = torch.min(boxes1[:, None, 2:], boxes2[:, 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[:, :, 0] * wh[:, :, 1]
+    union = area1[:, None] + area2 - inter
+    return inter / union, union
+
+
+def generalized_box_iou(boxes1, boxes2):
+    """ref: src/matcher.py:25-44."""
+    assert (boxes1[:, 2:] >= boxes1[:, :2]).all()
+    assert (boxes2[:, 2:] >= boxes2[:, :2]).all()
+    iou, union = box_iou(boxes1, boxes2)
+    lt = torch.min(boxes1[:, None, :2], boxes2[:, :2])
+    rb = torch.max(boxes1[:, None, 2:], boxes2[:, 2:])
+    wh = (rb - lt).clamp(min=0)
+    area = wh[:, :, 0] * wh[:, :, 1]
+    return iou - (area - union) / area
+
+
+@torch.no_grad()
+def match_one(sims, boxes, labels, tgt_boxes, n_classes):
+    """ref: src/matcher.py:85-159 for ONE image (the reference is batch-1).
+    sims [P,C], boxes [P,4], labels [n] i64, tgt_boxes [n,4].
+    Returns (cost [P,n] f32, pred_idx [n] ascending, tgt_idx [n], target_classes [P] i64)."""
+    out_prob = sims.softmax(-1)
+    cost_class = -out_prob[:, labels]
+    cost_bbox = torch.cdist(boxes, tgt_boxes, p=1)
+    cost_giou = -generalized_box_iou(boxes, tgt_boxes)
+    C = 1 * cost_bbox + 1 * cost_class + 1 * cost_giou
+    i, j = linear_sum_assignment(C.cpu().numpy())
+    i = torch.as_tensor(i, dtype=torch.int64)
+    j = torch.as_tensor(j, dtype=torch.int64)
+    tc = torch.full((sims.shape[0],), n_classes, dtype=torch.int64)
+    tc[i] = labels[j]
+    return C, i, j, tc
+
+
+@torch.no_grad()
+def spread_labels(pred_boxes, target_classes, bg, thr=0.85):
+    """ref: src/losses.py:100-106 -- sequential, in-place, transitive."""
+    tc = target_classes.clone()
+    P = tc.shape[0]
+    for p in range(P):
+        lab = int(tc[p])
+        if lab == bg:
+            continue
+        iou, _ = box_iou(pred_boxes[p:p + 1], pred_boxes)
+        tc[iou[0] > thr] = lab
+    return tc
+
+
+def class_loss(sims, tc, bg, scales):
+    """ref: src/losses.py:16-40 for one image.  sims [P,C], tc [P]."""
+    a = torch.abs(sims)
+    pos = tc != bg
+    pred_logits, bg_logits = a[pos], a[~pos]
+    pos_t = F.one_hot(tc[pos], bg).float()
+    neg_t = torch.zeros_like(bg_logits)
+    pos_l = F.binary_cross_entropy(pred_logits, pos_t, weight=scales, reduction="none")
+    neg_l = F.binary_cross_entropy(bg_logits, neg_t, weight=scales, reduction="none")
+    pos_l = (torch.pow(1 - torch.exp(-pos_l), 2) * pos_l).sum(dim=1).mean()
+    neg_l = (torch.pow(1 - torch.exp(-neg_l), 2) * neg_l).sum(dim=1).mean()
+    return pos_l, neg_l
+
+
+def push_pull_loss_one(sims, labels, boxes, tgt_boxes, n_classes, scales=None, detail=None):
+    """ref: src/losses.py:71-116 at its native batch size of one."""
+    C, i, j, tc = match_one(sims.detach(), boxes.detach(), labels, tgt_boxes, n_classes)
+    num_boxes = labels.shape[0]
+    src = boxes[i]
+    tgt = tgt_boxes[j]
+    loss_bbox = F.l1_loss(src, tgt, reduction="none").sum() / num_boxes
+    loss_giou = (1 - torch.diag(generalized_box_iou(src, tgt))).sum() / num_boxes
+    tc2 = spread_labels(boxes.detach(), tc, n_classes)
+    loss_ce, loss_bg = class_loss(sims, tc2, n_classes, scales)
+    if detail is not None:
+        detail.update(cost=C, pred_idx=i, tgt_idx=j, target_classes_matched=tc, target_classes=tc2)
+    return {"loss_ce": loss_ce, "loss_bg": loss_bg, "loss_bbox": loss_bbox, "loss_giou": loss_giou}
+
+
+def push_pull_loss(pred_sims, labels, pred_boxes, tgt_boxes, n_classes, scales=None, details=None):
+    """Batched semantics of this build: mean over images of the reference's
+    batch-1 loss, term by term.  ``labels`` / ``tgt_boxes``: per-image lists."""
+    B = pred_sims.shape[0]
+    acc = None
+    for b in range(B):
+        d = {} if details is not None else None
+        l = push_pull_loss_one(pred_sims[b], labels[b], pred_boxes[b], tgt_boxes[b], n_classes, scales, d)
+        if details is not None:
+            details.append(d)
+        acc = l if acc is None else {k: acc[k] + l[k] for k in acc}
+    return {k: v / B for k, v in acc.items()}
+
+
+# ------------------------------------------------------------------------------------------------
+# Train step (ref: main.py:74-91) and AdamW (ref: main.py:56-60)
+# ------------------------------------------------------------------------------------------------
+def trainable_names(w):
+    keep = ("layers.11", "box", "post_layernorm", "class_predictor", "queries")   # ref: src/models.py:173-184
+    return [n for n in w if any(s in n for s in keep)]
+
+
+def train_step(cfg, w, image, labels, tgt_boxes, scales=None, with_grads=True):
+    """One forward + loss + backward; returns (outputs, losses, grads{name: tensor})."""
+    names = trainable_names(w)
+    ww = {n: (t.detach().clone().requires_grad_(True) if n in names else t.detach()) for n, t in w.items()}
+    boxes, sims = model_forward(cfg, ww, image)
+    losses = push_pull_loss(sims, labels, boxes, tgt_boxes, cfg.n_classes, scales)
+    total = losses["loss_ce"] + losses["loss_bg"] + losses["loss_bbox"] + losses["loss_giou"]
+    grads = {}
+    if with_grads:
+        total.backward()
+        grads = {n: ww[n].grad for n in names}
+    return (boxes.detach(), sims.detach()), {k: v.detach() for k, v in losses.items()}, grads
+
+
+def adamw_step(p, g, m, v, step, lr=3e-6, wd=0.1, b1=0.9, b2=0.999, eps=1e-8):
+    """Decoupled AdamW exactly as torch.optim.AdamW (single param group; ref: main.py:56-60)."""
+    p = p * (1 - lr * wd)
+    m = b1 * m + (1 - b1) * g
+    v = b2 * v + (1 - b2) * g * g
+    bc1 = 1 - b1 ** step
+    bc2 = 1 - b2 ** step
+    denom = v.sqrt() / math.sqrt(bc2) + eps
+    p = p - (lr / bc1) * m / denom
+    return p, m, v

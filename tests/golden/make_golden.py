@@ -1,0 +1,322 @@
+"""Generate the golden fixtures under tests/golden by running THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference and `transformers`); never on the GPU box.
+What is committed are the OUTPUT VECTORS (.npz) plus this script -- no reference source.
+
+Recipe:
+  * stub `torchvision` (absent here) -- only `box_area` is used on the train path;
+  * build HF `OwlViTForObjectDetection` from a config (no hub access), eager attention;
+  * load this repo's deterministic weights (weights.make_weights) by name mapping;
+  * wrap with the reference's `src.models.OwlViT`, re-apply its freeze loop
+    (src/models.py:173-184 lives inside `load_model`, which needs the network);
+  * adapt `compute_box_bias` (transformers 5.x signature drift; numerically identical);
+  * re-enact main.py:74-91 around `src.losses.PushPullLoss` at the reference's batch size of 1.
+
+Usage:  python tests/golden/make_golden.py [f1 f2 f3 f4 f5 lsap]
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+import transformers  # noqa: E402  (must be imported BEFORE the torchvision stub)
+from transformers import OwlViTConfig, OwlViTForObjectDetection  # noqa: E402
+
+tv = types.ModuleType("torchvision")
+tv_ops = types.ModuleType("torchvision.ops")
+tv_ops.box_area = lambda b: (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+tv_ops.nms = None
+tv_ops.batched_nms = None
+tv.ops = tv_ops
+sys.modules["torchvision"] = tv
+sys.modules["torchvision.ops"] = tv_ops
+
+sys.path.insert(0, "/root/reference")
+from src.models import OwlViT as RefOwlViT  # noqa: E402
+from src.losses import PushPullLoss as RefPushPullLoss  # noqa: E402
+
+from owl_vit_object_detection_amd import synth, weights  # noqa: E402
+from owl_vit_object_detection_amd.config import get_config  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+
+def build_reference_model(cfg, seed=1234):
+    hf_cfg = OwlViTConfig(
+        vision_config=dict(hidden_size=cfg.hidden, intermediate_size=cfg.mlp, num_hidden_layers=cfg.layers,
+                           num_attention_heads=cfg.heads, image_size=cfg.image_size, patch_size=cfg.patch_size,
+                           hidden_act="quick_gelu", layer_norm_eps=cfg.ln_eps),
+        text_config=dict(hidden_size=cfg.text_dim, intermediate_size=64, num_hidden_layers=1,
+                         num_attention_heads=1, vocab_size=64, max_position_embeddings=16),
+        projection_dim=cfg.text_dim,
+    )
+    hf_cfg._attn_implementation = "eager"
+    hf_cfg.vision_config._attn_implementation = "eager"
+    hf = OwlViTForObjectDetection(hf_cfg)
+    W = weights.make_weights(cfg, seed)
+    sd = hf.state_dict()
+    for name, arr in W.items():
+        if name == "queries":
+            continue
+        if name.startswith("backbone."):
+            key = "owlvit.vision_model." + name[len("backbone."):]
+        elif name.startswith("post_post_layernorm."):
+            key = "layer_norm." + name[len("post_post_layernorm."):]
+        elif name.startswith("class_predictor.dense0."):
+            key = "class_head.dense0." + name[len("class_predictor.dense0."):]
+        else:
+            key = name
+        assert key in sd and tuple(sd[key].shape) == arr.shape, (name, key)
+        sd[key] = torch.from_numpy(arr.copy())
+    hf.load_state_dict(sd)
+    model = RefOwlViT(pretrained_model=hf, query_bank=torch.from_numpy(W["queries"].copy()))
+    model.compute_box_bias = lambda fm: hf.compute_box_bias(fm.shape[1], fm.shape[2])
+    # freeze loop: reference src/models.py:173-184
+    for name, parameter in model.named_parameters():
+        conditions = ["layers.11" in name, "box" in name, "post_layernorm" in name,
+                      "class_predictor" in name, "queries" in name]
+        if any(conditions):
+            continue
+        parameter.requires_grad = False
+    names = [n for n, _ in model.named_parameters()]
+    assert set(names) == set(weights.param_shapes(cfg).keys()), set(names) ^ set(weights.param_shapes(cfg).keys())
+    for n, p in model.named_parameters():
+        assert p.requires_grad == weights.is_trainable(n), n
+    model.train()
+    return model, W
+
+
+def run_reference_step(model, cfg, image, labels, boxes, scales, taps=None):
+    """main.py:74-91 re-enacted at batch 1. image [1,3,S,S]; labels [n]; boxes [n,4]."""
+    hooks = []
+    if taps is not None:
+        bb = model.backbone
+        hooks.append(bb.embeddings.register_forward_hook(lambda m, i, o: taps.__setitem__("embed", o.detach().clone())))
+        hooks.append(bb.pre_layernorm.register_forward_hook(lambda m, i, o: taps.__setitem__("pre_ln", o.detach().clone())))
+        for li, layer in enumerate(bb.encoder.layers):
+            hooks.append(layer.register_forward_hook(
+                lambda m, i, o, li=li: taps.__setitem__(f"backbone.encoder.layers.{li}.out",
+                                                        (o[0] if isinstance(o, tuple) else o).detach().clone())))
+        hooks.append(model.post_post_layernorm.register_forward_hook(lambda m, i, o: taps.__setitem__("feats", o.detach().clone())))
+    for p in model.parameters():
+        p.grad = None
+    criterion = RefPushPullLoss(cfg.n_classes, scales=None if scales is None else torch.tensor(scales))
+    pred_boxes, _none1, pred_sims, _none2 = model(torch.from_numpy(image))
+    assert _none1 is None and _none2 is None
+    lab = torch.from_numpy(labels)[None]
+    tb = torch.from_numpy(boxes)[None]
+    # capture matcher output (pre-spreading) by calling the matcher the same way forward() does
+    with torch.no_grad():
+        tc0, indices, _ = criterion.matcher({"pred_logits": pred_sims, "pred_boxes": pred_boxes},
+                                            [{"labels": lab[0], "boxes": tb[0]}])
+    losses = criterion(pred_sims, lab, pred_boxes, tb)
+    loss = losses["loss_ce"] + losses["loss_bg"] + losses["loss_bbox"] + losses["loss_giou"]
+    loss.backward()
+    for h in hooks:
+        h.remove()
+    grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.requires_grad}
+    out = dict(pred_boxes=pred_boxes.detach().numpy(), pred_sims=pred_sims.detach().numpy(),
+               target_classes_matched=tc0[0].numpy(), pred_idx=indices[0][0].numpy(), tgt_idx=indices[0][1].numpy())
+    for k, v in losses.items():
+        out[k] = np.float32(v.item())
+    return out, grads
+
+
+def recover_spread_labels(cfg, out):
+    """target_classes AFTER spreading is not returned by the reference; re-run its exact loop
+    (src/losses.py:100-106) on the captured tensors with the reference's own box_iou."""
+    from src.matcher import box_iou
+    pb = torch.from_numpy(out["pred_boxes"])
+    tc = torch.from_numpy(out["target_classes_matched"].copy())[None]
+    for box, label in zip(pb[0], tc[0]):
+        if label == cfg.n_classes:
+            continue
+        iou, _ = box_iou(box.unsqueeze(0), pb.squeeze(0))
+        idx = iou > 0.85
+        tc[idx] = label.item()
+    return tc[0].numpy()
+
+
+def grad_summary(grads, full):
+    d = {}
+    for n, g in grads.items():
+        g = g.numpy()
+        if full:
+            d["grad/" + n] = g
+        else:
+            d["gradnorm/" + n] = np.float64(np.linalg.norm(g.astype(np.float64)))
+            d["gradhead/" + n] = g.reshape(-1)[:64].copy()
+    return d
+
+
+def f1():
+    for cname in ("tiny", "tiny-l14"):
+        cfg = get_config(cname)
+        model, _ = build_reference_model(cfg)
+        img = synth.make_images(cfg, 1)
+        labels, boxes = synth.make_targets(cfg, 1, max_boxes=6)
+        scales = synth.class_scales(cfg, labels)
+        taps = {}
+        out, grads = run_reference_step(model, cfg, img, labels[0], boxes[0], scales, taps)
+        out["target_classes"] = recover_spread_labels(cfg, out)
+        out["scales"] = scales
+        for k, v in taps.items():
+            out["tap/" + k] = v.numpy()
+        out.update(grad_summary(grads, full=True))
+        np.savez_compressed(os.path.join(HERE, f"f1_{cname}.npz"), **out)
+        print("f1", cname, {k: float(out[k]) for k in ("loss_ce", "loss_bg", "loss_bbox", "loss_giou")})
+
+
+def _full(cname, tag, seed=1234):
+    cfg = get_config(cname)
+    model, _ = build_reference_model(cfg, seed)
+    img = synth.make_images(cfg, 1, seed)
+    labels, boxes = synth.make_targets(cfg, 1, seed, max_boxes=16)
+    scales = synth.class_scales(cfg, labels)
+    out, grads = run_reference_step(model, cfg, img, labels[0], boxes[0], scales)
+    out["target_classes"] = recover_spread_labels(cfg, out)
+    out["scales"] = scales
+    out["pred_boxes"] = out["pred_boxes"].astype(np.float32)
+    out.update(grad_summary(grads, full=False))
+    np.savez_compressed(os.path.join(HERE, f"{tag}.npz"), **out)
+    print(tag, {k: float(out[k]) for k in ("loss_ce", "loss_bg", "loss_bbox", "loss_giou")})
+
+
+def f2():
+    _full("owlvit-base-patch16", "f2_b16")
+
+
+def f3():
+    """Batched semantics: B separate batch-1 reference runs, losses and grads averaged."""
+    cfg = get_config("small")
+    B = 3
+    model, _ = build_reference_model(cfg)
+    imgs = synth.make_images(cfg, B)
+    labels, boxes = synth.make_targets(cfg, B, max_boxes=8)
+    scales = synth.class_scales(cfg, labels)
+    acc, gacc = None, None
+    pb, ps, tcs = [], [], []
+    for b in range(B):
+        out, grads = run_reference_step(model, cfg, imgs[b:b + 1], labels[b], boxes[b], scales)
+        pb.append(out["pred_boxes"][0]); ps.append(out["pred_sims"][0])
+        tcs.append(recover_spread_labels(cfg, out))
+        l = {k: float(out[k]) for k in ("loss_ce", "loss_bg", "loss_bbox", "loss_giou")}
+        acc = l if acc is None else {k: acc[k] + l[k] for k in acc}
+        gacc = grads if gacc is None else {k: gacc[k] + grads[k] for k in gacc}
+    res = dict(pred_boxes=np.stack(pb), pred_sims=np.stack(ps), target_classes=np.stack(tcs), scales=scales)
+    for k, v in acc.items():
+        res[k] = np.float32(v / B)
+    res.update(grad_summary({k: v / B for k, v in gacc.items()}, full=False))
+    np.savez_compressed(os.path.join(HERE, "f3_small_batch3.npz"), **res)
+    print("f3", {k: float(res[k]) for k in ("loss_ce", "loss_bg", "loss_bbox", "loss_giou")})
+
+
+def f4():
+    _full("owlvit-large-patch14", "f4_l14")
+
+
+def f5():
+    """Loss-only adversarial cases straight through the reference PushPullLoss (no model)."""
+    from owl_vit_object_detection_amd import rng
+    cases = {}
+
+    def boxes_from(seed, stream, n, wmin=0.02, wmax=0.37):
+        x0 = rng.uniform(seed, stream, n, 0) * 0.6
+        y0 = rng.uniform(seed, stream, n, 1) * 0.6
+        w = wmin + rng.uniform(seed, stream, n, 2) * (wmax - wmin)
+        h = wmin + rng.uniform(seed, stream, n, 3) * (wmax - wmin)
+        return np.stack([x0, y0, x0 + w, y0 + h], 1).astype(np.float32)
+
+    def add(name, P, C, n, scales, dup_chain=False, ties=False, sim_one=False):
+        sims = (rng.uniform(7, name + "/sims", P * C).reshape(P, C) * 1.6 - 0.8).astype(np.float32)
+        pb = boxes_from(7, name + "/pb", P, 0.05, 0.3)
+        tb = boxes_from(7, name + "/tb", n)
+        labels = rng.randint(7, name + "/lab", n, C)
+        if dup_chain:
+            # chains of near-duplicates: p+1 is p shifted by a hair -> IoU > 0.85 with p, lower with p-2
+            for s in range(0, P - 12, 12):
+                for k in range(1, 10):
+                    pb[s + k] = pb[s] + np.float32(0.012 * k) * np.array([1, 0, 1, 0], np.float32)
+            # and make some chain heads sit exactly on targets so they get matched
+            for t in range(min(n, P // 12)):
+                pb[12 * t] = tb[t]
+                for k in range(1, 10):
+                    pb[12 * t + k] = tb[t] + np.float32(0.012 * k) * np.array([1, 0, 1, 0], np.float32)
+        if ties:
+            pb[1::2] = pb[0::2][: len(pb[1::2])]
+            sims[1::2] = sims[0::2][: len(sims[1::2])]
+        if sim_one:
+            sims[3, 1] = 1.0
+            sims[5, 0] = -1.0
+            sims[6, 2] = 0.0
+        cases[name] = (sims, pb, labels, tb, scales)
+
+    add("basic_n7_noscale", 200, 10, 7, None)
+    add("basic_n7_scale", 200, 10, 7, np.round(3 + rng.uniform(7, "sc", 10) * 2, 1).astype(np.float32))
+    add("n1", 64, 10, 1, None)
+    add("n40", 300, 10, 40, np.round(3 + rng.uniform(7, "sc2", 10) * 2, 1).astype(np.float32))
+    add("dup_chain", 240, 10, 6, None, dup_chain=True)
+    add("ties", 128, 4, 5, None, ties=True)
+    add("sim_one", 96, 4, 3, np.array([3.0, 3.5, 4.1, 3.2], np.float32), sim_one=True)
+
+    res = {}
+    for name, (sims, pb, labels, tb, scales) in cases.items():
+        C = sims.shape[1]
+        crit = RefPushPullLoss(C, scales=None if scales is None else torch.tensor(scales))
+        s = torch.from_numpy(sims)[None].clone().requires_grad_(True)
+        b = torch.from_numpy(pb)[None].clone().requires_grad_(True)
+        lab = torch.from_numpy(labels)[None]
+        t = torch.from_numpy(tb)[None]
+        with torch.no_grad():
+            tc0, indices, _ = crit.matcher({"pred_logits": s, "pred_boxes": b}, [{"labels": lab[0], "boxes": t[0]}])
+        losses = crit(s, lab, b, t)
+        (losses["loss_ce"] + losses["loss_bg"] + losses["loss_bbox"] + losses["loss_giou"]).backward()
+        out = dict(pred_boxes=pb[None], target_classes_matched=tc0[0].numpy())
+        res[name + "/sims"] = sims
+        res[name + "/pred_boxes"] = pb
+        res[name + "/labels"] = labels
+        res[name + "/tgt_boxes"] = tb
+        if scales is not None:
+            res[name + "/scales"] = scales
+        res[name + "/target_classes_matched"] = tc0[0].numpy()
+        res[name + "/target_classes"] = recover_spread_labels(types.SimpleNamespace(n_classes=C), out)
+        res[name + "/pred_idx"] = indices[0][0].numpy()
+        res[name + "/tgt_idx"] = indices[0][1].numpy()
+        for k, v in losses.items():
+            res[name + "/" + k] = np.float32(v.item())
+        res[name + "/grad_sims"] = s.grad[0].numpy()
+        res[name + "/grad_boxes"] = b.grad[0].numpy()
+        print("f5", name, {k: float(v) for k, v in losses.items()},
+              "spread:", int((res[name + "/target_classes"] != C).sum()), "matched:", len(labels))
+    np.savez_compressed(os.path.join(HERE, "f5_loss_cases.npz"), **res)
+
+
+def lsap():
+    """Known-answer vectors from scipy (the reference's solver) for the C restatement."""
+    from scipy.optimize import linear_sum_assignment
+    from owl_vit_object_detection_amd import rng
+    res = {}
+    shapes = [(1, 1), (5, 5), (2304, 7), (7, 2304), (300, 40), (64, 64), (10, 3), (3, 10), (576, 16)]
+    for k, (nr, nc) in enumerate(shapes):
+        c = rng.uniform(11, f"lsap/{k}", nr * nc).reshape(nr, nc)
+        i, j = linear_sum_assignment(c)
+        res[f"c{k}/cost"] = c; res[f"c{k}/row"] = i; res[f"c{k}/col"] = j
+    for k, (nr, nc) in enumerate([(6, 6), (40, 8), (8, 40), (100, 10)]):
+        c = rng.randint(11, f"lsapint/{k}", nr * nc, 4).reshape(nr, nc).astype(np.float64)
+        i, j = linear_sum_assignment(c)
+        res[f"t{k}/cost"] = c; res[f"t{k}/row"] = i; res[f"t{k}/col"] = j
+    np.savez_compressed(os.path.join(HERE, "lsap_cases.npz"), **res)
+    print("lsap cases:", len(res) // 3)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["f1", "f3", "f5", "lsap", "f2", "f4"]
+    for w in which:
+        globals()[w]()
