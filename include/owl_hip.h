@@ -1,0 +1,77 @@
+/*
+ * libowlhip -- C ABI of the MI355X-native OWL-ViT train path (gfx950 / CDNA4).
+ *
+ * The reference (stevebottos/owl-vit-object-detection) has NO native layer: its hot path is Python
+ * over stock aten kernels.  The drop-in boundary is therefore the Python
+ * call surface (`model(image)`, `PushPullLoss(...)`, `HungarianMatcher(...)`); this header is the
+ * thin C ABI underneath it.  Each entry point names the reference arithmetic it replaces
+ * (`ref:` = path under the reference repo, `HF5:` = transformers/models/owlvit/modeling_owlvit.py).
+ *
+ * Conventions:
+ *   - every function enqueues on the hipStream_t passed as `stream` and returns immediately;
+ *     0 = OK, <0 = error (message via owl_last_error(), thread-local);
+ *   - the library never allocates or frees device memory; all pointers are device pointers to
+ *     contiguous row-major buffers owned by the caller; outputs are pre-allocated;
+ *   - bf16 buffers are passed as `void*` (raw 16-bit words), f32 as `float*`;
+ *   - activations are laid out [B * Tp, width] with Tp = tokens padded to a multiple of 8 per
+ *     image (class token first); allocations are padded to a multiple of 128 rows.
+ *
+ * The prototypes below are parsed by owl_vit_object_detection_amd/_lib.py to build the ctypes
+ * signatures -- keep one prototype per statement, plain C types only.
+ */
+#ifndef OWL_HIP_H
+#define OWL_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- runtime ---------------------------------------------------------------------------------- */
+const char* owl_last_error(void);
+int owl_abi_version(void);
+
+/* ---- GEMM  C[M,N] = A[M,K] . W[N,K]^T with fused epilogue ---------------------------------------
+ * replaces aten::addmm/mm under HF5:437-439,457 (q/k/v/out proj), HF5:472,474 (fc1/fc2),
+ * HF5:994-997 (box head dense0/1), ref src/models.py:25 (class dense0) and their autograd forms.
+ * epi: 0 bias->bf16 | 1 bias+quick_gelu->bf16 (aux = pre-activation) | 2 bias+erf-gelu->bf16 |
+ *      3 resid+acc+bias->f32 | 4 alpha*acc(+bias)->f32 | 5 atomicAdd f32 (split-K) |
+ *      6 per-head transposed bf16 out_t[b][n][t] (m = b*Tp + t) | 8 acc*quick_gelu'(aux)->bf16 |
+ *      9 acc*gelu'(aux)->bf16 | 10 out f32 += acc.
+ * a_rows / w_rows clamp the tile loads; M, N guard the stores; K % 64 == 0.                      */
+int owl_gemm_nt_bf16(void* stream, int epi, const void* A, int64_t lda, int64_t a_rows, const void* W, int64_t ldw, int64_t w_rows, const float* bias, void* out, int64_t ldo, const float* resid, void* aux, int64_t ld_aux, int64_t M, int64_t N, int64_t K, float alpha, int splits, int64_t Tp);
+
+/* ---- patch embedding (HF5:282-288 Conv2d k=s=patch, no bias; HF5:336-343 flatten + positions) ----
+ * im2row-free: the A-operand loader gathers 16-byte runs of each patch row straight from the
+ * bf16 image [B,3,S,S] into LDS.  x_out[b*Tp + 1 + p, :] = W_pe . vec(patch) + pos[1+p, :].      */
+int owl_patch_embed_bf16(void* stream, const void* image_bf16, const void* w_pe, const float* pos, float* x_out, int64_t B, int64_t S, int64_t ps, int64_t D, int64_t Tp);
+/* class-token rows x[b*Tp, :] = class_embedding + pos[0, :]  (HF5:338-343)                        */
+int owl_cls_rows(void* stream, float* x, const float* cls, const float* pos, int64_t B, int64_t Tp, int64_t D);
+
+/* ---- LayerNorm (HF5:484-486, 721-723; eps 1e-5).  out bf16 or f32 (may alias x); stats = (mean,rstd) */
+int owl_layernorm_fwd(void* stream, const float* x, const float* gamma, const float* beta, void* out, int out_bf16, float* stats, int64_t rows, int64_t D, float eps);
+
+/* ---- fused self-attention forward (HF5:377-402): softmax(Q K^T * scale) V, dh = 64 -----------------
+ * q, k row-major [B*Tp, ld_qk] (head h at column h*64); vt = V^T per head [B][..][64][Tp] as written
+ * by epilogue 6; out row-major [B*Tp, ld_out]; lse optional [B,H,Tp] (log2 domain).               */
+int owl_attention_fwd_bf16(void* stream, const void* q, const void* k, int64_t ld_qk, const void* vt, int64_t vt_img_stride, void* out, int64_t ld_out, float* lse, int64_t B, int64_t H, int64_t T, int64_t Tp, float scale);
+
+/* ---- post_layernorm on all tokens + class-token merge + post_post_layernorm (ref src/models.py:80-86) */
+int owl_merge_ln_fwd(void* stream, const float* x, const float* g1, const float* b1, const float* g2, const float* b2, float* cls_ln, void* feats_bf16, float* stats1, float* stats2, int64_t B, int64_t P, int64_t Tp, int64_t D, float eps);
+
+/* ---- heads -------------------------------------------------------------------------------------- */
+/* qhat = Q/|Q| + 1e-6 (ref src/models.py:31-33, eps placement literal); padded to 32 rows        */
+int owl_query_normalize(void* stream, const float* queries, float* qhat32, float* qnorm, int64_t nq, int64_t Dt);
+/* sims = max over 3 prompts of (e/(|e|+1e-6)) . qhat (ref src/models.py:25-36); f32 MFMA            */
+int owl_class_sims_fwd(void* stream, const float* e, const float* qhat32, float* sims, unsigned char* argmax, float* inv_norm, int64_t rows, int64_t Dt, int64_t C);
+/* dense2 + box bias + sigmoid + center_to_corners (HF5:998, 1071-1104; ref src/models.py:70-73)   */
+int owl_box_final_fwd(void* stream, const void* h_bf16, const float* w2, const float* b2, const float* box_bias, float* boxes, float* sig_out, int64_t rows, int64_t P, int64_t D);
+
+/* ---- utilities ------------------------------------------------------------------------------------ */
+int owl_cast_f32_bf16(void* stream, const float* in, void* out, int64_t n);
+int owl_transpose_bf16(void* stream, const void* in, int64_t ld_in, void* out, int64_t ld_out, int64_t R, int64_t C);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OWL_HIP_H */

@@ -1,0 +1,100 @@
+"""ctypes binding of libowlhip.so -- the C ABI declared in include/owl_hip.h.
+
+The argtypes are parsed from the header itself so the binding cannot drift from it.  There is NO
+fallback: if the shared library is missing or a symbol is absent this module raises, and every op
+in the package fails loudly (the product path never routes through the oracle or any CPU path).
+"""
+import ctypes
+import os
+import re
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+HEADER = os.path.join(_ROOT, "include", "owl_hip.h")
+LIB_PATH = os.path.join(_PKG, "libowlhip.so")
+
+_CTYPES = {
+    "void*": ctypes.c_void_p, "const void*": ctypes.c_void_p,
+    "float*": ctypes.c_void_p, "const float*": ctypes.c_void_p,
+    "double*": ctypes.c_void_p, "const double*": ctypes.c_void_p,
+    "unsigned char*": ctypes.c_void_p, "const unsigned char*": ctypes.c_void_p,
+    "int*": ctypes.c_void_p, "const int*": ctypes.c_void_p,
+    "int64_t*": ctypes.c_void_p, "const int64_t*": ctypes.c_void_p,
+    "int64_t": ctypes.c_int64, "int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double,
+}
+_RET = {"int": ctypes.c_int, "const char*": ctypes.c_char_p}
+
+
+def parse_header(path: str = HEADER):
+    """-> {name: (restype, [(ctype_name, arg_name), ...])} for every prototype in the header."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", " ", src)
+    protos = {}
+    for m in re.finditer(r"\b(int|const char\*)\s+(owl_\w+)\s*\(([^)]*)\)\s*;", src):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        parsed = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                mm = re.match(r"(.*?)(\w+)$", a)
+                ty = mm.group(1).strip().replace(" *", "*")
+                parsed.append((ty, mm.group(2)))
+        protos[name] = (ret, parsed)
+    return protos
+
+
+class OwlLibError(RuntimeError):
+    pass
+
+
+_lib = None
+_protos = None
+
+
+def load():
+    global _lib, _protos
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OwlLibError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or owl-vit-object-detection_amd/csrc/build.sh). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    _protos = parse_header()
+    for name, (ret, args) in _protos.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise OwlLibError(f"libowlhip.so does not export `{name}` declared in include/owl_hip.h") from e
+        fn.restype = _RET[ret]
+        fn.argtypes = [_CTYPES[t] for t, _ in args]
+    _lib = lib
+    return lib
+
+
+def protos():
+    load()
+    return _protos
+
+
+def last_error() -> str:
+    return load().owl_last_error().decode()
+
+
+def call(name: str, *args):
+    """Invoke a C-ABI entry; torch tensors are passed as device pointers; raises on rc != 0."""
+    lib = load()
+    fn = getattr(lib, name)
+    conv = []
+    for a in args:
+        if a is None:
+            conv.append(None)
+        elif hasattr(a, "data_ptr"):
+            conv.append(a.data_ptr())
+        else:
+            conv.append(a)
+    rc = fn(*conv)
+    if rc != 0:
+        raise OwlLibError(f"{name} failed (rc={rc}): {last_error()}")
+    return rc

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Build libowlhip.so (gfx950 only) in-tree.  hipcc cross-compiles without a GPU.
+set -e
+cd "$(dirname "$0")"
+ARCH=${OWL_ARCH:-gfx950}
+FLAGS="--offload-arch=${ARCH} -O3 -std=c++17 -fPIC -Wno-unused-value"
+mkdir -p build
+objs=""
+for f in *.hip; do
+  o=build/${f%.hip}.o
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ common.h -nt "$o" ]; then
+    extra=""
+    case "$f" in loss.hip) extra="-ffp-contract=off";; esac
+    hipcc $FLAGS $extra -c "$f" -o "$o" &
+  fi
+  objs="$objs $o"
+done
+wait
+g++ -O2 -fPIC -std=c++17 -c runtime.cpp -o build/runtime.o
+hipcc --offload-arch=${ARCH} -shared -fPIC -o ../libowlhip.so $objs build/runtime.o
+echo "built $(cd .. && pwd)/libowlhip.so"

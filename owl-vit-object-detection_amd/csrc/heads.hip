@@ -1,0 +1,146 @@
+// Detection heads' tails.
+//  * box_final : dense2 (D -> 4) + box bias + sigmoid + cxcywh -> xyxy
+//                (HF5:998 dense2, HF5:1071-1104 bias, ref src/models.py:70-73).
+//  * class_sims: e / (|e| + 1e-6) . (Q/|Q| + 1e-6)^T, MaxPool1d(3,3) over the query axis
+//                (ref src/models.py:24-38; eps placement reproduced literally).  The [rows,Dt]x[Dt,32]
+//                contraction runs on the exact-f32 matrix core (v_mfma_f32_32x32x2_f32) so the cosine
+//                similarities carry f32 accuracy into the matcher / loss.
+#include "common.h"
+
+// ---- query bank normalisation: qhat[j,:] = Q[j,:]/|Q[j,:]| + 1e-6 ; rows >= nq zero ---------------
+__global__ __launch_bounds__(64) void qhat_kernel(const float* __restrict__ q, float* qhat, float* qnorm, int nq, int Dt) {
+    const int j = blockIdx.x, lane = threadIdx.x;
+    if (j >= nq) {
+        for (int k = lane; k < Dt; k += 64) qhat[(int64_t)j * Dt + k] = 0.f;
+        return;
+    }
+    float s = 0.f;
+    for (int k = lane; k < Dt; k += 64) { const float v = q[(int64_t)j * Dt + k]; s += v * v; }
+    const float n = sqrtf(wave_sum(s));
+    if (lane == 0 && qnorm) qnorm[j] = n;
+    for (int k = lane; k < Dt; k += 64) qhat[(int64_t)j * Dt + k] = q[(int64_t)j * Dt + k] / n + 1e-6f;
+}
+
+extern "C" int owl_query_normalize(void* stream, const float* queries, float* qhat32, float* qnorm, int64_t nq, int64_t Dt) {
+    OWL_CHECK_ARG(queries && qhat32 && nq >= 1 && nq <= 32, "owl_query_normalize: need 1 <= queries <= 32 (got %lld)", (long long)nq);
+    hipLaunchKernelGGL(qhat_kernel, dim3(32), dim3(64), 0, (hipStream_t)stream, queries, qhat32, qnorm, (int)nq, (int)Dt);
+    OWL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- class sims ---------------------------------------------------------------------------------
+// block = 4 waves, each wave 32 rows.  qhat [32][Dt] f32 lives in LDS (row stride Dt+4 words).
+__global__ __launch_bounds__(256) void class_sims_kernel(const float* __restrict__ e, const float* __restrict__ qhat,
+                                                         float* sims, unsigned char* argmax, float* inv_norm,
+                                                         int64_t rows, int Dt, int C) {
+    extern __shared__ __attribute__((aligned(16))) float lq[];
+    const int ldq = Dt + 4;
+    float* lnorm = lq + 32 * ldq;   // [4 waves][32]
+    for (int i = threadIdx.x; i < 32 * (Dt >> 2); i += 256) {
+        const int j = i / (Dt >> 2), k4 = i - j * (Dt >> 2);
+        *(float4*)(lq + j * ldq + k4 * 4) = ((const float4*)(qhat + (int64_t)j * Dt))[k4];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hi = lane >> 5;
+    const int64_t r0 = ((int64_t)blockIdx.x * 4 + w) * 32;
+    int64_t row = r0 + (lane & 31);
+    const bool valid = row < rows;
+    if (!valid) row = rows - 1;
+    const float* er = e + row * Dt;
+    const float* qr = lq + (lane & 31) * ldq;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    float ss = 0.f;
+    // contraction split: lanes hi=0 take k in [c*128, c*128+64), hi=1 take [c*128+64, c*128+128)
+    for (int c0 = 0; c0 < Dt; c0 += 128) {
+        // no divergence around MFMAs: a half-chunk past Dt (Dt % 128 == 64) feeds zeros instead
+        const bool act = (c0 + hi * 64) < Dt;
+        const int kb = act ? c0 + hi * 64 : 0;
+        const float msk = act ? 1.f : 0.f;
+#pragma unroll 4
+        for (int s4 = 0; s4 < 16; s4++) {
+            float4 a = *(const float4*)(er + kb + s4 * 4);
+            const float4 b = *(const float4*)(qr + kb + s4 * 4);
+            a.x *= msk; a.y *= msk; a.z *= msk; a.w *= msk;
+            ss += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+        }
+    }
+    ss += __shfl_xor(ss, 32, 64);
+    const float inv = 1.0f / (sqrtf(ss) + 1e-6f);
+    if (hi == 0) {
+        lnorm[w * 32 + lane] = inv;
+        if (valid && inv_norm) inv_norm[row] = inv;
+    }
+    __syncthreads();
+    // acc[r]: row i = (r&3) + 8*(r>>2) + 4*hi, query j = lane&31.  Max over query triples via shuffles.
+    const int j = lane & 31;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const float v0 = acc[r] * lnorm[w * 32 + i];
+        const float v1 = __shfl_down(v0, 1, 64), v2 = __shfl_down(v0, 2, 64);
+        float best = v0; int arg = 0;
+        if (v1 > best) { best = v1; arg = 1; }
+        if (v2 > best) { best = v2; arg = 2; }
+        const int64_t orow = r0 + i;
+        if (j % 3 == 0 && j / 3 < C && orow < rows) {
+            sims[orow * C + j / 3] = best;
+            if (argmax) argmax[orow * C + j / 3] = (unsigned char)arg;
+        }
+    }
+}
+
+extern "C" int owl_class_sims_fwd(void* stream, const float* e, const float* qhat32, float* sims, unsigned char* argmax,
+                                  float* inv_norm, int64_t rows, int64_t Dt, int64_t C) {
+    OWL_CHECK_ARG(e && qhat32 && sims, "owl_class_sims_fwd: null pointer");
+    OWL_CHECK_ARG(Dt % 64 == 0 && 3 * C <= 32 && C >= 1, "owl_class_sims_fwd: Dt %% 64 == 0 and 3*C <= 32 required (Dt=%lld C=%lld)", (long long)Dt, (long long)C);
+    const size_t shmem = (size_t)(32 * (Dt + 4) + 128) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)class_sims_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
+    hipLaunchKernelGGL(class_sims_kernel, dim3((unsigned)((rows + 127) / 128)), dim3(256), shmem, (hipStream_t)stream, e, qhat32, sims, argmax, inv_norm, rows, (int)Dt, (int)C);
+    OWL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- box final ------------------------------------------------------------------------------------
+// one wave per row: 4 dot products over D (bf16 activations, f32 weights), + bias + box_bias[p],
+// sigmoid, cxcywh -> xyxy.  sig_out keeps sigma(.) for the backward.
+__global__ __launch_bounds__(256) void box_final_kernel(const bf16_t* __restrict__ h, const float* __restrict__ w2,
+                                                        const float* __restrict__ b2, const float* __restrict__ box_bias,
+                                                        float* boxes, float* sig_out, int64_t rows, int64_t P, int D) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int k = lane * 8; k < D; k += 512) {
+        const us8 hv = *(const us8*)(h + row * D + k);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const float x = bf2f(hv[e]);
+            a0 += x * w2[k + e]; a1 += x * w2[D + k + e]; a2 += x * w2[2 * D + k + e]; a3 += x * w2[3 * D + k + e];
+        }
+    }
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
+    if (lane == 0) {
+        const float* bb = box_bias + (row % P) * 4;
+        const float cx = 1.f / (1.f + expf(-(a0 + b2[0] + bb[0]))), cy = 1.f / (1.f + expf(-(a1 + b2[1] + bb[1])));
+        const float bw = 1.f / (1.f + expf(-(a2 + b2[2] + bb[2]))), bh = 1.f / (1.f + expf(-(a3 + b2[3] + bb[3])));
+        if (sig_out) *(float4*)(sig_out + row * 4) = make_float4(cx, cy, bw, bh);
+        *(float4*)(boxes + row * 4) = make_float4(cx - 0.5f * bw, cy - 0.5f * bh, cx + 0.5f * bw, cy + 0.5f * bh);
+    }
+}
+
+extern "C" int owl_box_final_fwd(void* stream, const void* h_bf16, const float* w2, const float* b2, const float* box_bias,
+                                 float* boxes, float* sig_out, int64_t rows, int64_t P, int64_t D) {
+    OWL_CHECK_ARG(h_bf16 && w2 && b2 && box_bias && boxes, "owl_box_final_fwd: null pointer");
+    OWL_CHECK_ARG(D % 8 == 0, "owl_box_final_fwd: D %% 8");
+    hipLaunchKernelGGL(box_final_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)h_bf16, w2, b2, box_bias, boxes, sig_out, rows, P, (int)D);
+    OWL_LAUNCH_CHECK();
+    return 0;
+}

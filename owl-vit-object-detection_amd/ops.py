@@ -1,0 +1,112 @@
+"""Thin Python wrappers over the C ABI (include/owl_hip.h): shape/dtype validation, stream, call.
+
+PyTorch is plumbing here (device memory + streams); every op below runs a hand-written HIP kernel
+from libowlhip.so and raises if the library is missing -- there is no eager fallback.
+"""
+import torch
+
+from . import _lib
+
+EPI_BIAS_BF16, EPI_QGELU_BF16, EPI_GELU_BF16, EPI_RESID_F32, EPI_F32, EPI_ATOMIC_F32 = 0, 1, 2, 3, 4, 5
+EPI_TRANS_BF16, EPI_PATCH_F32, EPI_DQGELU_BF16, EPI_DGELU_BF16, EPI_ACC_F32 = 6, 7, 8, 9, 10
+
+ROW_PAD = 128
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def pad_rows(n: int) -> int:
+    return (n + ROW_PAD - 1) // ROW_PAD * ROW_PAD
+
+
+def zeros_rows(rows: int, width: int, dtype, device) -> torch.Tensor:
+    """[pad_rows(rows), width] zero buffer (pad rows stay zero / finite by construction)."""
+    return torch.zeros(pad_rows(rows), width, dtype=dtype, device=device)
+
+
+def _chk(t, dtype, name):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise ValueError(f"{name} must be a device tensor")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+
+
+def gemm(epi, A, W, out, bias=None, resid=None, aux=None, M=None, N=None, K=None, lda=None, ldw=None, ldo=None,
+         ld_aux=0, a_rows=None, w_rows=None, alpha=1.0, splits=1, Tp=0):
+    """out = epilogue(A[M,K] @ W[N,K]^T).  A/W bf16; see include/owl_hip.h for epilogues."""
+    _chk(A, torch.bfloat16, "A"); _chk(W, torch.bfloat16, "W"); _chk(bias, torch.float32, "bias")
+    K = K if K is not None else A.shape[-1]
+    N = N if N is not None else W.shape[0]
+    M = M if M is not None else A.shape[0]
+    lda = lda if lda is not None else A.shape[-1]
+    ldw = ldw if ldw is not None else W.shape[-1]
+    ldo = ldo if ldo is not None else (out.shape[-1] if epi != EPI_TRANS_BF16 else 0)
+    a_rows = a_rows if a_rows is not None else A.shape[0]
+    w_rows = w_rows if w_rows is not None else W.shape[0]
+    if aux is not None and ld_aux == 0:
+        ld_aux = aux.shape[-1]
+    _lib.call("owl_gemm_nt_bf16", stream(), epi, A, lda, a_rows, W, ldw, w_rows, bias, out, ldo, resid, aux, ld_aux,
+              M, N, K, float(alpha), int(splits), int(Tp))
+    return out
+
+
+def patch_embed(image_bf16, w_pe, pos, x_out, B, S, ps, D, Tp):
+    _chk(image_bf16, torch.bfloat16, "image"); _chk(w_pe, torch.bfloat16, "w_pe"); _chk(pos, torch.float32, "pos")
+    _chk(x_out, torch.float32, "x_out")
+    _lib.call("owl_patch_embed_bf16", stream(), image_bf16, w_pe, pos, x_out, B, S, ps, D, Tp)
+
+
+def cls_rows(x, cls, pos, B, Tp, D):
+    _lib.call("owl_cls_rows", stream(), x, cls, pos, B, Tp, D)
+
+
+def layernorm(x, gamma, beta, out, rows, D, stats=None, eps=1e-5):
+    _chk(x, torch.float32, "x"); _chk(gamma, torch.float32, "gamma"); _chk(beta, torch.float32, "beta")
+    _lib.call("owl_layernorm_fwd", stream(), x, gamma, beta, out, 1 if out.dtype == torch.bfloat16 else 0, stats,
+              rows, D, float(eps))
+    return out
+
+
+def attention_fwd(q, k, ld_qk, vt, vt_img_stride, out, ld_out, lse, B, H, T, Tp, scale):
+    _lib.call("owl_attention_fwd_bf16", stream(), q, k, ld_qk, vt, vt_img_stride, out, ld_out, lse, B, H, T, Tp,
+              float(scale))
+    return out
+
+
+def merge_ln(x, g1, b1, g2, b2, cls_ln, feats, stats1, stats2, B, P, Tp, D, eps=1e-5):
+    _lib.call("owl_merge_ln_fwd", stream(), x, g1, b1, g2, b2, cls_ln, feats, stats1, stats2, B, P, Tp, D, float(eps))
+
+
+def query_normalize(queries, qhat32, qnorm, nq, Dt):
+    _chk(queries, torch.float32, "queries")
+    _lib.call("owl_query_normalize", stream(), queries, qhat32, qnorm, nq, Dt)
+
+
+def class_sims(e, qhat32, sims, argmax, inv_norm, rows, Dt, C):
+    _chk(e, torch.float32, "e")
+    _lib.call("owl_class_sims_fwd", stream(), e, qhat32, sims, argmax, inv_norm, rows, Dt, C)
+
+
+def box_final(h, w2, b2, box_bias, boxes, sig, rows, P, D):
+    _chk(h, torch.bfloat16, "h"); _chk(w2, torch.float32, "w2")
+    _lib.call("owl_box_final_fwd", stream(), h, w2, b2, box_bias, boxes, sig, rows, P, D)
+
+
+def cast_bf16(src, dst=None):
+    _chk(src, torch.float32, "src")
+    if dst is None:
+        dst = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
+    _lib.call("owl_cast_f32_bf16", stream(), src, dst, src.numel())
+    return dst
+
+
+def transpose_bf16(src, dst, R, C, ld_in=None, ld_out=None):
+    _lib.call("owl_transpose_bf16", stream(), src, ld_in if ld_in is not None else src.shape[-1], dst,
+              ld_out if ld_out is not None else dst.shape[-1], R, C)
+    return dst

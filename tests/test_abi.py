@@ -1,0 +1,40 @@
+"""CPU-side checks of the C-ABI boundary: the shared library loads and exports every symbol
+include/owl_hip.h declares (no compute calls without a GPU)."""
+import ctypes
+import os
+
+import pytest
+
+from owl_vit_object_detection_amd import _lib
+
+
+@pytest.fixture(scope="module")
+def built():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return _lib.load()
+
+
+def test_header_parses():
+    protos = _lib.parse_header()
+    assert "owl_gemm_nt_bf16" in protos and "owl_last_error" in protos
+    ret, args = protos["owl_gemm_nt_bf16"]
+    assert ret == "int" and args[0] == ("void*", "stream") and len(args) == 20
+    for name, (ret, args) in protos.items():
+        for ty, _ in args:
+            assert ty in _lib._CTYPES, (name, ty)
+
+
+def test_library_exports_every_declared_symbol(built):
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in _lib.parse_header():
+        assert hasattr(lib, name), f"{name} declared in include/owl_hip.h but not exported"
+    assert built.owl_abi_version() >= 1
+
+
+def test_argument_validation_sets_error_without_gpu(built):
+    # argument checks run before any HIP call: safe without a device
+    with pytest.raises(_lib.OwlLibError, match="null pointer"):
+        _lib.call("owl_gemm_nt_bf16", None, 0, None, 0, 0, None, 0, 0, None, None, 0, None, None, 0, 1, 4, 64, 1.0, 1, 0)
+    assert "null pointer" in _lib.last_error()

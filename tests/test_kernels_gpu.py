@@ -1,0 +1,240 @@
+"""Per-kernel numerics on a real MI355X: each HIP kernel (called through the C ABI) against a plain
+PyTorch fp32 reference of the same op on the same (bf16-rounded) inputs."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from owl_vit_object_detection_amd import ops  # noqa: E402
+
+DEV = "cuda"
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def report(name, got, ref, atol, rtol):
+    got = got.float(); ref = ref.float()
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = err > tol
+    if bad.any():
+        idx = bad.nonzero()[:8].tolist()
+        raise AssertionError(f"{name}: {int(bad.sum())}/{bad.numel()} off; max err {float(err.max()):.4g} "
+                             f"(ref max {float(ref.abs().max()):.4g}); first bad idx {idx}; "
+                             f"got {got[bad][:4].tolist()} ref {ref[bad][:4].tolist()}")
+
+
+def qgelu(x):
+    return x * torch.sigmoid(1.702 * x)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 192, 128), (2048, 768, 768), (128, 128, 64), (1000, 3072, 256)])
+def test_gemm_bias_bf16(M, N, K):
+    A = ops.zeros_rows(M, K, torch.bfloat16, DEV)
+    A[:M] = rnd(M, K).bfloat16()
+    W = rnd(N, K, scale=0.1, seed=1).bfloat16()
+    bias = rnd(N, seed=2)
+    out = ops.zeros_rows(M, N, torch.bfloat16, DEV)
+    ops.gemm(ops.EPI_BIAS_BF16, A, W, out, bias=bias, M=M)
+    ref = A[:M].float() @ W.float().t() + bias
+    report("gemm bias", out[:M], ref, 2e-2, 1e-2)
+    assert float(out[M:].abs().max()) == 0.0 if out.shape[0] > M else True
+
+
+def test_gemm_epilogues():
+    M, N, K = 300, 256, 192
+    A = ops.zeros_rows(M, K, torch.bfloat16, DEV); A[:M] = rnd(M, K).bfloat16()
+    W = rnd(N, K, scale=0.1, seed=1).bfloat16()
+    bias = rnd(N, seed=2)
+    acc = A[:M].float() @ W.float().t()
+    u = acc + bias
+    # quick-gelu with pre-activation
+    out = ops.zeros_rows(M, N, torch.bfloat16, DEV); aux = ops.zeros_rows(M, N, torch.bfloat16, DEV)
+    ops.gemm(ops.EPI_QGELU_BF16, A, W, out, bias=bias, aux=aux, M=M)
+    report("qgelu", out[:M], qgelu(u), 2e-2, 1e-2); report("qgelu aux", aux[:M], u, 2e-2, 1e-2)
+    # erf gelu
+    out.zero_()
+    ops.gemm(ops.EPI_GELU_BF16, A, W, out, bias=bias, M=M)
+    report("gelu", out[:M], F.gelu(u), 2e-2, 1e-2)
+    # residual f32 (in place)
+    x = ops.zeros_rows(M, N, torch.float32, DEV); x[:M] = rnd(M, N, seed=5)
+    ref = x[:M].clone() + u
+    ops.gemm(ops.EPI_RESID_F32, A, W, x, bias=bias, resid=x, M=M)
+    report("resid", x[:M], ref, 1e-3, 1e-4)
+    # f32 with alpha, no bias
+    o32 = ops.zeros_rows(M, N, torch.float32, DEV)
+    ops.gemm(ops.EPI_F32, A, W, o32, M=M, alpha=0.5)
+    report("f32 alpha", o32[:M], 0.5 * acc, 1e-3, 1e-4)
+    # accumulate
+    ops.gemm(ops.EPI_ACC_F32, A, W, o32, M=M)
+    report("acc", o32[:M], 1.5 * acc, 1e-3, 1e-4)
+    # split-K atomic
+    o32.zero_()
+    ops.gemm(ops.EPI_ATOMIC_F32, A, W, o32, M=M, splits=3)
+    report("atomic", o32[:M], acc, 1e-3, 1e-4)
+    # activation-derivative epilogues
+    upre = ops.zeros_rows(M, N, torch.bfloat16, DEV); upre[:M] = rnd(M, N, seed=9).bfloat16()
+    uf = upre[:M].float()
+    uf.requires_grad_(True)
+    (g1,) = torch.autograd.grad(qgelu(uf).sum(), uf)
+    (g2,) = torch.autograd.grad(F.gelu(uf).sum(), uf)
+    out.zero_()
+    ops.gemm(ops.EPI_DQGELU_BF16, A, W, out, aux=upre, M=M)
+    report("dqgelu", out[:M], acc * g1, 2e-2, 1e-2)
+    ops.gemm(ops.EPI_DGELU_BF16, A, W, out, aux=upre, M=M)
+    report("dgelu", out[:M], acc * g2, 2e-2, 1e-2)
+
+
+def test_gemm_transposed_epilogue():
+    B, Tp, T, K, N = 2, 152, 150, 128, 192          # 3 heads of 64
+    M = B * Tp
+    A = ops.zeros_rows(M, K, torch.bfloat16, DEV); A[:M] = rnd(M, K).bfloat16()
+    W = rnd(N, K, scale=0.1, seed=1).bfloat16(); bias = rnd(N, seed=2)
+    out = torch.zeros(B, N, Tp, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(ops.EPI_TRANS_BF16, A, W, out, bias=bias, M=M, Tp=Tp)
+    ref = (A[:M].float() @ W.float().t() + bias).view(B, Tp, N).permute(0, 2, 1)
+    report("trans", out, ref, 2e-2, 1e-2)
+
+
+def test_patch_embed():
+    B, S, ps, D = 3, 96, 16, 128
+    G = S // ps; P = G * G; T = P + 1; Tp = (T + 7) // 8 * 8
+    img = rnd(B, 3, S, S).bfloat16()
+    w = rnd(D, 3, ps, ps, scale=0.05, seed=1).bfloat16()
+    pos = rnd(T, D, seed=2); cls = rnd(D, seed=3)
+    x = ops.zeros_rows(B * Tp, D, torch.float32, DEV)
+    ops.patch_embed(img, w.view(D, -1).contiguous(), pos, x, B, S, ps, D, Tp)
+    ops.cls_rows(x, cls, pos, B, Tp, D)
+    pe = F.conv2d(img.float(), w.float(), stride=ps).flatten(2).transpose(1, 2)
+    ref = torch.cat([cls.expand(B, 1, D), pe], 1) + pos
+    got = x[: B * Tp].view(B, Tp, D)[:, :T]
+    report("patch embed", got, ref, 1e-3, 1e-3)
+    assert float(x[: B * Tp].view(B, Tp, D)[:, T:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("D", [128, 768, 1024])
+def test_layernorm(D):
+    rows = 77
+    x = rnd(rows, D, scale=2.0) + 0.3
+    g = 1 + 0.1 * rnd(D, seed=1); b = 0.1 * rnd(D, seed=2)
+    ref = F.layer_norm(x, (D,), g, b, 1e-5)
+    out = torch.zeros(rows, D, dtype=torch.bfloat16, device=DEV); stats = torch.zeros(rows, 2, device=DEV)
+    ops.layernorm(x, g, b, out, rows, D, stats)
+    report("ln bf16", out, ref, 2e-2, 1e-2)
+    report("ln mean", stats[:, 0], x.mean(-1), 1e-5, 1e-5)
+    report("ln rstd", stats[:, 1], 1 / torch.sqrt(x.var(-1, unbiased=False) + 1e-5), 1e-5, 1e-4)
+    x2 = x.clone()
+    ops.layernorm(x2, g, b, x2, rows, D)          # in place f32
+    report("ln f32 inplace", x2, ref, 1e-5, 1e-5)
+
+
+def test_merge_ln():
+    B, P, D = 2, 36, 128
+    T = P + 1; Tp = 40
+    x = torch.zeros(B * Tp, D, device=DEV); xv = x.view(B, Tp, D)
+    xv[:, :T] = rnd(B, T, D, scale=1.5)
+    g1 = 1 + 0.1 * rnd(D, seed=1); b1 = 0.1 * rnd(D, seed=2); g2 = 1 + 0.1 * rnd(D, seed=3); b2 = 0.1 * rnd(D, seed=4)
+    y = F.layer_norm(xv[:, :T], (D,), g1, b1, 1e-5)
+    ref = F.layer_norm(y[:, 1:] * y[:, :1], (D,), g2, b2, 1e-5)
+    cls_ln = torch.zeros(B, D, device=DEV); feats = ops.zeros_rows(B * P, D, torch.bfloat16, DEV)
+    s1 = torch.zeros(B * Tp, 2, device=DEV); s2 = torch.zeros(B * P, 2, device=DEV)
+    ops.merge_ln(x, g1, b1, g2, b2, cls_ln, feats, s1, s2, B, P, Tp, D)
+    report("merge feats", feats[: B * P].view(B, P, D), ref, 2e-2, 1e-2)
+    report("cls_ln", cls_ln, y[:, 0], 1e-5, 1e-5)
+
+
+def _attn_case(B, H, T, seed):
+    Tp = (T + 7) // 8 * 8
+    D = H * 64
+    M = B * Tp
+    qkv = ops.zeros_rows(M, 3 * D, torch.bfloat16, DEV)
+    v = qkv[:M].view(B, Tp, 3 * D)
+    v[:, :T] = rnd(B, T, 3 * D, scale=1.0, seed=seed).bfloat16()
+    q = v[:, :T, :D].float().view(B, T, H, 64).transpose(1, 2)
+    k = v[:, :T, D:2 * D].float().view(B, T, H, 64).transpose(1, 2)
+    vv = v[:, :T, 2 * D:].float().view(B, T, H, 64).transpose(1, 2)
+    # V^T buffer [B][H][64][Tp] (+ slack for the last tile's over-read)
+    vt_flat = torch.zeros(B * H * 64 * Tp + 128, dtype=torch.bfloat16, device=DEV)
+    vt = vt_flat[: B * H * 64 * Tp].view(B, H, 64, Tp)
+    vt[:, :, :, :T] = vv.transpose(2, 3).bfloat16()
+    att = torch.softmax(q @ k.transpose(2, 3) * 0.125, -1)
+    ref = (att @ vv).transpose(1, 2).reshape(B, T, D)
+    lse_ref = torch.logsumexp(q @ k.transpose(2, 3) * 0.125, -1) / math.log(2.0)
+    out = ops.zeros_rows(M, D, torch.bfloat16, DEV)
+    lse = torch.zeros(B, H, Tp, device=DEV)
+    ops.attention_fwd(qkv, qkv[:, D:], 3 * D, vt_flat, H * 64 * Tp, out, D, lse, B, H, T, Tp, 0.125)
+    report(f"attn T={T}", out[:M].view(B, Tp, D)[:, :T], ref, 2e-2, 2e-2)
+    report(f"lse T={T}", lse[:, :, :T], lse_ref, 2e-3, 1e-3)
+
+
+@pytest.mark.parametrize("B,H,T", [(2, 2, 37), (1, 3, 200), (2, 1, 577), (1, 12, 2305)])
+def test_attention_fwd(B, H, T):
+    _attn_case(B, H, T, seed=T)
+
+
+def test_attention_fwd_spiked_scores():
+    """Large score spread: one key dominating forces big running-max jumps between KV tiles."""
+    B, H, T = 1, 1, 300
+    Tp, D, M = 304, 64, 304
+    qkv = ops.zeros_rows(M, 3 * D, torch.bfloat16, DEV)
+    v = qkv[:M].view(B, Tp, 3 * D)
+    x = rnd(B, T, 3 * D, seed=3)
+    x[0, 250, D:2 * D] *= 12.0      # key 250 spikes (third KV tile)
+    x[0, 10, :D] *= 6.0
+    v[:, :T] = x.bfloat16()
+    q = v[:, :T, :D].float(); k = v[:, :T, D:2 * D].float(); vv = v[:, :T, 2 * D:].float()
+    vt_flat = torch.zeros(64 * Tp + 128, dtype=torch.bfloat16, device=DEV)
+    vt_flat[: 64 * Tp].view(64, Tp)[:, :T] = vv[0].t().bfloat16()
+    ref = torch.softmax(q @ k.transpose(1, 2) * 0.125, -1) @ vv
+    out = ops.zeros_rows(M, D, torch.bfloat16, DEV)
+    ops.attention_fwd(qkv, qkv[:, D:], 3 * D, vt_flat, 64 * Tp, out, D, None, B, H, T, Tp, 0.125)
+    report("attn spiked", out[:T], ref[0], 3e-2, 2e-2)
+
+
+@pytest.mark.parametrize("Dt,C", [(64, 4), (512, 10), (768, 10), (128, 1)])
+def test_class_sims(Dt, C):
+    rows = 300
+    e = rnd(rows, Dt, scale=0.7)
+    Q = rnd(3 * C, Dt, seed=4)
+    qhat = torch.zeros(32, Dt, device=DEV); qn = torch.zeros(32, device=DEV)
+    ops.query_normalize(Q, qhat, qn, 3 * C, Dt)
+    qh_ref = Q / torch.linalg.norm(Q, dim=-1, keepdim=True) + 1e-6
+    report("qhat", qhat[: 3 * C], qh_ref, 1e-6, 1e-5)
+    assert float(qhat[3 * C:].abs().max()) == 0.0
+    en = e / (torch.linalg.norm(e, dim=-1, keepdim=True) + 1e-6)
+    s = en @ qh_ref.t()
+    ref = F.max_pool1d(s[None], 3, 3)[0]
+    sims = torch.zeros(rows, C, device=DEV); am = torch.zeros(rows, C, dtype=torch.uint8, device=DEV)
+    inv = torch.zeros(rows, device=DEV)
+    ops.class_sims(e, qhat, sims, am, inv, rows, Dt, C)
+    report("sims", sims, ref, 2e-5, 1e-4)
+    report("argmax", am.float(), s.view(rows, C, 3).argmax(-1).float(), 0, 0)
+    report("inv_norm", inv, 1 / (torch.linalg.norm(e, dim=-1) + 1e-6), 1e-6, 1e-5)
+
+
+def test_box_final():
+    B, P, D = 2, 36, 128
+    rows = B * P
+    h = rnd(rows, D).bfloat16()
+    w2 = rnd(4, D, scale=0.1, seed=1); b2 = rnd(4, seed=2); bb = rnd(P, 4, seed=3)
+    boxes = torch.zeros(rows, 4, device=DEV); sig = torch.zeros(rows, 4, device=DEV)
+    ops.box_final(h, w2, b2, bb, boxes, sig, rows, P, D)
+    s = torch.sigmoid(h.float() @ w2.t() + b2 + bb.repeat(B, 1))
+    ref = torch.stack([s[:, 0] - 0.5 * s[:, 2], s[:, 1] - 0.5 * s[:, 3], s[:, 0] + 0.5 * s[:, 2], s[:, 1] + 0.5 * s[:, 3]], -1)
+    report("sig", sig, s, 1e-5, 1e-5); report("boxes", boxes, ref, 1e-5, 1e-5)
+
+
+def test_cast_and_transpose():
+    x = rnd(1000, 37)
+    y = ops.cast_bf16(x.contiguous())
+    assert torch.equal(y, x.bfloat16())
+    a = rnd(200, 136).bfloat16()
+    t = torch.zeros(136, 200, dtype=torch.bfloat16, device=DEV)
+    ops.transpose_bf16(a, t, 200, 136)
+    assert torch.equal(t, a.t().contiguous())
