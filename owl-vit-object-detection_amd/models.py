@@ -1,0 +1,288 @@
+"""OWL-ViT vision path on MI355X -- host-side mirror of reference src/models.py.
+
+Call surface kept from the reference:
+    model = load_model(labelmap, device)            # ref src/models.py:149
+    pred_boxes, None, pred_sims, None = model(image) # ref src/models.py:98-119
+    model.parameters() / .train() / .eval() / named_parameters() with the reference's names, so the
+    freeze rule (ref src/models.py:173-184) and `torch.optim.AdamW(model.parameters(), ...)`
+    (ref main.py:56-60) work unchanged.
+
+Everything below that surface is new: the forward and backward are sequences of hand-written HIP
+kernels (libowlhip.so, C ABI in include/owl_hip.h) driven from one coarse autograd.Function; PyTorch
+only owns memory, streams and the autograd edge.  Activations are bf16 with an f32 residual stream;
+trainable parameters are f32 views into ONE flat bucket (and their grads into one flat grad bucket,
+which is what the single RCCL all-reduce per step operates on -- SURVEY.md section 8e).
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops, weights as W
+from .config import OwlConfig, get_config
+
+
+def box_bias_table(grid: int) -> torch.Tensor:
+    """HF5:1071-1104 `compute_box_bias` for a square grid (computed once on the host, as HF keeps
+    it as a buffer): [P,4] f32, p = y*W + x."""
+    coords = torch.arange(1, grid + 1, dtype=torch.float32)
+    xx, yy = torch.meshgrid(coords, coords, indexing="xy")
+    bc = torch.stack((xx, yy), dim=-1)
+    bc[..., 0] /= grid
+    bc[..., 1] /= grid
+    bc = torch.clip(bc.view(-1, 2), 0.0, 1.0)
+    coord_bias = torch.log(bc + 1e-4) - torch.log1p(-bc + 1e-4)
+    size = torch.full_like(coord_bias, 1.0)
+    size[..., 0] /= grid
+    size[..., 1] /= grid
+    size_bias = torch.log(size + 1e-4) - torch.log1p(-size + 1e-4)
+    return torch.cat([coord_bias, size_bias], dim=-1).contiguous()
+
+
+class _Node(nn.Module):
+    """Bare container so that parameter names match the reference module tree."""
+
+
+def _flat_order(cfg: OwlConfig):
+    """Order of the trainable tensors inside the flat bucket (q,k,v adjacent -> fused views)."""
+    tl = f"backbone.encoder.layers.{cfg.trainable_layer()}."
+    names = ["queries"]
+    names += [tl + f"self_attn.{p}_proj.weight" for p in "qkv"] + [tl + f"self_attn.{p}_proj.bias" for p in "qkv"]
+    names += [tl + "self_attn.out_proj.weight", tl + "self_attn.out_proj.bias", tl + "layer_norm1.weight", tl + "layer_norm1.bias",
+              tl + "mlp.fc1.weight", tl + "mlp.fc1.bias", tl + "mlp.fc2.weight", tl + "mlp.fc2.bias",
+              tl + "layer_norm2.weight", tl + "layer_norm2.bias"]
+    names += ["backbone.post_layernorm.weight", "backbone.post_layernorm.bias", "post_post_layernorm.weight",
+              "post_post_layernorm.bias", "class_predictor.dense0.weight", "class_predictor.dense0.bias",
+              "box_head.dense0.weight", "box_head.dense0.bias", "box_head.dense1.weight", "box_head.dense1.bias",
+              "box_head.dense2.weight", "box_head.dense2.bias"]
+    return names
+
+
+class OwlViT(nn.Module):
+    """Vision-only OWL-ViT with a learnable query bank (ref src/models.py:41-119)."""
+
+    def __init__(self, cfg: OwlConfig, state: "dict[str, np.ndarray]", device="cuda"):
+        super().__init__()
+        self.cfg = cfg
+        self.device_ = torch.device(device)
+        if cfg.head_dim != 64:
+            raise ValueError("attention kernels are built for head_dim = 64")
+        shapes = W.param_shapes(cfg)
+        missing = set(shapes) - set(state)
+        if missing:
+            raise KeyError(f"missing parameters: {sorted(missing)[:4]} ...")
+        order = _flat_order(cfg)
+        assert set(order) == {n for n in shapes if W.is_trainable(n)}, "flat order must cover the trainable set"
+
+        # ---- flat trainable bucket (f32) + grad bucket; every tensor starts 8-element aligned ----
+        offs, off = OrderedDict(), 0
+        for n in order:
+            offs[n] = off
+            off += (int(np.prod(shapes[n])) + 7) // 8 * 8
+        self.flat_numel = off
+        self.flat_offsets = offs
+        self.flat_param = torch.zeros(off, dtype=torch.float32, device=self.device_)
+        self.flat_grad = torch.zeros(off, dtype=torch.float32, device=self.device_)
+        self.flat_bf16 = torch.zeros(off, dtype=torch.bfloat16, device=self.device_)
+
+        # ---- parameter tree with the reference's names ---------------------------------------------
+        self._pnames = []
+        for name, shape in shapes.items():
+            src = torch.as_tensor(np.asarray(state[name]), dtype=torch.float32)
+            assert tuple(src.shape) == tuple(shape), name
+            if name in offs:
+                view = self.flat_param[offs[name]: offs[name] + src.numel()].view(shape)
+                view.copy_(src)
+                p = nn.Parameter(view, requires_grad=True)
+            else:
+                p = nn.Parameter(src.to(self.device_), requires_grad=False)
+            self._attach(name, p)
+            self._pnames.append(name)
+        self._byname = dict(self.named_parameters())
+        assert list(self._byname.keys()) == list(shapes.keys()) or set(self._byname) == set(shapes)
+
+        # ---- frozen bf16 compute copies ---------------------------------------------------------------
+        D = cfg.hidden
+        self._fz = {}
+        P_ = self._byname
+        with torch.no_grad():
+            self._fz["w_pe"] = P_["backbone.embeddings.patch_embedding.weight"].reshape(D, -1).to(torch.bfloat16).contiguous()
+            for i in range(cfg.layers):
+                if i == cfg.trainable_layer():
+                    continue
+                pre = f"backbone.encoder.layers.{i}."
+                self._fz[f"{i}.wqkv"] = torch.cat([P_[pre + f"self_attn.{p}_proj.weight"] for p in "qkv"], 0).to(torch.bfloat16).contiguous()
+                self._fz[f"{i}.bqkv"] = torch.cat([P_[pre + f"self_attn.{p}_proj.bias"] for p in "qkv"], 0).contiguous()
+                self._fz[f"{i}.wo"] = P_[pre + "self_attn.out_proj.weight"].to(torch.bfloat16).contiguous()
+                self._fz[f"{i}.w1"] = P_[pre + "mlp.fc1.weight"].to(torch.bfloat16).contiguous()
+                self._fz[f"{i}.w2"] = P_[pre + "mlp.fc2.weight"].to(torch.bfloat16).contiguous()
+        self.box_bias = box_bias_table(cfg.grid).to(self.device_)
+        self._ws = {}
+        self._saved = None
+
+    # -- module-tree plumbing -----------------------------------------------------------------------
+    def _attach(self, dotted: str, p: nn.Parameter):
+        parts = dotted.split(".")
+        node = self
+        for part in parts[:-1]:
+            if part not in node._modules:
+                node.add_module(part, _Node())
+            node = node._modules[part]
+        node.register_parameter(parts[-1], p)
+
+    def p(self, name: str) -> torch.Tensor:
+        return self._byname[name]
+
+    def _tview(self, name: str, dtype=torch.bfloat16):
+        """bf16 (or f32) view of a trainable tensor inside the flat buckets."""
+        o = self.flat_offsets[name]
+        n = self._byname[name].numel()
+        src = self.flat_bf16 if dtype == torch.bfloat16 else self.flat_param
+        return src[o: o + n].view(self._byname[name].shape)
+
+    def _layer_weights(self, i: int):
+        cfg, D = self.cfg, self.cfg.hidden
+        pre = f"backbone.encoder.layers.{i}."
+        P_ = self._byname
+        if i == cfg.trainable_layer():
+            o = self.flat_offsets[pre + "self_attn.q_proj.weight"]
+            wqkv = self.flat_bf16[o: o + 3 * D * D].view(3 * D, D)
+            ob = self.flat_offsets[pre + "self_attn.q_proj.bias"]
+            bqkv = self.flat_param[ob: ob + 3 * D]
+            wo, w1, w2 = (self._tview(pre + "self_attn.out_proj.weight"), self._tview(pre + "mlp.fc1.weight"),
+                          self._tview(pre + "mlp.fc2.weight"))
+        else:
+            wqkv, bqkv = self._fz[f"{i}.wqkv"], self._fz[f"{i}.bqkv"]
+            wo, w1, w2 = self._fz[f"{i}.wo"], self._fz[f"{i}.w1"], self._fz[f"{i}.w2"]
+        return dict(wqkv=wqkv, bqkv=bqkv, wo=wo, bo=P_[pre + "self_attn.out_proj.bias"], w1=w1, b1=P_[pre + "mlp.fc1.bias"],
+                    w2=w2, b2=P_[pre + "mlp.fc2.bias"], g1=P_[pre + "layer_norm1.weight"], be1=P_[pre + "layer_norm1.bias"],
+                    g2=P_[pre + "layer_norm2.weight"], be2=P_[pre + "layer_norm2.bias"])
+
+    # -- workspaces -----------------------------------------------------------------------------------
+    def _workspace(self, B: int):
+        if B in self._ws:
+            return self._ws[B]
+        cfg, dev = self.cfg, self.device_
+        D, I, Tp, P, Dt, C = cfg.hidden, cfg.mlp, cfg.tokens_padded, cfg.patches, cfg.text_dim, cfg.n_classes
+        M, Mh = B * Tp, B * P
+        bf, f32 = torch.bfloat16, torch.float32
+        z = ops.zeros_rows
+        ws = dict(
+            x=z(M, D, f32, dev), h=z(M, D, bf, dev), qkv=z(M, 3 * D, bf, dev),
+            qkvT=torch.zeros(B * 3 * D * Tp + 256, dtype=bf, device=dev),   # [B][3D][Tp] (+ slack for tile over-read)
+            att=z(M, D, bf, dev), g=z(M, I, bf, dev),
+            # trainable-layer saves
+            x_in=z(M, D, f32, dev), x_mid=z(M, D, f32, dev), h1=z(M, D, bf, dev), h2=z(M, D, bf, dev), u=z(M, I, bf, dev),
+            st1=torch.zeros(M, 2, device=dev), st2=torch.zeros(M, 2, device=dev), lse=torch.zeros(B, cfg.heads, Tp, device=dev),
+            # heads
+            cls_ln=torch.zeros(B, D, device=dev), feats=z(Mh, D, bf, dev), st_post=torch.zeros(M, 2, device=dev),
+            st_pp=torch.zeros(Mh, 2, device=dev), hb0=z(Mh, D, bf, dev), ub0=z(Mh, D, bf, dev), hb1=z(Mh, D, bf, dev),
+            ub1=z(Mh, D, bf, dev), sig=torch.zeros(Mh, 4, device=dev), e=z(Mh, Dt, f32, dev),
+            qhat=torch.zeros(32, Dt, device=dev), qnorm=torch.zeros(32, device=dev),
+            argmax=torch.zeros(Mh, C, dtype=torch.uint8, device=dev), inv_norm=torch.zeros(Mh, device=dev),
+            img=torch.zeros(B, 3, cfg.image_size, cfg.image_size, dtype=bf, device=dev),
+        )
+        self._ws[B] = ws
+        return ws
+
+    def refresh_compute_weights(self):
+        """bf16 copies of the trainable tensors (one cast over the flat bucket)."""
+        ops.cast_bf16(self.flat_param, self.flat_bf16)
+
+    # -- forward ---------------------------------------------------------------------------------------
+    def _forward_impl(self, image: torch.Tensor, save: bool):
+        cfg = self.cfg
+        D, I, H, Tp, T, P, Dt, C = cfg.hidden, cfg.mlp, cfg.heads, cfg.tokens_padded, cfg.tokens, cfg.patches, cfg.text_dim, cfg.n_classes
+        B = image.shape[0]
+        if tuple(image.shape[1:]) != (3, cfg.image_size, cfg.image_size):
+            raise ValueError(f"image must be [B,3,{cfg.image_size},{cfg.image_size}], got {tuple(image.shape)}")
+        ws = self._workspace(B)
+        M, Mh = B * Tp, B * P
+        P_ = self._byname
+        self.refresh_compute_weights()
+
+        if image.dtype == torch.float32:
+            ops.cast_bf16(image.contiguous(), ws["img"])
+            img = ws["img"]
+        elif image.dtype == torch.bfloat16:
+            img = image.contiguous()
+        else:
+            raise TypeError("image must be float32 or bfloat16")
+
+        x = ws["x"]
+        ops.patch_embed(img, self._fz["w_pe"], P_["backbone.embeddings.position_embedding.weight"], x, B, cfg.image_size,
+                        cfg.patch_size, D, Tp)
+        ops.cls_rows(x, P_["backbone.embeddings.class_embedding"], P_["backbone.embeddings.position_embedding.weight"], B, Tp, D)
+        ops.layernorm(x, P_["backbone.pre_layernorm.weight"], P_["backbone.pre_layernorm.bias"], x, M, D, eps=cfg.ln_eps)
+
+        scale = cfg.head_dim ** -0.5
+        qkv, qkvT, att, g = ws["qkv"], ws["qkvT"], ws["att"], ws["g"]
+        for i in range(cfg.layers):
+            lw = self._layer_weights(i)
+            sv = save and i == cfg.trainable_layer()
+            h = ws["h1"] if sv else ws["h"]
+            x_src = x
+            if sv:
+                ws["x_in"].copy_(x)
+                x_src = ws["x_in"]
+            ops.layernorm(x_src, lw["g1"], lw["be1"], h, M, D, ws["st1"] if sv else None, cfg.ln_eps)
+            if sv:   # row-major q,k,v and per-head transposed q,k,v (backward operands)
+                ops.gemm(ops.EPI_BIAS_BF16, h, lw["wqkv"], qkv, bias=lw["bqkv"], M=M, N=3 * D, K=D, ldo=3 * D)
+                ops.gemm(ops.EPI_TRANS_BF16, h, lw["wqkv"], qkvT, bias=lw["bqkv"], M=M, N=3 * D, K=D, Tp=Tp)
+                vt, vt_stride = qkvT[2 * D * Tp:], 3 * D * Tp
+            else:    # row-major q,k ; V only transposed
+                ops.gemm(ops.EPI_BIAS_BF16, h, lw["wqkv"], qkv, bias=lw["bqkv"], M=M, N=2 * D, K=D, ldo=3 * D, w_rows=2 * D)
+                ops.gemm(ops.EPI_TRANS_BF16, h, lw["wqkv"][2 * D:], qkvT, bias=lw["bqkv"][2 * D:], M=M, N=D, K=D, Tp=Tp, w_rows=D)
+                vt, vt_stride = qkvT, D * Tp
+            ops.attention_fwd(qkv, qkv[:, D:], 3 * D, vt, vt_stride, att, D, ws["lse"] if sv else None, B, H, T, Tp, scale)
+            x_dst = ws["x_mid"] if sv else x
+            ops.gemm(ops.EPI_RESID_F32, att, lw["wo"], x_dst, bias=lw["bo"], resid=x_src, M=M, N=D, K=D)
+            h2 = ws["h2"] if sv else ws["h"]
+            ops.layernorm(x_dst, lw["g2"], lw["be2"], h2, M, D, ws["st2"] if sv else None, cfg.ln_eps)
+            ops.gemm(ops.EPI_QGELU_BF16, h2, lw["w1"], g, bias=lw["b1"], aux=ws["u"] if sv else None, M=M, N=I, K=D)
+            ops.gemm(ops.EPI_RESID_F32, g, lw["w2"], x, bias=lw["b2"], resid=x_dst, M=M, N=D, K=I)
+
+        # ---- post_layernorm (all tokens) * class token -> post_post_layernorm (ref src/models.py:80-86)
+        feats = ws["feats"]
+        tv = lambda n: self._tview(n)
+        ops.merge_ln(x, P_["backbone.post_layernorm.weight"], P_["backbone.post_layernorm.bias"], P_["post_post_layernorm.weight"],
+                     P_["post_post_layernorm.bias"], ws["cls_ln"], feats, ws["st_post"], ws["st_pp"], B, P, Tp, D, cfg.ln_eps)
+        # ---- box head (HF5:983-999) + bias / sigmoid / corners ---------------------------------------
+        ops.gemm(ops.EPI_GELU_BF16, feats, tv("box_head.dense0.weight"), ws["hb0"], bias=P_["box_head.dense0.bias"],
+                 aux=ws["ub0"] if save else None, M=Mh, N=D, K=D)
+        ops.gemm(ops.EPI_GELU_BF16, ws["hb0"], tv("box_head.dense1.weight"), ws["hb1"], bias=P_["box_head.dense1.bias"],
+                 aux=ws["ub1"] if save else None, M=Mh, N=D, K=D)
+        pred_boxes = torch.empty(B, P, 4, device=self.device_)
+        ops.box_final(ws["hb1"], P_["box_head.dense2.weight"], P_["box_head.dense2.bias"], self.box_bias, pred_boxes, ws["sig"], Mh, P, D)
+        # ---- class head (ref src/models.py:24-38) ------------------------------------------------------
+        ops.gemm(ops.EPI_F32, feats, tv("class_predictor.dense0.weight"), ws["e"], bias=P_["class_predictor.dense0.bias"], M=Mh, N=Dt, K=D)
+        ops.query_normalize(P_["queries"], ws["qhat"], ws["qnorm"], cfg.queries, Dt)
+        pred_sims = torch.empty(B, P, C, device=self.device_)
+        ops.class_sims(ws["e"], ws["qhat"], pred_sims, ws["argmax"], ws["inv_norm"], Mh, Dt, C)
+        return pred_boxes, pred_sims
+
+    def forward(self, image: torch.Tensor):
+        """ref src/models.py:98-119: returns (pred_boxes xyxy, None, pred_sims, None)."""
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if need_grad:
+            from .autograd import OwlViTFunction
+            names = list(self.flat_offsets.keys())
+            boxes, sims = OwlViTFunction.apply(self, image, *[self._byname[n] for n in names])
+        else:
+            boxes, sims = self._forward_impl(image, save=False)
+        return (boxes, None, sims, None)
+
+
+def load_model(labelmap, device="cuda", arch: str = "owlvit-base-patch32", seed: int = 1234, state=None):
+    """ref src/models.py:149-191.  The reference downloads `google/owlvit-base-patch32` and runs the
+    CLIP text tower once to initialise the query bank; neither box has network access, so weights
+    come from `state` (name -> array, reference parameter names) or, by default, the deterministic
+    random set (weights.make_weights).  The freeze rule is applied by construction (trainable
+    tensors live in the flat bucket with requires_grad=True; everything else is frozen)."""
+    n_classes = len(labelmap)
+    cfg = get_config(arch, n_classes=n_classes)
+    if state is None:
+        state = W.make_weights(cfg, seed)
+    return OwlViT(cfg, state, device)
