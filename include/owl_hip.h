@@ -67,6 +67,23 @@ int owl_class_sims_fwd(void* stream, const float* e, const float* qhat32, float*
 /* dense2 + box bias + sigmoid + center_to_corners (HF5:998, 1071-1104; ref src/models.py:70-73)   */
 int owl_box_final_fwd(void* stream, const void* h_bf16, const float* w2, const float* b2, const float* box_bias, float* boxes, float* sig_out, int64_t rows, int64_t P, int64_t D);
 
+/* ---- Hungarian-matched push-pull loss, fully on device (no host sync) --------------------------------
+ * Targets are padded: labels [B,Nmax] i64, tgt_boxes [B,Nmax,4] f32, counts [B] i32.
+ * costT[b][j][p] = w_bbox*|box_p - tgt_j|_1 - w_class*softmax(sims_p)[label_j] - w_giou*GIoU   (ref src/matcher.py:106-131) */
+int owl_match_cost(void* stream, const float* sims, const float* boxes, const int64_t* labels, const float* tgt_boxes, const int* counts, float* costT, int64_t B, int64_t P, int64_t C, int64_t Nmax, float w_class, float w_bbox, float w_giou);
+/* rectangular LSAP per image (replaces scipy.optimize.linear_sum_assignment at ref src/matcher.py:134-137, f64 duals,
+ * scipy's tie rule) + target scatter (ref src/matcher.py:146-157): pairs ordered by prediction index             */
+int owl_hungarian(void* stream, const float* costT, const int64_t* labels, const int* counts, int64_t* pred_idx, int64_t* tgt_idx, int64_t* target_classes, int64_t B, int64_t P, int64_t Nmax, int64_t bg);
+/* sequential IoU > thr label spreading (ref src/losses.py:100-106), in place on target_classes [B,P]             */
+int owl_spread_labels(void* stream, const float* boxes, int64_t* target_classes, int64_t B, int64_t P, int64_t bg, float thr);
+/* class_loss (ref src/losses.py:16-40) + loss_boxes (ref src/losses.py:42-69); losses[4] = mean over images of
+ * {loss_ce, loss_bg, loss_bbox, loss_giou}; optional per-term gradients wrt sims / boxes                          */
+int owl_push_pull_loss(void* stream, const float* sims, const float* boxes, const int64_t* target_classes, const float* scales, const float* tgt_boxes, const int64_t* pred_idx, const int64_t* tgt_idx, const int* counts, float* per_image, float* losses, float* dsims, float* dl1, float* dgiou, int64_t B, int64_t P, int64_t C, int64_t Nmax, int64_t bg);
+int owl_push_pull_loss_bwd(void* stream, const float* g4, const int64_t* target_classes, const float* dsims, const float* dl1, const float* dgiou, float* out_sims, float* out_boxes, int64_t B, int64_t P, int64_t C, int64_t bg);
+
+/* pairwise out3 = {iou, union, giou} each [N,M] (free functions box_iou / generalized_box_iou, ref src/matcher.py:8-44) */
+int owl_box_pairwise(void* stream, const float* boxes1, const float* boxes2, float* out3, int64_t N, int64_t M);
+
 /* ---- utilities ------------------------------------------------------------------------------------ */
 int owl_cast_f32_bf16(void* stream, const float* in, void* out, int64_t n);
 int owl_transpose_bf16(void* stream, const void* in, int64_t ld_in, void* out, int64_t ld_out, int64_t R, int64_t C);

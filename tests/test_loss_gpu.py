@@ -1,0 +1,114 @@
+"""Matcher + push-pull loss on device vs the oracle and vs the reference-generated fixture F5
+(indices / target classes bit-exact; f32 losses and gradients within 1e-3 -- in practice ~1e-6)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import owl_oracle as O  # noqa: E402  (checker only)
+from owl_vit_object_detection_amd import rng  # noqa: E402
+from owl_vit_object_detection_amd.losses import PushPullLoss, box_iou, generalized_box_iou  # noqa: E402
+from owl_vit_object_detection_amd.matcher import HungarianMatcher  # noqa: E402
+
+DEV = "cuda"
+KEYS = ("loss_ce", "loss_bg", "loss_bbox", "loss_giou")
+
+
+def test_f5_reference_loss_cases(golden_dir):
+    g = np.load(os.path.join(golden_dir, "f5_loss_cases.npz"))
+    names = sorted({k.split("/")[0] for k in g.files})
+    for name in names:
+        sims = torch.from_numpy(g[name + "/sims"])[None].to(DEV).requires_grad_(True)
+        pb = torch.from_numpy(g[name + "/pred_boxes"])[None].to(DEV).requires_grad_(True)
+        labels = torch.from_numpy(g[name + "/labels"])[None].to(DEV)
+        tb = torch.from_numpy(g[name + "/tgt_boxes"])[None].to(DEV)
+        scales = torch.from_numpy(g[name + "/scales"]) if name + "/scales" in g.files else None
+        C = sims.shape[-1]
+        crit = PushPullLoss(C, scales)
+        losses = crit(sims, labels, pb, tb)
+        n = labels.shape[1]
+        assert np.array_equal(crit.last["pred_idx"][0, :n].cpu().numpy(), g[name + "/pred_idx"]), name
+        assert np.array_equal(crit.last["tgt_idx"][0, :n].cpu().numpy(), g[name + "/tgt_idx"]), name
+        assert np.array_equal(crit.last["target_classes"][0].cpu().numpy(), g[name + "/target_classes"]), name
+        for k in KEYS:
+            assert float(losses[k]) == pytest.approx(float(g[name + "/" + k]), rel=1e-4, abs=1e-6), (name, k)
+        (losses["loss_ce"] + losses["loss_bg"] + losses["loss_bbox"] + losses["loss_giou"]).backward()
+        np.testing.assert_allclose(sims.grad[0].cpu().numpy(), g[name + "/grad_sims"], rtol=1e-3, atol=1e-6, err_msg=name)
+        np.testing.assert_allclose(pb.grad[0].cpu().numpy(), g[name + "/grad_boxes"], rtol=1e-3, atol=1e-6, err_msg=name)
+        # the matcher's own call surface (reference src/matcher.py:85-159)
+        m = HungarianMatcher(C)
+        tc, indices, idx = m({"pred_logits": sims.detach(), "pred_boxes": pb.detach()}, [{"labels": labels[0], "boxes": tb[0]}])
+        assert np.array_equal(tc[0].cpu().numpy(), g[name + "/target_classes_matched"]), name
+        assert np.array_equal(indices[0][0].cpu().numpy(), g[name + "/pred_idx"]) and idx[0].shape == idx[1].shape
+
+
+def _random_case(B, P, C, seed, nmax=16):
+    sims = (rng.uniform(seed, "s", B * P * C).reshape(B, P, C) * 1.2 - 0.6).astype(np.float32)
+    x0 = rng.uniform(seed, "b", B * P, 0) * 0.7; y0 = rng.uniform(seed, "b", B * P, 1) * 0.7
+    w = 0.03 + rng.uniform(seed, "b", B * P, 2) * 0.25; h = 0.03 + rng.uniform(seed, "b", B * P, 3) * 0.25
+    pb = np.stack([x0, y0, x0 + w, y0 + h], -1).reshape(B, P, 4).astype(np.float32)
+    labels, tbs = [], []
+    for b in range(B):
+        n = 1 + int(rng.randint(seed, f"n{b}", 1, nmax)[0])
+        tx = rng.uniform(seed, f"t{b}", n, 0) * 0.6; ty = rng.uniform(seed, f"t{b}", n, 1) * 0.6
+        tw = 0.02 + rng.uniform(seed, f"t{b}", n, 2) * 0.35; th = 0.02 + rng.uniform(seed, f"t{b}", n, 3) * 0.35
+        tbs.append(np.stack([tx, ty, tx + tw, ty + th], -1).astype(np.float32))
+        labels.append(rng.randint(seed, f"l{b}", n, C))
+    return sims, pb, labels, tbs
+
+
+@pytest.mark.parametrize("B,P,C,scaled", [(4, 576, 10, True), (3, 2304, 10, False), (2, 3600, 10, True), (5, 36, 4, True)])
+def test_batched_loss_matches_oracle(B, P, C, scaled):
+    sims, pb, labels, tbs = _random_case(B, P, C, seed=B * 1000 + P)
+    scales = np.round(3 + rng.uniform(5, "sc", C) * 2, 1).astype(np.float32) if scaled else None
+    # oracle (CPU)
+    so = torch.from_numpy(sims).requires_grad_(True); bo = torch.from_numpy(pb).requires_grad_(True)
+    det = []
+    lo = O.push_pull_loss(so, [torch.from_numpy(l) for l in labels], bo, [torch.from_numpy(t) for t in tbs], C,
+                          None if scales is None else torch.from_numpy(scales), det)
+    sum(lo.values()).backward()
+    # HIP
+    sg = torch.from_numpy(sims).to(DEV).requires_grad_(True); bg = torch.from_numpy(pb).to(DEV).requires_grad_(True)
+    crit = PushPullLoss(C, scales)
+    lg = crit(sg, [torch.from_numpy(l).to(DEV) for l in labels], bg, [torch.from_numpy(t).to(DEV) for t in tbs])
+    (lg["loss_ce"] + lg["loss_bg"] + lg["loss_bbox"] + lg["loss_giou"]).backward()
+    for b in range(B):
+        n = len(labels[b])
+        assert np.array_equal(crit.last["pred_idx"][b, :n].cpu().numpy(), det[b]["pred_idx"].numpy()), b
+        assert np.array_equal(crit.last["tgt_idx"][b, :n].cpu().numpy(), det[b]["tgt_idx"].numpy()), b
+        assert np.array_equal(crit.last["target_classes"][b].cpu().numpy(), det[b]["target_classes"].numpy()), b
+    for k in KEYS:
+        assert float(lg[k]) == pytest.approx(float(lo[k]), rel=1e-4, abs=1e-6), k
+    np.testing.assert_allclose(sg.grad.cpu().numpy(), so.grad.numpy(), rtol=1e-3, atol=1e-7)
+    np.testing.assert_allclose(bg.grad.cpu().numpy(), bo.grad.numpy(), rtol=1e-3, atol=1e-7)
+
+
+def test_hungarian_tie_heavy_matches_scipy_rule():
+    """Integer costs (many ties): the device solver must reproduce scipy's indices, not just the cost."""
+    from owl_vit_object_detection_amd import _lib, ops
+    B, P, Nmax = 3, 200, 12
+    cost = rng.randint(3, "ties", B * P * Nmax, 3).reshape(B, P, Nmax).astype(np.float32)
+    costT = torch.from_numpy(np.ascontiguousarray(cost.transpose(0, 2, 1))).to(DEV)
+    labels = torch.zeros(B, Nmax, dtype=torch.int64, device=DEV)
+    counts = torch.tensor([12, 7, 1], dtype=torch.int32, device=DEV)
+    pi = torch.zeros(B, Nmax, dtype=torch.int64, device=DEV); ti = torch.zeros_like(pi)
+    tc = torch.zeros(B, P, dtype=torch.int64, device=DEV)
+    _lib.call("owl_hungarian", ops.stream(), costT, labels, counts, pi, ti, tc, B, P, Nmax, 99)
+    for b, n in enumerate([12, 7, 1]):
+        i, j = O.linear_sum_assignment(cost[b][:, :n])
+        assert np.array_equal(pi[b, :n].cpu().numpy(), i) and np.array_equal(ti[b, :n].cpu().numpy(), j), b
+
+
+def test_box_ops_free_functions():
+    _, pb, _, tbs = _random_case(1, 300, 4, seed=77)
+    a = torch.from_numpy(pb[0]); b = torch.from_numpy(tbs[0])
+    iou, uni = box_iou(a.to(DEV), b.to(DEV))
+    riou, runi = O.box_iou(a, b)
+    assert torch.equal(iou.cpu(), riou) and torch.equal(uni.cpu(), runi)          # bit-exact (fp-contract off)
+    g = generalized_box_iou(a.to(DEV), b.to(DEV))
+    assert torch.equal(g.cpu(), O.generalized_box_iou(a, b))
+    with pytest.raises(AssertionError):
+        generalized_box_iou(torch.tensor([[0.5, 0.5, 0.1, 0.6]], device=DEV), b.to(DEV))
