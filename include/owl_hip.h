@@ -56,6 +56,10 @@ int owl_layernorm_fwd(void* stream, const float* x, const float* gamma, const fl
  * by epilogue 6; out row-major [B*Tp, ld_out]; lse optional [B,H,Tp] (log2 domain).               */
 int owl_attention_fwd_bf16(void* stream, const void* q, const void* k, int64_t ld_qk, const void* vt, int64_t vt_img_stride, void* out, int64_t ld_out, float* lse, int64_t B, int64_t H, int64_t T, int64_t Tp, float scale);
 
+/* backward of the above for the trainable layer: qkv row-major [B*Tp,3D] (q|k|v), qkvT / dOT per-head
+ * transposed copies ([B][3D][Tp] / [B][D][Tp], epilogue 6), O and dO row-major [B*Tp,D]; writes dqkv [B*Tp,3D]. */
+int owl_attention_bwd_bf16(void* stream, const void* qkv, const void* qkvT, const void* dO, const void* dOT, const void* O, const float* lse, float* dvec_ws, void* dqkv, int64_t B, int64_t H, int64_t T, int64_t Tp, float scale);
+
 /* ---- post_layernorm on all tokens + class-token merge + post_post_layernorm (ref src/models.py:80-86) */
 int owl_merge_ln_fwd(void* stream, const float* x, const float* g1, const float* b1, const float* g2, const float* b2, float* cls_ln, void* feats_bf16, float* stats1, float* stats2, int64_t B, int64_t P, int64_t Tp, int64_t D, float eps);
 
@@ -83,6 +87,16 @@ int owl_push_pull_loss_bwd(void* stream, const float* g4, const int64_t* target_
 
 /* pairwise out3 = {iou, union, giou} each [N,M] (free functions box_iou / generalized_box_iou, ref src/matcher.py:8-44) */
 int owl_box_pairwise(void* stream, const float* boxes1, const float* boxes2, float* out3, int64_t N, int64_t M);
+
+/* ---- backward of the row-wise pieces (autograd forms of the entries above) --------------------------
+ * parameter-gradient outputs (dgamma, dbeta, dw2, db2, dqueries, colsum) ACCUMULATE (atomics) into
+ * buffers the caller zeroes once per step -- they are views of the flat gradient bucket.              */
+int owl_layernorm_bwd(void* stream, const void* dy, int dy_bf16, const float* x, const float* stats, const float* gamma, const float* dres, float* dx, float* dgamma, float* dbeta, int64_t rows, int64_t D);
+int owl_merge_ln_bwd(void* stream, const float* dfeats, const float* x, const float* cls_ln, const float* stats1, const float* stats2, const float* g1, const float* b1, const float* g2, float* dx, float* dcls_ws, float* dg1, float* db1, float* dg2, float* db2, int64_t B, int64_t P, int64_t Tp, int64_t D);
+int owl_class_sims_bwd(void* stream, const float* dsims, const float* sims, const unsigned char* argmax, const float* inv_norm, const float* e, const float* qhat32, const float* queries, void* de_bf16, float* dqhat_ws, float* dqueries, int64_t rows, int64_t Dt, int64_t C);
+int owl_box_final_bwd(void* stream, const float* dboxes, const float* sig, const void* h1_bf16, const void* u1_bf16, const float* w2, void* du1_bf16, float* dw2, float* db2, int64_t rows, int64_t D);
+int owl_transpose_colsum_bf16(void* stream, const void* in, int64_t ld_in, void* out_t, int64_t ld_out, float* colsum, int64_t R, int64_t C);
+int owl_colsum_f32(void* stream, const float* in, float* colsum, int64_t R, int64_t C);
 
 /* ---- utilities ------------------------------------------------------------------------------------ */
 int owl_cast_f32_bf16(void* stream, const float* in, void* out, int64_t n);

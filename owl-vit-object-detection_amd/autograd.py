@@ -1,0 +1,172 @@
+"""The autograd edge of the HIP train path: ONE coarse torch.autograd.Function around the whole vision
+model.  forward = OwlViT._forward_impl (saving the trainable layer's activations); backward = a fixed
+sequence of hand-written HIP kernels (csrc/backward.hip, attention_bwd.hip, gemm.hip) for exactly the
+trainable set of the reference freeze rule (ref src/models.py:173-184): queries, encoder layer 11,
+post_layernorm, post_post_layernorm, class_predictor.dense0, box_head.  Everything upstream of the
+trainable layer is frozen, so the backward stops there (ref main.py:90).
+
+Parameter gradients are ACCUMULATED by the kernels directly into `model.flat_grad` (each parameter's
+.grad is a view of that bucket), so `loss.backward()` leaves one contiguous buffer ready for the single
+all-reduce + optimizer step; the Function therefore returns no per-parameter tensors.
+"""
+import torch
+
+from . import ops
+
+
+def _attach_grads(model):
+    """Make every trainable parameter's .grad a view of model.flat_grad.  If an optimizer set them to
+    None (zero_grad(set_to_none=True)) the bucket is zeroed first -- None means zero."""
+    attached = True
+    for n, off in model.flat_offsets.items():
+        p = model._byname[n]
+        g = p.grad
+        if g is None or g.data_ptr() != model.flat_grad.data_ptr() + 4 * off:
+            attached = False
+            break
+    if attached:
+        return
+    keep = {}
+    for n in model.flat_offsets:
+        g = model._byname[n].grad
+        if g is not None:
+            keep[n] = g
+    model.flat_grad.zero_()
+    for n, off in model.flat_offsets.items():
+        p = model._byname[n]
+        view = model.flat_grad[off: off + p.numel()].view(p.shape)
+        if n in keep and keep[n].data_ptr() != view.data_ptr():
+            view.copy_(keep[n])          # foreign accumulated grads are preserved
+        p.grad = view
+
+
+class OwlViTFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, image, *params):
+        cfg = model.cfg
+        if cfg.trainable_layer() != cfg.layers - 1:
+            raise NotImplementedError(
+                "backward through frozen layers above the trainable one (layers.11 of a deeper model) is not built yet")
+        boxes, sims = model._forward_impl(image, save=True)
+        ctx.model = model
+        ctx.B = image.shape[0]
+        ctx.sims = sims
+        return boxes, sims
+
+    @staticmethod
+    def backward(ctx, d_boxes, d_sims):
+        model, B = ctx.model, ctx.B
+        backward_impl(model, B, d_boxes, d_sims, ctx.sims)
+        return (None, None) + (None,) * len(model.flat_offsets)
+
+
+def _bws(model, B):
+    key = ("bwd", B)
+    if key in model._ws:
+        return model._ws[key]
+    cfg, dev = model.cfg, model.device_
+    D, I, Tp, P, Dt, H = cfg.hidden, cfg.mlp, cfg.tokens_padded, cfg.patches, cfg.text_dim, cfg.heads
+    M, Mh = B * Tp, B * P
+    Mp, Mhp = ops.pad_rows(M), ops.pad_rows(Mh)
+    bf, f32 = torch.bfloat16, torch.float32
+    z = ops.zeros_rows
+    wide = max(3 * D, I)
+    ws = dict(
+        de=z(Mh, Dt, bf, dev), dqhat=torch.zeros(32, Dt, device=dev), du1=z(Mh, D, bf, dev), du0=z(Mh, D, bf, dev),
+        dfeats=z(Mh, D, f32, dev), dcls=torch.zeros(B, D, device=dev),
+        dx=z(M, D, f32, dev), dxb=z(M, D, bf, dev), du=z(M, I, bf, dev), dh=z(M, D, bf, dev), dxm=z(M, D, f32, dev),
+        datt=z(M, D, bf, dev), dattT=torch.zeros(B * D * Tp + 256, dtype=bf, device=dev), dqkv=z(M, 3 * D, bf, dev),
+        dvec=torch.zeros(B, H, Tp, device=dev),
+        tA=torch.zeros(wide, max(Mp, Mhp), dtype=bf, device=dev), tB=torch.zeros(wide, max(Mp, Mhp), dtype=bf, device=dev),
+        wT=torch.zeros(wide * max(D, I), dtype=bf, device=dev),
+    )
+    model._ws[key] = ws
+    return ws
+
+
+def _split_k(n_rows_out, n_cols_out, k):
+    """Split the (long) token contraction so that the dW GEMM fills the chip: ~1k workgroups."""
+    tiles = ((n_rows_out + 127) // 128) * ((n_cols_out + 127) // 128)
+    return max(1, min(k // 64, (1024 + tiles - 1) // tiles))
+
+
+def backward_impl(model, B, d_boxes, d_sims, sims):
+    cfg = model.cfg
+    D, I, H, Tp, T, P, Dt, C = cfg.hidden, cfg.mlp, cfg.heads, cfg.tokens_padded, cfg.tokens, cfg.patches, cfg.text_dim, cfg.n_classes
+    M, Mh = B * Tp, B * P
+    Mp, Mhp = ops.pad_rows(M), ops.pad_rows(Mh)
+    ws, bw = model._workspace(B), _bws(model, B)
+    P_ = model._byname
+    _attach_grads(model)
+    G = lambda n: P_[n].grad                      # views into model.flat_grad (accumulated into)
+    tv = model._tview
+    tl = f"backbone.encoder.layers.{cfg.trainable_layer()}."
+    d_boxes = d_boxes.contiguous().float()
+    d_sims = d_sims.contiguous().float()
+
+    def wT(name, rows, cols):
+        """bf16 transpose of a trainable weight [rows, cols] -> [cols, rows] in scratch."""
+        out = bw["wT"][: rows * cols].view(cols, rows)
+        ops.transpose_bf16(tv(name), out, rows, cols)
+        return out
+
+    def dW(dy, x, grad_w, n_out, n_in, rows, rows_pad, grad_b=None):
+        """grad_w[n_out, n_in] += dy[rows, n_out]^T x[rows, n_in];  grad_b += colsum(dy)  (one pass each)."""
+        tA = bw["tA"][:n_out, :rows_pad]
+        tB = bw["tB"][:n_in, :rows_pad]
+        ld = bw["tA"].shape[1]
+        ops.transpose_colsum(dy, bw["tA"], grad_b, rows, n_out, ld_in=dy.shape[-1], ld_out=ld)
+        ops.transpose_colsum(x, bw["tB"], None, rows, n_in, ld_in=x.shape[-1], ld_out=ld)
+        ops.gemm(ops.EPI_ATOMIC_F32, bw["tA"], bw["tB"], grad_w, M=n_out, N=n_in, K=rows_pad, lda=ld, ldw=ld, ldo=n_in,
+                 a_rows=n_out, w_rows=n_in, splits=_split_k(n_out, n_in, rows_pad))
+
+    # pad columns [rows, rows_pad) of the transposed scratch must be zero: rows beyond `rows` are never
+    # written by the transposes and the buffers start zeroed; M and Mh never change for a given B.
+
+    # ---- class head ---------------------------------------------------------------------------------
+    ops.class_sims_bwd(d_sims, sims, ws["argmax"], ws["inv_norm"], ws["e"], ws["qhat"], P_["queries"], bw["de"], bw["dqhat"],
+                       G("queries"), Mh, Dt, C)
+    dW(bw["de"], ws["feats"], G("class_predictor.dense0.weight"), Dt, D, Mh, Mhp, G("class_predictor.dense0.bias"))
+    ops.gemm(ops.EPI_F32, bw["de"], wT("class_predictor.dense0.weight", Dt, D), bw["dfeats"], M=Mh, N=D, K=Dt)
+    # ---- box head -------------------------------------------------------------------------------------
+    ops.box_final_bwd(d_boxes, ws["sig"], ws["hb1"], ws["ub1"], P_["box_head.dense2.weight"], bw["du1"],
+                      G("box_head.dense2.weight"), G("box_head.dense2.bias"), Mh, D)
+    dW(bw["du1"], ws["hb0"], G("box_head.dense1.weight"), D, D, Mh, Mhp, G("box_head.dense1.bias"))
+    ops.gemm(ops.EPI_DGELU_BF16, bw["du1"], wT("box_head.dense1.weight", D, D), bw["du0"], aux=ws["ub0"], M=Mh, N=D, K=D)
+    dW(bw["du0"], ws["feats"], G("box_head.dense0.weight"), D, D, Mh, Mhp, G("box_head.dense0.bias"))
+    ops.gemm(ops.EPI_ACC_F32, bw["du0"], wT("box_head.dense0.weight", D, D), bw["dfeats"], M=Mh, N=D, K=D)
+    # ---- merge + the two final LayerNorms --------------------------------------------------------------
+    ops.merge_ln_bwd(bw["dfeats"], ws["x"], ws["cls_ln"], ws["st_post"], ws["st_pp"], P_["backbone.post_layernorm.weight"],
+                     P_["backbone.post_layernorm.bias"], P_["post_post_layernorm.weight"], bw["dx"], bw["dcls"],
+                     G("backbone.post_layernorm.weight"), G("backbone.post_layernorm.bias"), G("post_post_layernorm.weight"),
+                     G("post_post_layernorm.bias"), B, P, Tp, D)
+    # ---- trainable encoder layer: MLP ---------------------------------------------------------------------
+    ops.cast_bf16(bw["dx"], bw["dxb"])
+    ops.colsum_f32(bw["dx"], G(tl + "mlp.fc2.bias"), M, D)
+    dW(bw["dxb"], ws["g"], G(tl + "mlp.fc2.weight"), D, I, M, Mp)
+    ops.gemm(ops.EPI_DQGELU_BF16, bw["dxb"], wT(tl + "mlp.fc2.weight", D, I), bw["du"], aux=ws["u"], M=M, N=I, K=D)
+    dW(bw["du"], ws["h2"], G(tl + "mlp.fc1.weight"), I, D, M, Mp, G(tl + "mlp.fc1.bias"))
+    ops.gemm(ops.EPI_BIAS_BF16, bw["du"], wT(tl + "mlp.fc1.weight", I, D), bw["dh"], M=M, N=D, K=I)
+    ops.layernorm_bwd(bw["dh"], ws["x_mid"], ws["st2"], P_[tl + "layer_norm2.weight"], bw["dx"], bw["dxm"],
+                      G(tl + "layer_norm2.weight"), G(tl + "layer_norm2.bias"), M, D)
+    # ---- trainable encoder layer: attention -----------------------------------------------------------------
+    ops.cast_bf16(bw["dxm"], bw["dxb"])
+    ops.colsum_f32(bw["dxm"], G(tl + "self_attn.out_proj.bias"), M, D)
+    dW(bw["dxb"], ws["att"], G(tl + "self_attn.out_proj.weight"), D, D, M, Mp)
+    woT = wT(tl + "self_attn.out_proj.weight", D, D)
+    ops.gemm(ops.EPI_BIAS_BF16, bw["dxb"], woT, bw["datt"], M=M, N=D, K=D)
+    ops.gemm(ops.EPI_TRANS_BF16, bw["dxb"], woT, bw["dattT"], M=M, N=D, K=D, Tp=Tp)
+    ops.attention_bwd(ws["qkv"], ws["qkvT"], bw["datt"], bw["dattT"], ws["att"], ws["lse"], bw["dvec"], bw["dqkv"], B, H, T, Tp,
+                      cfg.head_dim ** -0.5)
+    o = model.flat_offsets[tl + "self_attn.q_proj.weight"]
+    g_wqkv = model.flat_grad[o: o + 3 * D * D].view(3 * D, D)
+    ob = model.flat_offsets[tl + "self_attn.q_proj.bias"]
+    g_bqkv = model.flat_grad[ob: ob + 3 * D]
+    dW(bw["dqkv"], ws["h1"], g_wqkv, 3 * D, D, M, Mp, g_bqkv)
+    wqkv = model.flat_bf16[o: o + 3 * D * D].view(3 * D, D)
+    wqkvT = bw["wT"][: 3 * D * D].view(D, 3 * D)
+    ops.transpose_bf16(wqkv, wqkvT, 3 * D, D)
+    ops.gemm(ops.EPI_BIAS_BF16, bw["dqkv"], wqkvT, bw["dh"], M=M, N=D, K=3 * D)
+    # everything below layer_norm1 is frozen: only its affine parameters need gradients
+    ops.layernorm_bwd(bw["dh"], ws["x_in"], ws["st1"], P_[tl + "layer_norm1.weight"], None, None,
+                      G(tl + "layer_norm1.weight"), G(tl + "layer_norm1.bias"), M, D)

@@ -1,0 +1,334 @@
+// Fused self-attention backward (autograd form of HF5:377-402) for the trainable encoder layer.
+// Flash-style: probabilities are recomputed from the saved log-sum-exp, never read from HBM.
+//   D[q]   = sum_d dO[q,d] O[q,d]
+//   P      = exp2(S*c - LSE[q]),  S = Q K^T,  c = scale*log2(e)
+//   dV     = P^T dO ;  dP = dO V^T ;  dA = P * (dP - D[q]) ;  dQ = scale * dA K ;  dK = scale * dA^T Q
+// Two kernels, no atomics:
+//   * dkdv: a workgroup owns 128 keys (4 waves x 32) and streams 64-query tiles; per wave
+//       S[q,k], dP[q,k] (A = Q / dO rows from LDS, B = K / V fragments held in registers),
+//       dV^T[d,k] += dO^T[d,q] P[q,k] and dK^T[d,k] += Q^T[d,q] dA[q,k]: the accumulator registers of
+//       the first pair ARE the B operands of the second pair (same trick as the forward kernel);
+//   * dq: a workgroup owns 128 queries and streams 64-key tiles; S^T[k,q], dP^T[k,q], then
+//       dQ^T[d,q] += K^T[d,k] dA^T[k,q].
+// Operands whose contraction index must be the fast per-lane index come from the per-head transposed
+// copies (Q^T, K^T, dO^T as [B][heads*64][Tp]) written by the GEMM's transposing epilogue.
+// All tiles go HBM -> LDS by LDS-DMA, double-buffered, XOR-swizzled as in gemm.hip.
+#include "common.h"
+
+struct AttnBwdP {
+    const bf16_t* qkv; int64_t ld_qkv;       // row-major [B*Tp, 3D]: q | k | v
+    const bf16_t* qkvT;                      // [B][3D][Tp]
+    const bf16_t* dO; int64_t ld_do;         // row-major [B*Tp, D]
+    const bf16_t* dOT;                       // [B][D][Tp]
+    const bf16_t* O;                         // row-major [B*Tp, D]
+    const float* lse; float* dvec;           // [B][H][Tp]
+    bf16_t* dqkv;                            // row-major [B*Tp, 3D]
+    int B, T, Tp, H, D;
+    float scale, scale_log2e;
+};
+
+__device__ __forceinline__ int swap23b(int m) { return (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1); }
+__device__ __forceinline__ int tile_off(int row, int ch) { return row * 128 + ((ch ^ ((row >> 1) & 7)) << 4); }
+
+// ---- D vector ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_dvec_kernel(AttnBwdP p) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;       // over B*Tp*H
+    const int64_t nrow = (int64_t)p.Tp * p.H;
+    const int64_t b = i / nrow;
+    if (b >= p.B) return;
+    const int64_t rem = i - b * nrow;
+    const int t = (int)(rem / p.H), h = (int)(rem - (int64_t)t * p.H);
+    float acc = 0.f;
+    if (t < p.T) {
+        const bf16_t* a = p.dO + ((int64_t)b * p.Tp + t) * p.ld_do + h * 64;
+        const bf16_t* o = p.O + ((int64_t)b * p.Tp + t) * p.ld_do + h * 64;
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const us8 av = *(const us8*)(a + c * 8), ov = *(const us8*)(o + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; e++) acc += bf2f(av[e]) * bf2f(ov[e]);
+        }
+    }
+    p.dvec[((int64_t)b * p.H + h) * p.Tp + t] = acc;
+}
+
+// ---- dK, dV ------------------------------------------------------------------------------------------
+static constexpr int BWD1_STAGE = 4 * 8192 + 512;   // Q, dO, Q^T, dO^T tiles + lse[64] + dvec[64]
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int k0 = blockIdx.x * 128 + w * 32;
+    const float c = p.scale_log2e;
+    const int D = p.D;
+
+    int key = k0 + l31;
+    const bool key_ok = key < p.T;
+    if (!key_ok) key = p.T - 1;
+    const bf16_t* krow = p.qkv + ((int64_t)b * p.Tp + key) * p.ld_qkv + D + h * 64;
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int kc = 0; kc < 4; kc++) {
+        kf[kc] = *(const bf16x8*)(krow + kc * 16 + hi * 8);
+        vf[kc] = *(const bf16x8*)(krow + D + kc * 16 + hi * 8);
+    }
+
+    const bf16_t* qbase = p.qkv + (int64_t)b * p.Tp * p.ld_qkv + h * 64;
+    const bf16_t* dobase = p.dO + (int64_t)b * p.Tp * p.ld_do + h * 64;
+    const bf16_t* qtbase = p.qkvT + ((int64_t)b * 3 * D + h * 64) * p.Tp;
+    const bf16_t* dotbase = p.dOT + ((int64_t)b * D + h * 64) * p.Tp;
+    const float* lsebase = p.lse + ((int64_t)b * p.H + h) * p.Tp;
+    const float* dvbase = p.dvec + ((int64_t)b * p.H + h) * p.Tp;
+
+    auto stage = [&](int buf, int qt) {
+        unsigned char* base = lds + buf * BWD1_STAGE;
+#pragma unroll
+        for (int qd = 0; qd < 2; qd++) {
+            const int r0 = (w * 2 + qd) * 8;
+            const int r = r0 + (lane >> 3);
+            const int ch = (lane & 7) ^ ((r >> 1) & 7);
+            int q = qt * 64 + r;
+            if (q >= p.T) q = p.T - 1;
+            __builtin_amdgcn_global_load_lds(GPTR(qbase + (int64_t)q * p.ld_qkv + ch * 8), LPTR(base + r0 * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GPTR(dobase + (int64_t)q * p.ld_do + ch * 8), LPTR(base + 8192 + r0 * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GPTR(qtbase + (int64_t)r * p.Tp + qt * 64 + ch * 8), LPTR(base + 16384 + r0 * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GPTR(dotbase + (int64_t)r * p.Tp + qt * 64 + ch * 8), LPTR(base + 24576 + r0 * 128), 16, 0, 0);
+        }
+    };
+    // lse / D values of a tile travel through a register: loaded when the tile is staged, written to
+    // LDS after the compute phase (keeps ordinary loads out of the LDS-DMA window)
+    auto load_scal = [&](int qt) -> float {
+        const int i = threadIdx.x & 63;
+        const int q = qt * 64 + i;
+        if (threadIdx.x < 64) return (q < p.T) ? lsebase[q] : INFINITY;
+        if (threadIdx.x < 128) return (q < p.T) ? dvbase[q] : 0.f;
+        return 0.f;
+    };
+    auto store_scal = [&](int buf, float v) {
+        if (threadIdx.x < 128) ((float*)(lds + buf * BWD1_STAGE + 32768))[threadIdx.x] = v;
+    };
+
+    f32x16 dv[2], dk[2];
+#pragma unroll
+    for (int d = 0; d < 2; d++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) { dv[d][r] = 0.f; dk[d][r] = 0.f; }
+
+    const int nq = (p.T + 63) / 64;
+    stage(0, 0);
+    store_scal(0, load_scal(0));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (int qt = 0; qt < nq; qt++) {
+        float pend = 0.f;
+        if (qt + 1 < nq) { stage(cur ^ 1, qt + 1); pend = load_scal(qt + 1); }
+        const unsigned char* tb = lds + cur * BWD1_STAGE;
+        const float* lse_t = (const float*)(tb + 32768);
+        const float* dv_t = lse_t + 64;
+#pragma unroll
+        for (int sub = 0; sub < 2; sub++) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
+            const int qrow = sub * 32 + swap23b(l31);
+#pragma unroll
+            for (int kc = 0; kc < 4; kc++) {
+                const bf16x8 qa = *(const bf16x8*)(tb + tile_off(qrow, kc * 2 + hi));
+                const bf16x8 da = *(const bf16x8*)(tb + 8192 + tile_off(qrow, kc * 2 + hi));
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[kc], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[kc], dp, 0, 0, 0);
+            }
+            // register r <-> query sub*32 + 16*(r>>3) + 8*hi + (r&7)
+#pragma unroll
+            for (int cc = 0; cc < 2; cc++) {
+                const int qb = sub * 32 + cc * 16 + 8 * hi;
+                const float4 l0 = *(const float4*)(lse_t + qb), l1 = *(const float4*)(lse_t + qb + 4);
+                const float4 d0 = *(const float4*)(dv_t + qb), d1 = *(const float4*)(dv_t + qb + 4);
+                const float lv[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+                const float dd[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+                bf16x8 pf, dsf;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[cc * 8 + j], c, -lv[j]));
+                    pf[j] = (short)f2bf(pv);
+                    dsf[j] = (short)f2bf(pv * (dp[cc * 8 + j] - dd[j]));
+                }
+                const int ch = sub * 4 + cc * 2 + hi;
+#pragma unroll
+                for (int d = 0; d < 2; d++) {
+                    const int drow = d * 32 + l31;
+                    const bf16x8 dot = *(const bf16x8*)(tb + 24576 + tile_off(drow, ch));
+                    const bf16x8 qt_ = *(const bf16x8*)(tb + 16384 + tile_off(drow, ch));
+                    dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot, pf, dv[d], 0, 0, 0);
+                    dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt_, dsf, dk[d], 0, 0, 0);
+                }
+            }
+        }
+        if (qt + 1 < nq) store_scal(cur ^ 1, pend);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (key_ok) {
+        bf16_t* orow = p.dqkv + ((int64_t)b * p.Tp + key) * p.ld_qkv + h * 64;
+#pragma unroll
+        for (int d = 0; d < 2; d++)
+#pragma unroll
+            for (int qd = 0; qd < 4; qd++) {
+                const int dd = d * 32 + 8 * qd + 4 * hi;
+                uint2 v;
+                v.x = pack_bf2(dk[d][qd * 4 + 0] * p.scale, dk[d][qd * 4 + 1] * p.scale);
+                v.y = pack_bf2(dk[d][qd * 4 + 2] * p.scale, dk[d][qd * 4 + 3] * p.scale);
+                *(uint2*)(orow + D + dd) = v;
+                v.x = pack_bf2(dv[d][qd * 4 + 0], dv[d][qd * 4 + 1]);
+                v.y = pack_bf2(dv[d][qd * 4 + 2], dv[d][qd * 4 + 3]);
+                *(uint2*)(orow + 2 * D + dd) = v;
+            }
+    }
+}
+
+// ---- dQ ----------------------------------------------------------------------------------------------
+static constexpr int BWD2_STAGE = 3 * 8192;   // K, V, K^T tiles
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 128 + w * 32;
+    const float c = p.scale_log2e;
+    const int D = p.D;
+
+    int q = q0 + l31;
+    const bool q_ok = q < p.T;
+    if (!q_ok) q = p.T - 1;
+    const bf16_t* qrow = p.qkv + ((int64_t)b * p.Tp + q) * p.ld_qkv + h * 64;
+    const bf16_t* dorow = p.dO + ((int64_t)b * p.Tp + q) * p.ld_do + h * 64;
+    bf16x8 qf[4], dof[4];
+#pragma unroll
+    for (int kc = 0; kc < 4; kc++) {
+        qf[kc] = *(const bf16x8*)(qrow + kc * 16 + hi * 8);
+        dof[kc] = *(const bf16x8*)(dorow + kc * 16 + hi * 8);
+    }
+    const float lse_q = p.lse[((int64_t)b * p.H + h) * p.Tp + q];
+    const float dvec_q = p.dvec[((int64_t)b * p.H + h) * p.Tp + q];
+
+    const bf16_t* kbase = p.qkv + (int64_t)b * p.Tp * p.ld_qkv + D + h * 64;
+    const bf16_t* ktbase = p.qkvT + ((int64_t)b * 3 * D + D + h * 64) * p.Tp;
+    auto stage = [&](int buf, int kv) {
+        unsigned char* base = lds + buf * BWD2_STAGE;
+#pragma unroll
+        for (int qd = 0; qd < 2; qd++) {
+            const int r0 = (w * 2 + qd) * 8;
+            const int r = r0 + (lane >> 3);
+            const int ch = (lane & 7) ^ ((r >> 1) & 7);
+            int key = kv * 64 + r;
+            if (key >= p.T) key = p.T - 1;
+            __builtin_amdgcn_global_load_lds(GPTR(kbase + (int64_t)key * p.ld_qkv + ch * 8), LPTR(base + r0 * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GPTR(kbase + D + (int64_t)key * p.ld_qkv + ch * 8), LPTR(base + 8192 + r0 * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GPTR(ktbase + (int64_t)r * p.Tp + kv * 64 + ch * 8), LPTR(base + 16384 + r0 * 128), 16, 0, 0);
+        }
+    };
+
+    f32x16 dq[2];
+#pragma unroll
+    for (int d = 0; d < 2; d++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) dq[d][r] = 0.f;
+
+    const int nkv = (p.T + 63) / 64;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int cur = 0;
+    for (int kv = 0; kv < nkv; kv++) {
+        if (kv + 1 < nkv) stage(cur ^ 1, kv + 1);
+        const unsigned char* tb = lds + cur * BWD2_STAGE;
+        const bool tail = kv * 64 + 64 > p.T;
+#pragma unroll
+        for (int sub = 0; sub < 2; sub++) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
+            const int krow = sub * 32 + swap23b(l31);
+#pragma unroll
+            for (int kc = 0; kc < 4; kc++) {
+                const bf16x8 ka = *(const bf16x8*)(tb + tile_off(krow, kc * 2 + hi));
+                const bf16x8 va = *(const bf16x8*)(tb + 8192 + tile_off(krow, kc * 2 + hi));
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[kc], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[kc], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int cc = 0; cc < 2; cc++) {
+                bf16x8 dsf;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[cc * 8 + j], c, -lse_q));
+                    if (tail) {
+                        const int key = kv * 64 + sub * 32 + cc * 16 + 8 * hi + j;
+                        if (key >= p.T) pv = 0.f;
+                    }
+                    dsf[j] = (short)f2bf(pv * (dp[cc * 8 + j] - dvec_q));
+                }
+                const int ch = sub * 4 + cc * 2 + hi;
+#pragma unroll
+                for (int d = 0; d < 2; d++) {
+                    const bf16x8 kt = *(const bf16x8*)(tb + 16384 + tile_off(d * 32 + l31, ch));
+                    dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt, dsf, dq[d], 0, 0, 0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        cur ^= 1;
+    }
+    if (q_ok) {
+        bf16_t* orow = p.dqkv + ((int64_t)b * p.Tp + q) * p.ld_qkv + h * 64;
+#pragma unroll
+        for (int d = 0; d < 2; d++)
+#pragma unroll
+            for (int qd = 0; qd < 4; qd++) {
+                uint2 v;
+                v.x = pack_bf2(dq[d][qd * 4 + 0] * p.scale, dq[d][qd * 4 + 1] * p.scale);
+                v.y = pack_bf2(dq[d][qd * 4 + 2] * p.scale, dq[d][qd * 4 + 3] * p.scale);
+                *(uint2*)(orow + d * 32 + 8 * qd + 4 * hi) = v;
+            }
+    }
+}
+
+extern "C" int owl_attention_bwd_bf16(void* stream, const void* qkv, const void* qkvT, const void* dO, const void* dOT, const void* O,
+                                      const float* lse, float* dvec_ws, void* dqkv, int64_t B, int64_t H, int64_t T, int64_t Tp,
+                                      float scale) {
+    OWL_CHECK_ARG(qkv && qkvT && dO && dOT && O && lse && dvec_ws && dqkv, "owl_attention_bwd_bf16: null pointer");
+    OWL_CHECK_ARG(Tp % 8 == 0 && T > 0 && T <= Tp, "owl_attention_bwd_bf16: Tp %% 8, T <= Tp");
+    AttnBwdP p{};
+    p.D = (int)(H * 64);
+    p.qkv = (const bf16_t*)qkv; p.ld_qkv = 3 * (int64_t)p.D; p.qkvT = (const bf16_t*)qkvT;
+    p.dO = (const bf16_t*)dO; p.ld_do = p.D; p.dOT = (const bf16_t*)dOT; p.O = (const bf16_t*)O;
+    p.lse = lse; p.dvec = dvec_ws; p.dqkv = (bf16_t*)dqkv;
+    p.B = (int)B; p.T = (int)T; p.Tp = (int)Tp; p.H = (int)H;
+    p.scale = scale; p.scale_log2e = scale * 1.4426950408889634f;
+    hipStream_t s = (hipStream_t)stream;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BWD1_STAGE);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BWD2_STAGE);
+        attr_done = true;
+    }
+    const int64_t nd = B * Tp * H;
+    hipLaunchKernelGGL(attn_dvec_kernel, dim3((unsigned)((nd + 255) / 256), 1, 1), dim3(256), 0, s, p);
+    OWL_LAUNCH_CHECK();
+    dim3 grid((unsigned)((T + 127) / 128), (unsigned)H, (unsigned)B);
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(256), 2 * BWD1_STAGE, s, p);
+    OWL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 2 * BWD2_STAGE, s, p);
+    OWL_LAUNCH_CHECK();
+    return 0;
+}

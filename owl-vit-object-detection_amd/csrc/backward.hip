@@ -1,0 +1,447 @@
+// Backward kernels for the row-wise (HBM-bound) pieces of the train path: LayerNorm, class-token merge,
+// class head, box head tail, bias gradients.  The GEMM-shaped backward work (dX, dW) reuses gemm.hip.
+// Reference: these are the autograd forms of ref src/models.py:24-38, 65-73, 80-86 and HF5:484-509.
+// Parameter-gradient reductions over rows use per-workgroup partial sums followed by f32 atomics
+// into the flat gradient bucket (which the host zeroes once per step).
+#include "common.h"
+
+static constexpr int LN_MAXV = 4;
+
+// ---------------------------------------------------------------------------------------------------
+// LayerNorm backward: dx = (dres) + rstd * (g*dy - mean(g*dy) - xhat*mean(g*dy*xhat));  dgamma += dy*xhat,
+// dbeta += dy.  dy is bf16 (GEMM output) or f32; one wave per row, RPB rows per workgroup.
+// ---------------------------------------------------------------------------------------------------
+template <bool DY_BF16>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy_, const float* __restrict__ x,
+                                                     const float2* __restrict__ stats, const float* __restrict__ gamma,
+                                                     const float* dres, float* dx, float* dgamma, float* dbeta, int64_t rows,
+                                                     int D, int rows_per_block) {
+    __shared__ float red[2][4][LN_MAXV * 256 + 4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nvec = D >> 2;
+    float4 ag[LN_MAXV], ab[LN_MAXV];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; i++) { ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0); }
+    const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r_end = min(rows, r_begin + rows_per_block);
+    for (int64_t row = r_begin + w; row < r_end; row += 4) {
+        const float2 st = stats[row];
+        float4 xh[LN_MAXV], gd[LN_MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; i++) {
+            const int idx = lane + i * 64;
+            if (idx < nvec) {
+                const float4 xv = ((const float4*)(x + row * D))[idx];
+                float4 dyv;
+                if constexpr (DY_BF16) {
+                    const uint2 u = ((const uint2*)((const bf16_t*)dy_ + row * D))[idx];
+                    dyv = make_float4(bf2f(u.x & 0xffff), bf2f(u.x >> 16), bf2f(u.y & 0xffff), bf2f(u.y >> 16));
+                } else {
+                    dyv = ((const float4*)((const float*)dy_ + row * D))[idx];
+                }
+                const float4 g = ((const float4*)gamma)[idx];
+                xh[i] = make_float4((xv.x - st.x) * st.y, (xv.y - st.x) * st.y, (xv.z - st.x) * st.y, (xv.w - st.x) * st.y);
+                gd[i] = make_float4(dyv.x * g.x, dyv.y * g.y, dyv.z * g.z, dyv.w * g.w);
+                s1 += gd[i].x + gd[i].y + gd[i].z + gd[i].w;
+                s2 += gd[i].x * xh[i].x + gd[i].y * xh[i].y + gd[i].z * xh[i].z + gd[i].w * xh[i].w;
+                ag[i].x += dyv.x * xh[i].x; ag[i].y += dyv.y * xh[i].y; ag[i].z += dyv.z * xh[i].z; ag[i].w += dyv.w * xh[i].w;
+                ab[i].x += dyv.x; ab[i].y += dyv.y; ab[i].z += dyv.z; ab[i].w += dyv.w;
+            }
+        }
+        s1 = wave_sum(s1) / (float)D; s2 = wave_sum(s2) / (float)D;
+        if (dx) {
+#pragma unroll
+            for (int i = 0; i < LN_MAXV; i++) {
+                const int idx = lane + i * 64;
+                if (idx < nvec) {
+                    float4 o = make_float4(st.y * (gd[i].x - s1 - xh[i].x * s2), st.y * (gd[i].y - s1 - xh[i].y * s2),
+                                           st.y * (gd[i].z - s1 - xh[i].z * s2), st.y * (gd[i].w - s1 - xh[i].w * s2));
+                    if (dres) {
+                        const float4 r = ((const float4*)(dres + row * D))[idx];
+                        o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+                    }
+                    ((float4*)(dx + row * D))[idx] = o;
+                }
+            }
+        }
+    }
+    if (!dgamma) return;
+    // reduce the 4 waves' partials through LDS, then one atomic per column per workgroup
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; i++) {
+        const int idx = lane + i * 64;
+        if (idx < nvec) { *(float4*)&red[0][w][idx * 4] = ag[i]; *(float4*)&red[1][w][idx * 4] = ab[i]; }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+        atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+        atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+    }
+}
+
+extern "C" int owl_layernorm_bwd(void* stream, const void* dy, int dy_bf16, const float* x, const float* stats, const float* gamma,
+                                 const float* dres, float* dx, float* dgamma, float* dbeta, int64_t rows, int64_t D) {
+    OWL_CHECK_ARG(dy && x && stats && gamma, "owl_layernorm_bwd: null pointer");
+    OWL_CHECK_ARG(D % 4 == 0 && D <= 256 * LN_MAXV, "owl_layernorm_bwd: D must be a multiple of 4 and <= 1024");
+    OWL_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "owl_layernorm_bwd: dgamma/dbeta both or neither");
+    const int rpb = 64;
+    dim3 grid((unsigned)((rows + rpb - 1) / rpb));
+    if (dy_bf16)
+        hipLaunchKernelGGL(ln_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dy, x, (const float2*)stats, gamma, dres, dx, dgamma, dbeta, rows, (int)D, rpb);
+    else
+        hipLaunchKernelGGL(ln_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dy, x, (const float2*)stats, gamma, dres, dx, dgamma, dbeta, rows, (int)D, rpb);
+    OWL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// merge + LN2 backward (ref src/models.py:80-86).  Patch rows: from d_feats (f32) back to the residual
+// stream rows 1..P of each image, accumulating d(cls_ln)[b,:] and the four LN parameter gradients.
+// grid = (ceil(P / RPB), B).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void merge_ln_bwd_kernel(const float* __restrict__ dfeats, const float* __restrict__ x,
+                                                           const float* __restrict__ cls_ln, const float2* __restrict__ stats1,
+                                                           const float2* __restrict__ stats2, const float* __restrict__ g1,
+                                                           const float* __restrict__ b1, const float* __restrict__ g2, float* dx,
+                                                           float* dcls, float* dg1, float* db1, float* dg2, float* db2, int64_t P,
+                                                           int64_t Tp, int D, int rows_per_block) {
+    __shared__ float red[4][LN_MAXV * 256 + 4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t b = blockIdx.y;
+    const int nvec = D >> 2;
+    float4 a_c[LN_MAXV], a_g1[LN_MAXV], a_b1[LN_MAXV], a_g2[LN_MAXV], a_b2[LN_MAXV];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; i++) a_c[i] = a_g1[i] = a_b1[i] = a_g2[i] = a_b2[i] = make_float4(0, 0, 0, 0);
+    const int64_t p_begin = (int64_t)blockIdx.x * rows_per_block, p_end = min(P, p_begin + rows_per_block);
+    for (int64_t pp = p_begin + w; pp < p_end; pp += 4) {
+        const int64_t xrow = b * Tp + 1 + pp, frow = b * P + pp;
+        const float2 s1 = stats1[xrow], s2 = stats2[frow];
+        float4 xh[LN_MAXV], y[LN_MAXV], zh[LN_MAXV], gz[LN_MAXV], cv[LN_MAXV];
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; i++) {
+            const int idx = lane + i * 64;
+            if (idx < nvec) {
+                const float4 xv = ((const float4*)(x + xrow * D))[idx];
+                const float4 ga = ((const float4*)g1)[idx], be = ((const float4*)b1)[idx], gb = ((const float4*)g2)[idx];
+                cv[i] = ((const float4*)(cls_ln + b * D))[idx];
+                const float4 df = ((const float4*)(dfeats + frow * D))[idx];
+                xh[i] = make_float4((xv.x - s1.x) * s1.y, (xv.y - s1.x) * s1.y, (xv.z - s1.x) * s1.y, (xv.w - s1.x) * s1.y);
+                y[i] = make_float4(xh[i].x * ga.x + be.x, xh[i].y * ga.y + be.y, xh[i].z * ga.z + be.z, xh[i].w * ga.w + be.w);
+                zh[i] = make_float4((y[i].x * cv[i].x - s2.x) * s2.y, (y[i].y * cv[i].y - s2.x) * s2.y,
+                                    (y[i].z * cv[i].z - s2.x) * s2.y, (y[i].w * cv[i].w - s2.x) * s2.y);
+                gz[i] = make_float4(df.x * gb.x, df.y * gb.y, df.z * gb.z, df.w * gb.w);
+                a_g2[i].x += df.x * zh[i].x; a_g2[i].y += df.y * zh[i].y; a_g2[i].z += df.z * zh[i].z; a_g2[i].w += df.w * zh[i].w;
+                a_b2[i].x += df.x; a_b2[i].y += df.y; a_b2[i].z += df.z; a_b2[i].w += df.w;
+                m1 += gz[i].x + gz[i].y + gz[i].z + gz[i].w;
+                m2 += gz[i].x * zh[i].x + gz[i].y * zh[i].y + gz[i].z * zh[i].z + gz[i].w * zh[i].w;
+            }
+        }
+        m1 = wave_sum(m1) / (float)D; m2 = wave_sum(m2) / (float)D;
+        float4 gd[LN_MAXV];
+        float n1 = 0.f, n2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; i++) {
+            const int idx = lane + i * 64;
+            if (idx < nvec) {
+                const float4 ga = ((const float4*)g1)[idx];
+                // dz
+                const float4 dz = make_float4(s2.y * (gz[i].x - m1 - zh[i].x * m2), s2.y * (gz[i].y - m1 - zh[i].y * m2),
+                                              s2.y * (gz[i].z - m1 - zh[i].z * m2), s2.y * (gz[i].w - m1 - zh[i].w * m2));
+                a_c[i].x += dz.x * y[i].x; a_c[i].y += dz.y * y[i].y; a_c[i].z += dz.z * y[i].z; a_c[i].w += dz.w * y[i].w;
+                const float4 dy = make_float4(dz.x * cv[i].x, dz.y * cv[i].y, dz.z * cv[i].z, dz.w * cv[i].w);
+                a_g1[i].x += dy.x * xh[i].x; a_g1[i].y += dy.y * xh[i].y; a_g1[i].z += dy.z * xh[i].z; a_g1[i].w += dy.w * xh[i].w;
+                a_b1[i].x += dy.x; a_b1[i].y += dy.y; a_b1[i].z += dy.z; a_b1[i].w += dy.w;
+                gd[i] = make_float4(dy.x * ga.x, dy.y * ga.y, dy.z * ga.z, dy.w * ga.w);
+                n1 += gd[i].x + gd[i].y + gd[i].z + gd[i].w;
+                n2 += gd[i].x * xh[i].x + gd[i].y * xh[i].y + gd[i].z * xh[i].z + gd[i].w * xh[i].w;
+            }
+        }
+        n1 = wave_sum(n1) / (float)D; n2 = wave_sum(n2) / (float)D;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; i++) {
+            const int idx = lane + i * 64;
+            if (idx < nvec)
+                ((float4*)(dx + xrow * D))[idx] = make_float4(s1.y * (gd[i].x - n1 - xh[i].x * n2), s1.y * (gd[i].y - n1 - xh[i].y * n2),
+                                                              s1.y * (gd[i].z - n1 - xh[i].z * n2), s1.y * (gd[i].w - n1 - xh[i].w * n2));
+        }
+    }
+    // five column reductions: 4 waves -> LDS -> atomics
+    auto flush = [&](float4 (&acc)[LN_MAXV], float* dst) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; i++) {
+            const int idx = lane + i * 64;
+            if (idx < nvec) *(float4*)&red[w][idx * 4] = acc[i];
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < D; c += 256) atomicAdd(dst + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+    };
+    flush(a_c, dcls + b * D);
+    flush(a_g1, dg1); flush(a_b1, db1); flush(a_g2, dg2); flush(a_b2, db2);
+}
+
+// cls rows: dy0 = dcls[b,:] -> LN1 backward on token 0 of image b
+__global__ __launch_bounds__(64) void cls_ln_bwd_kernel(const float* __restrict__ dcls, const float* __restrict__ x,
+                                                        const float2* __restrict__ stats1, const float* __restrict__ g1, float* dx,
+                                                        float* dg1, float* db1, int64_t Tp, int D) {
+    const int lane = threadIdx.x;
+    const int64_t b = blockIdx.x, row = b * Tp;
+    const int nvec = D >> 2;
+    const float2 st = stats1[row];
+    float4 xh[LN_MAXV], gd[LN_MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; i++) {
+        const int idx = lane + i * 64;
+        if (idx < nvec) {
+            const float4 xv = ((const float4*)(x + row * D))[idx], dy = ((const float4*)(dcls + b * D))[idx], g = ((const float4*)g1)[idx];
+            xh[i] = make_float4((xv.x - st.x) * st.y, (xv.y - st.x) * st.y, (xv.z - st.x) * st.y, (xv.w - st.x) * st.y);
+            gd[i] = make_float4(dy.x * g.x, dy.y * g.y, dy.z * g.z, dy.w * g.w);
+            s1 += gd[i].x + gd[i].y + gd[i].z + gd[i].w;
+            s2 += gd[i].x * xh[i].x + gd[i].y * xh[i].y + gd[i].z * xh[i].z + gd[i].w * xh[i].w;
+            float* pg = dg1 + idx * 4; float* pb = db1 + idx * 4;
+            atomicAdd(pg + 0, dy.x * xh[i].x); atomicAdd(pg + 1, dy.y * xh[i].y); atomicAdd(pg + 2, dy.z * xh[i].z); atomicAdd(pg + 3, dy.w * xh[i].w);
+            atomicAdd(pb + 0, dy.x); atomicAdd(pb + 1, dy.y); atomicAdd(pb + 2, dy.z); atomicAdd(pb + 3, dy.w);
+        }
+    }
+    s1 = wave_sum(s1) / (float)D; s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; i++) {
+        const int idx = lane + i * 64;
+        if (idx < nvec)
+            ((float4*)(dx + row * D))[idx] = make_float4(st.y * (gd[i].x - s1 - xh[i].x * s2), st.y * (gd[i].y - s1 - xh[i].y * s2),
+                                                         st.y * (gd[i].z - s1 - xh[i].z * s2), st.y * (gd[i].w - s1 - xh[i].w * s2));
+    }
+}
+
+extern "C" int owl_merge_ln_bwd(void* stream, const float* dfeats, const float* x, const float* cls_ln, const float* stats1,
+                                const float* stats2, const float* g1, const float* b1, const float* g2, float* dx, float* dcls_ws,
+                                float* dg1, float* db1, float* dg2, float* db2, int64_t B, int64_t P, int64_t Tp, int64_t D) {
+    OWL_CHECK_ARG(dfeats && x && cls_ln && stats1 && stats2 && g1 && b1 && g2 && dx && dcls_ws && dg1 && db1 && dg2 && db2, "owl_merge_ln_bwd: null pointer");
+    OWL_CHECK_ARG(D % 4 == 0 && D <= 256 * LN_MAXV, "owl_merge_ln_bwd: D must be a multiple of 4 and <= 1024");
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(dcls_ws, 0, (size_t)(B * D) * sizeof(float), s);
+    OWL_CHECK_ARG(e == hipSuccess, "owl_merge_ln_bwd: memset failed");
+    const int rpb = 64;
+    hipLaunchKernelGGL(merge_ln_bwd_kernel, dim3((unsigned)((P + rpb - 1) / rpb), (unsigned)B), dim3(256), 0, s, dfeats, x, cls_ln,
+                       (const float2*)stats1, (const float2*)stats2, g1, b1, g2, dx, dcls_ws, dg1, db1, dg2, db2, P, Tp, (int)D, rpb);
+    OWL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(cls_ln_bwd_kernel, dim3((unsigned)B), dim3(64), 0, s, dcls_ws, x, (const float2*)stats1, g1, dx, dg1, db1, Tp, (int)D);
+    OWL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// class head backward (ref src/models.py:25-36): s_c = inv * (e . qhat_j*), inv = 1/(|e|+1e-6)
+//   de = inv * sum_c g_c qhat_{j*c} - (sum_c g_c s_c) * inv * e/|e| ;  dqhat_j += sum_rows [j = j*] g_c inv e
+// workgroup = (RPB rows) x (256-column chunk of Dt): thread t owns column chunk*256 + t; dqhat partials
+// for the chunk accumulate in LDS and are flushed with one atomic per (query, column) per workgroup.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void class_sims_bwd_kernel(const float* __restrict__ dsims, const float* __restrict__ sims,
+                                                             const unsigned char* __restrict__ argmax, const float* __restrict__ inv_norm,
+                                                             const float* __restrict__ e, const float* __restrict__ qhat, bf16_t* de,
+                                                             float* dqhat, int64_t rows, int Dt, int C, int rows_per_block) {
+    __shared__ float lq[32][256];
+    __shared__ float acc[32][256];
+    __shared__ float rowg[32];     // g_c * inv for the current row, by query j (0 elsewhere)
+    __shared__ float rowscal[2];
+    const int t = threadIdx.x;
+    const int k = blockIdx.y * 256 + t;
+    const bool kv = k < Dt;
+    for (int j = 0; j < 32; j++) { lq[j][t] = kv ? qhat[j * Dt + k] : 0.f; acc[j][t] = 0.f; }
+    __syncthreads();
+    const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block, r_end = min(rows, r_begin + rows_per_block);
+    for (int64_t r = r_begin; r < r_end; r++) {
+        if (t < 32) {
+            const int j = t, c = j / 3;
+            float gj = 0.f;
+            if (c < C && (int)argmax[r * C + c] == j - 3 * c) gj = dsims[r * C + c] * inv_norm[r];
+            rowg[j] = gj;
+            float gs = (j < C) ? dsims[r * C + j] * sims[r * C + j] : 0.f;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) gs += __shfl_xor(gs, o, 64);
+            if (j == 0) { rowscal[0] = gs; rowscal[1] = inv_norm[r]; }
+        }
+        __syncthreads();
+        const float inv = rowscal[1];
+        const float nrm = 1.0f / inv - 1e-6f;
+        const float coef_e = rowscal[0] * inv / nrm;
+        if (kv) {
+            const float ev = e[r * Dt + k];
+            float d = -coef_e * ev;
+            for (int j = 0; j < 3 * C; j++) {
+                const float gj = rowg[j];
+                if (gj != 0.f) { d += gj * lq[j][t]; acc[j][t] += gj * ev; }
+            }
+            de[r * Dt + k] = f2bf(d);
+        }
+        __syncthreads();
+    }
+    if (kv)
+        for (int j = 0; j < 3 * C; j++) atomicAdd(dqhat + j * Dt + k, acc[j][t]);
+}
+
+// dQ from dqhat: qhat = Q/|Q| + 1e-6  ->  dQ = (dqhat - (dqhat . Qn) Qn) / |Q|,  Qn = Q/|Q|
+__global__ __launch_bounds__(64) void qhat_bwd_kernel(const float* __restrict__ dqhat, const float* __restrict__ q, float* dq, int Dt) {
+    const int j = blockIdx.x, lane = threadIdx.x;
+    float ss = 0.f, dt = 0.f;
+    for (int k = lane; k < Dt; k += 64) { const float v = q[(int64_t)j * Dt + k]; ss += v * v; dt += v * dqhat[(int64_t)j * Dt + k]; }
+    ss = wave_sum(ss); dt = wave_sum(dt);
+    const float n = sqrtf(ss);
+    for (int k = lane; k < Dt; k += 64) {
+        const float qn = q[(int64_t)j * Dt + k] / n;
+        dq[(int64_t)j * Dt + k] += (dqhat[(int64_t)j * Dt + k] - (dt / n) * qn) / n;
+    }
+}
+
+extern "C" int owl_class_sims_bwd(void* stream, const float* dsims, const float* sims, const unsigned char* argmax, const float* inv_norm,
+                                  const float* e, const float* qhat32, const float* queries, void* de_bf16, float* dqhat_ws,
+                                  float* dqueries, int64_t rows, int64_t Dt, int64_t C) {
+    OWL_CHECK_ARG(dsims && sims && argmax && inv_norm && e && qhat32 && queries && de_bf16 && dqhat_ws && dqueries, "owl_class_sims_bwd: null pointer");
+    OWL_CHECK_ARG(3 * C <= 32, "owl_class_sims_bwd: 3*C <= 32");
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t er = hipMemsetAsync(dqhat_ws, 0, (size_t)(32 * Dt) * sizeof(float), s);
+    OWL_CHECK_ARG(er == hipSuccess, "owl_class_sims_bwd: memset failed");
+    const int rpb = 256;
+    hipLaunchKernelGGL(class_sims_bwd_kernel, dim3((unsigned)((rows + rpb - 1) / rpb), (unsigned)((Dt + 255) / 256)), dim3(256), 0, s, dsims, sims, argmax, inv_norm, e,
+                       qhat32, (bf16_t*)de_bf16, dqhat_ws, rows, (int)Dt, (int)C, rpb);
+    OWL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(qhat_bwd_kernel, dim3((unsigned)(3 * C)), dim3(64), 0, s, dqhat_ws, queries, dqueries, (int)Dt);
+    OWL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// box head tail backward: d(xyxy) -> d(cx,cy,w,h) -> sigmoid' -> dense2 backward fused with dense1's
+// erf-GELU derivative.  du1 = (dpre . W2) * gelu'(u1) (bf16) ; dW2 += dpre^T h1 ; db2 += sum dpre.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dgelu_erf(float u) {
+    return 0.5f * (1.0f + erff(u * 0.70710678118654752f)) + u * 0.39894228040143268f * __expf(-0.5f * u * u);
+}
+
+__global__ __launch_bounds__(256) void box_final_bwd_kernel(const float* __restrict__ dboxes, const float* __restrict__ sig,
+                                                            const bf16_t* __restrict__ h1, const bf16_t* __restrict__ u1,
+                                                            const float* __restrict__ w2, bf16_t* du1, float* dw2, float* db2,
+                                                            int64_t rows, int D, int rows_per_block) {
+    __shared__ float4 dpre_s[256];
+    const int t = threadIdx.x;
+    const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block, r_end = min(rows, r_begin + rows_per_block);
+    float accw[4][4];   // [k][column slot]
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) accw[k][c] = 0.f;
+    float4 accb = make_float4(0, 0, 0, 0);
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += 256) {
+        const int64_t r = r0 + t;
+        float4 dp = make_float4(0, 0, 0, 0);
+        if (r < r_end) {
+            const float4 g = *(const float4*)(dboxes + r * 4), s = *(const float4*)(sig + r * 4);
+            const float dcx = g.x + g.z, dcy = g.y + g.w, dw = 0.5f * (g.z - g.x), dh = 0.5f * (g.w - g.y);
+            dp = make_float4(dcx * s.x * (1.f - s.x), dcy * s.y * (1.f - s.y), dw * s.z * (1.f - s.z), dh * s.w * (1.f - s.w));
+            accb.x += dp.x; accb.y += dp.y; accb.z += dp.z; accb.w += dp.w;
+        }
+        __syncthreads();
+        dpre_s[t] = dp;
+        __syncthreads();
+        const int nr = (int)min((int64_t)256, r_end - r0);
+        for (int rr = 0; rr < nr; rr++) {
+            const float4 d = dpre_s[rr];
+            const int64_t row = r0 + rr;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int col = t + c * 256;
+                if (col < D) {
+                    const float hv = bf2f(h1[row * D + col]), uv = bf2f(u1[row * D + col]);
+                    const float dh1 = d.x * w2[col] + d.y * w2[D + col] + d.z * w2[2 * D + col] + d.w * w2[3 * D + col];
+                    du1[row * D + col] = f2bf(dh1 * dgelu_erf(uv));
+                    accw[0][c] += d.x * hv; accw[1][c] += d.y * hv; accw[2][c] += d.z * hv; accw[3][c] += d.w * hv;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int col = t + c * 256;
+        if (col < D)
+#pragma unroll
+            for (int k = 0; k < 4; k++) atomicAdd(dw2 + k * D + col, accw[k][c]);
+    }
+    accb.x = wave_sum(accb.x); accb.y = wave_sum(accb.y); accb.z = wave_sum(accb.z); accb.w = wave_sum(accb.w);
+    if ((t & 63) == 0) { atomicAdd(db2 + 0, accb.x); atomicAdd(db2 + 1, accb.y); atomicAdd(db2 + 2, accb.z); atomicAdd(db2 + 3, accb.w); }
+}
+
+extern "C" int owl_box_final_bwd(void* stream, const float* dboxes, const float* sig, const void* h1_bf16, const void* u1_bf16,
+                                 const float* w2, void* du1_bf16, float* dw2, float* db2, int64_t rows, int64_t D) {
+    OWL_CHECK_ARG(dboxes && sig && h1_bf16 && u1_bf16 && w2 && du1_bf16 && dw2 && db2, "owl_box_final_bwd: null pointer");
+    OWL_CHECK_ARG(D <= 1024, "owl_box_final_bwd: D <= 1024");
+    const int rpb = 256;
+    hipLaunchKernelGGL(box_final_bwd_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, dboxes, sig,
+                       (const bf16_t*)h1_bf16, (const bf16_t*)u1_bf16, w2, (bf16_t*)du1_bf16, dw2, db2, rows, (int)D, rpb);
+    OWL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// transpose bf16 [R,C] -> [C,R] with optional column sums (bias gradient) in the same pass.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_colsum_kernel(const bf16_t* __restrict__ in, int64_t ld_in, bf16_t* __restrict__ out,
+                                                               int64_t ld_out, float* colsum, int64_t R, int64_t C, int row_tiles) {
+    __shared__ bf16_t tile[64][66];
+    __shared__ float cs[4][64];
+    const int64_t c0 = (int64_t)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    float acc = 0.f;
+    for (int rt = 0; rt < row_tiles; rt++) {
+        const int64_t r0 = ((int64_t)blockIdx.y * row_tiles + rt) * 64;
+        if (r0 >= R) break;
+        __syncthreads();
+        for (int i = ty; i < 64; i += 4) {
+            const int64_t r = r0 + i, c = c0 + tx;
+            const bf16_t v = (r < R && c < C) ? in[r * ld_in + c] : (bf16_t)0;
+            tile[i][tx] = v;
+            acc += bf2f(v);
+        }
+        __syncthreads();
+        if (out)
+            for (int i = ty; i < 64; i += 4) {
+                const int64_t c = c0 + i, r = r0 + tx;
+                if (c < C && r < R) out[c * ld_out + r] = tile[tx][i];
+            }
+    }
+    if (colsum) {
+        cs[ty][tx] = acc;
+        __syncthreads();
+        if (ty == 0 && c0 + tx < C) atomicAdd(colsum + c0 + tx, cs[0][tx] + cs[1][tx] + cs[2][tx] + cs[3][tx]);
+    }
+}
+
+extern "C" int owl_transpose_colsum_bf16(void* stream, const void* in, int64_t ld_in, void* out_t, int64_t ld_out, float* colsum,
+                                         int64_t R, int64_t C) {
+    OWL_CHECK_ARG(in && (out_t || colsum) && R > 0 && C > 0, "owl_transpose_colsum_bf16: bad args");
+    const int row_tiles = 8;
+    dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + 64 * row_tiles - 1) / (64 * row_tiles)));
+    hipLaunchKernelGGL(transpose_colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, ld_in, (bf16_t*)out_t, ld_out, colsum, R, C, row_tiles);
+    OWL_LAUNCH_CHECK();
+    return 0;
+}
+
+// f32 column sums (bias gradient of an f32 upstream, e.g. the residual-stream gradient)
+__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ in, float* colsum, int64_t R, int64_t C, int rows_per_block) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
+    float acc = 0.f;
+    for (int64_t r = r0; r < r1; r++) acc += in[r * C + c];
+    atomicAdd(colsum + c, acc);
+}
+
+extern "C" int owl_colsum_f32(void* stream, const float* in, float* colsum, int64_t R, int64_t C) {
+    OWL_CHECK_ARG(in && colsum, "owl_colsum_f32: null pointer");
+    const int rpb = 256;
+    hipLaunchKernelGGL(colsum_f32_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)((R + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, in, colsum, R, C, rpb);
+    OWL_LAUNCH_CHECK();
+    return 0;
+}

@@ -110,3 +110,34 @@ def transpose_bf16(src, dst, R, C, ld_in=None, ld_out=None):
     _lib.call("owl_transpose_bf16", stream(), src, ld_in if ld_in is not None else src.shape[-1], dst,
               ld_out if ld_out is not None else dst.shape[-1], R, C)
     return dst
+
+
+# ---- backward-side wrappers ---------------------------------------------------------------------------
+def layernorm_bwd(dy, x, stats, gamma, dres, dx, dgamma, dbeta, rows, D):
+    _lib.call("owl_layernorm_bwd", stream(), dy, 1 if dy.dtype == torch.bfloat16 else 0, x, stats, gamma, dres, dx,
+              dgamma, dbeta, rows, D)
+
+
+def merge_ln_bwd(dfeats, x, cls_ln, st1, st2, g1, b1, g2, dx, dcls_ws, dg1, db1, dg2, db2, B, P, Tp, D):
+    _lib.call("owl_merge_ln_bwd", stream(), dfeats, x, cls_ln, st1, st2, g1, b1, g2, dx, dcls_ws, dg1, db1, dg2, db2, B, P, Tp, D)
+
+
+def class_sims_bwd(dsims, sims, argmax, inv_norm, e, qhat32, queries, de, dqhat_ws, dqueries, rows, Dt, C):
+    _lib.call("owl_class_sims_bwd", stream(), dsims, sims, argmax, inv_norm, e, qhat32, queries, de, dqhat_ws, dqueries, rows, Dt, C)
+
+
+def box_final_bwd(dboxes, sig, h1, u1, w2, du1, dw2, db2, rows, D):
+    _lib.call("owl_box_final_bwd", stream(), dboxes, sig, h1, u1, w2, du1, dw2, db2, rows, D)
+
+
+def transpose_colsum(src, dst, colsum, R, C, ld_in=None, ld_out=None):
+    _lib.call("owl_transpose_colsum_bf16", stream(), src, ld_in if ld_in is not None else src.shape[-1], dst,
+              (ld_out if ld_out is not None else dst.shape[-1]) if dst is not None else 0, colsum, R, C)
+
+
+def colsum_f32(src, colsum, R, C):
+    _lib.call("owl_colsum_f32", stream(), src, colsum, R, C)
+
+
+def attention_bwd(qkv, qkvT, dO, dOT, O, lse, dvec, dqkv, B, H, T, Tp, scale):
+    _lib.call("owl_attention_bwd_bf16", stream(), qkv, qkvT, dO, dOT, O, lse, dvec, dqkv, B, H, T, Tp, float(scale))

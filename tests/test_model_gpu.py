@@ -65,3 +65,133 @@ def test_forward_b16_matches_reference_fixture_f2(golden_dir):
     with torch.no_grad():
         pb8, _, ps8, _ = model(imgs)
     assert _maxerr(pb8[0], pb[0]) < 1e-6 and _maxerr(ps8[0], ps[0]) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------
+# full train step: forward + matcher/loss + backward through the reference call surface
+# ---------------------------------------------------------------------------------------------------
+from owl_vit_object_detection_amd.losses import PushPullLoss  # noqa: E402
+
+LOSS_KEYS = ("loss_ce", "loss_bg", "loss_bbox", "loss_giou")
+
+
+def _step_hip(cfg, Wnp, img, labels, boxes, scales):
+    model = OwlViT(cfg, Wnp, DEV)
+    crit = PushPullLoss(cfg.n_classes, scales)
+    pb, _, ps, _ = model(torch.from_numpy(img).to(DEV))
+    losses = crit(ps, [torch.from_numpy(l).to(DEV) for l in labels], pb, [torch.from_numpy(b).to(DEV) for b in boxes])
+    loss = losses["loss_ce"] + losses["loss_bg"] + losses["loss_bbox"] + losses["loss_giou"]   # ref main.py:84-89
+    loss.backward()
+    grads = {n: p.grad.detach().float().cpu() for n, p in model.named_parameters() if p.requires_grad}
+    return model, crit, {k: float(v) for k, v in losses.items()}, grads, pb.detach(), ps.detach()
+
+
+def _grad_report(grads, ref, tag):
+    """rel-L2 per tensor, measured against max(|ref|, 1e-3 * largest |ref|): tensors whose true gradient
+    is ~0 (k_proj.bias: softmax is invariant to a key bias) are judged on an absolute scale."""
+    floor = 1e-3 * max(float(r.float().norm()) for r in ref.values())
+    worst, worst_cos = 0.0, 1.0
+    lines = []
+    for n, r in ref.items():
+        g = grads[n]
+        r = r.float()
+        rel = float((g - r).norm() / max(float(r.norm()), floor))
+        cos = float((g * r).sum() / (g.norm() * r.norm() + 1e-20)) if float(r.norm()) > floor else 1.0
+        lines.append(f"  {n:58s} rel_l2={rel:.3e} cos={cos:.5f} |ref|={float(r.norm()):.3e}")
+        worst = max(worst, rel)
+        worst_cos = min(worst_cos, cos)
+    print(f"[{tag}] worst rel-L2 grad error {worst:.3e}, worst cos {worst_cos:.5f}\n" + "\n".join(lines))
+    return worst, worst_cos
+
+
+@pytest.mark.parametrize("cname,B", [("tiny", 1), ("tiny", 3), ("small", 2)])
+def test_backward_chain_matches_oracle_given_same_upstream(cname, B):
+    """Backward kernels in isolation: identical upstream (d_boxes, d_sims) into the HIP backward and into
+    the oracle's autograd -- removes the loss's 1/|sim| amplification of bf16 forward noise."""
+    cfg = get_config(cname)
+    Wnp = weights.make_weights(cfg)
+    img = synth.make_images(cfg, B)
+    g = torch.Generator().manual_seed(5)
+    d_boxes = torch.randn(B, cfg.patches, 4, generator=g) * 0.1
+    d_sims = torch.randn(B, cfg.patches, cfg.n_classes, generator=g) * 0.1
+    w = {k: torch.from_numpy(v) for k, v in Wnp.items()}
+    names = O.trainable_names(w)
+    ww = {n: (t.clone().requires_grad_(True) if n in names else t) for n, t in w.items()}
+    taps = {}
+    rb, rs = O.model_forward(cfg, ww, torch.from_numpy(img), taps)
+    # MaxPool1d(3) routes each class gradient to ONE of three prompts; where the top two prompts are within
+    # bf16 forward noise of each other the routing is a coin flip, so those (row, class) pairs get no upstream
+    with torch.no_grad():
+        e = torch.nn.functional.linear(taps["feats"], w["class_predictor.dense0.weight"], w["class_predictor.dense0.bias"])
+        e = e / (torch.linalg.norm(e, dim=-1, keepdim=True) + 1e-6)
+        q = w["queries"] / torch.linalg.norm(w["queries"], dim=-1, keepdim=True) + 1e-6
+        top2 = (e @ q.transpose(1, 2)).view(B, cfg.patches, cfg.n_classes, 3).topk(2, dim=-1).values
+        d_sims = d_sims * ((top2[..., 0] - top2[..., 1]) > 0.02).float()
+    model = OwlViT(cfg, Wnp, DEV)
+    pb, _, ps, _ = model(torch.from_numpy(img).to(DEV))
+    torch.autograd.backward([pb, ps], [d_boxes.to(DEV), d_sims.to(DEV)])
+    grads = {n: p.grad.detach().float().cpu() for n, p in model.named_parameters() if p.requires_grad}
+    torch.autograd.backward([rb, rs], [d_boxes, d_sims])
+    gref = {n: ww[n].grad for n in names}
+    worst, worst_cos = _grad_report(grads, gref, f"backward-only {cname} B={B}")
+    assert worst < 3e-2 and worst_cos > 0.999
+
+
+@pytest.mark.parametrize("cname,B", [("tiny", 1), ("tiny", 3), ("small", 2)])
+def test_train_step_matches_oracle(cname, B):
+    cfg = get_config(cname)
+    Wnp = weights.make_weights(cfg)
+    img = synth.make_images(cfg, B)
+    labels, boxes = synth.make_targets(cfg, B, max_boxes=6)
+    scales = synth.class_scales(cfg, labels)
+    model, crit, lg, grads, pb, ps = _step_hip(cfg, Wnp, img, labels, boxes, scales)
+    w = {k: torch.from_numpy(v) for k, v in Wnp.items()}
+    (rb, rs), lo, gref = O.train_step(cfg, w, torch.from_numpy(img), [torch.from_numpy(l) for l in labels],
+                                      [torch.from_numpy(b) for b in boxes], torch.from_numpy(scales))
+    assert _maxerr(pb, rb) < 1e-2 and _maxerr(ps, rs) < 1e-2
+    # matched loss within the bf16 bar (relative for the large class terms)
+    for k in LOSS_KEYS:
+        assert lg[k] == pytest.approx(float(lo[k]), rel=2e-2, abs=1e-2), (k, lg[k], float(lo[k]))
+    assert set(grads) == set(gref) and len(grads) == 29
+    # end-to-end gradients are a sanity check only: the class terms' -w/|sim| slope and the max-over-prompts
+    # routing amplify the ~1e-3 bf16 forward deviation (the strict kernel check is the backward-only test)
+    worst, worst_cos = _grad_report(grads, gref, f"{cname} B={B}")
+    assert worst_cos > 0.99
+
+
+def test_train_step_matches_reference_fixture_f1(golden_dir):
+    cfg = get_config("tiny")
+    g = np.load(os.path.join(golden_dir, "f1_tiny.npz"))
+    img = synth.make_images(cfg, 1)
+    labels, boxes = synth.make_targets(cfg, 1, max_boxes=6)
+    model, crit, lg, grads, pb, ps = _step_hip(cfg, weights.make_weights(cfg), img, labels, boxes, g["scales"])
+    assert np.array_equal(crit.last["target_classes"][0].cpu().numpy(), g["target_classes"])
+    for k in LOSS_KEYS:
+        assert lg[k] == pytest.approx(float(g[k]), rel=2e-2, abs=1e-2), k
+    ref = {k[5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("grad/")}
+    worst, worst_cos = _grad_report(grads, ref, "tiny vs reference fixture")
+    assert worst_cos > 0.99
+
+
+def test_train_step_b16_matches_reference_fixture_f2(golden_dir):
+    """BASELINE configs[2] shape family at batch 1: full train step of owlvit-base-patch16 vs the
+    reference's CPU run (losses, per-tensor gradient norms and leading elements)."""
+    cfg = get_config("owlvit-base-patch16")
+    g = np.load(os.path.join(golden_dir, "f2_b16.npz"))
+    img = synth.make_images(cfg, 1)
+    labels, boxes = synth.make_targets(cfg, 1, max_boxes=16)
+    model, crit, lg, grads, pb, ps = _step_hip(cfg, weights.make_weights(cfg), img, labels, boxes, g["scales"])
+    same = float((crit.last["target_classes"][0].cpu() == torch.from_numpy(g["target_classes"])).float().mean())
+    print("B/16 losses", lg, "ref", {k: float(g[k]) for k in LOSS_KEYS}, "target_classes agreement", same)
+    assert same == 1.0
+    for k in LOSS_KEYS:
+        assert lg[k] == pytest.approx(float(g[k]), rel=2e-2, abs=1e-2), k
+    for n, gr in grads.items():
+        ref_norm = float(g["gradnorm/" + n])
+        if ref_norm < 1e-5:
+            assert float(gr.double().norm()) < 1e-3, n          # k_proj.bias: true gradient is zero
+            continue
+        assert float(gr.double().norm()) == pytest.approx(ref_norm, rel=0.3), n
+        head = torch.from_numpy(g["gradhead/" + n])
+        cos = float((gr.reshape(-1)[:64] * head).sum() / (gr.reshape(-1)[:64].norm() * head.norm() + 1e-20))
+        assert cos > 0.98, (n, cos)
