@@ -98,6 +98,11 @@ int owl_box_final_bwd(void* stream, const float* dboxes, const float* sig, const
 int owl_transpose_colsum_bf16(void* stream, const void* in, int64_t ld_in, void* out_t, int64_t ld_out, float* colsum, int64_t R, int64_t C);
 int owl_colsum_f32(void* stream, const float* in, float* colsum, int64_t R, int64_t C);
 
+/* ---- fused AdamW on the flat trainable bucket (replaces torch.optim.AdamW.step, ref main.py:56-60,91) -----
+ * decoupled weight decay, bias-corrected; g is pre-scaled by grad_scale (1/world after the sum all-reduce);
+ * optionally refreshes the bf16 compute copy in the same pass                                              */
+int owl_adamw_step(void* stream, float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale);
+
 /* ---- utilities ------------------------------------------------------------------------------------ */
 int owl_cast_f32_bf16(void* stream, const float* in, void* out, int64_t n);
 int owl_transpose_bf16(void* stream, const void* in, int64_t ld_in, void* out, int64_t ld_out, int64_t R, int64_t C);

@@ -77,7 +77,10 @@ def _bws(model, B):
         dx=z(M, D, f32, dev), dxb=z(M, D, bf, dev), du=z(M, I, bf, dev), dh=z(M, D, bf, dev), dxm=z(M, D, f32, dev),
         datt=z(M, D, bf, dev), dattT=torch.zeros(B * D * Tp + 256, dtype=bf, device=dev), dqkv=z(M, 3 * D, bf, dev),
         dvec=torch.zeros(B, H, Tp, device=dev),
-        tA=torch.zeros(wide, max(Mp, Mhp), dtype=bf, device=dev), tB=torch.zeros(wide, max(Mp, Mhp), dtype=bf, device=dev),
+        # transposed-operand scratch for the dW GEMMs; token-row and head-row users get their own buffers so
+        # that the zero pad columns [rows, rows_pad) of each are never dirtied by the other row count
+        tA=torch.zeros(wide, Mp, dtype=bf, device=dev), tB=torch.zeros(wide, Mp, dtype=bf, device=dev),
+        tAh=torch.zeros(max(D, Dt), Mhp, dtype=bf, device=dev), tBh=torch.zeros(max(D, Dt), Mhp, dtype=bf, device=dev),
         wT=torch.zeros(wide * max(D, I), dtype=bf, device=dev),
     )
     model._ws[key] = ws
@@ -111,17 +114,15 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
         return out
 
     def dW(dy, x, grad_w, n_out, n_in, rows, rows_pad, grad_b=None):
-        """grad_w[n_out, n_in] += dy[rows, n_out]^T x[rows, n_in];  grad_b += colsum(dy)  (one pass each)."""
-        tA = bw["tA"][:n_out, :rows_pad]
-        tB = bw["tB"][:n_in, :rows_pad]
-        ld = bw["tA"].shape[1]
-        ops.transpose_colsum(dy, bw["tA"], grad_b, rows, n_out, ld_in=dy.shape[-1], ld_out=ld)
-        ops.transpose_colsum(x, bw["tB"], None, rows, n_in, ld_in=x.shape[-1], ld_out=ld)
-        ops.gemm(ops.EPI_ATOMIC_F32, bw["tA"], bw["tB"], grad_w, M=n_out, N=n_in, K=rows_pad, lda=ld, ldw=ld, ldo=n_in,
+        """grad_w[n_out, n_in] += dy[rows, n_out]^T x[rows, n_in];  grad_b += colsum(dy)  (one pass each).
+        Pad columns [rows, rows_pad) of the scratch stay zero: never written, buffers start zeroed."""
+        tA, tB = (bw["tAh"], bw["tBh"]) if rows == Mh else (bw["tA"], bw["tB"])
+        ld = tA.shape[1]
+        assert ld == rows_pad
+        ops.transpose_colsum(dy, tA, grad_b, rows, n_out, ld_in=dy.shape[-1], ld_out=ld)
+        ops.transpose_colsum(x, tB, None, rows, n_in, ld_in=x.shape[-1], ld_out=ld)
+        ops.gemm(ops.EPI_ATOMIC_F32, tA, tB, grad_w, M=n_out, N=n_in, K=rows_pad, lda=ld, ldw=ld, ldo=n_in,
                  a_rows=n_out, w_rows=n_in, splits=_split_k(n_out, n_in, rows_pad))
-
-    # pad columns [rows, rows_pad) of the transposed scratch must be zero: rows beyond `rows` are never
-    # written by the transposes and the buffers start zeroed; M and Mh never change for a given B.
 
     # ---- class head ---------------------------------------------------------------------------------
     ops.class_sims_bwd(d_sims, sims, ws["argmax"], ws["inv_norm"], ws["e"], ws["qhat"], P_["queries"], bw["de"], bw["dqhat"],

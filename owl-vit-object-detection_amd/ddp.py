@@ -1,0 +1,61 @@
+"""Data-parallel training: one process per GPU, ONE all-reduce per step.
+
+The reference has no distributed code; images are independent units, so the build
+shards the batch across ranks (pure data parallel, full weight replica per GPU) and exchanges exactly one
+contiguous buffer per step: the flat gradient bucket (8 684 292 f32 = 34.7 MB for B/16, C = 10).  On ROCm
+the "nccl" backend IS RCCL; over xGMI a ring all-reduce of 34.7 MB on 8 GPUs is ~0.4 ms, far below the
+compute time of a step, so it is issued once after backward on the compute stream (no bucketing games).
+Loss semantics: mean over images; with equal per-rank batches the mean of per-rank
+means equals the global mean, so the summed bucket is scaled by 1/world inside the fused optimizer.
+The same code runs on CPU tensors with the gloo backend (tests/test_ddp_cpu.py).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str = None):
+    """torchrun-style bootstrap (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def allreduce_flat(flat_grad: torch.Tensor, group=None) -> torch.Tensor:
+    """SUM all-reduce of the flat gradient bucket, in place (single collective per step)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
+    return flat_grad
+
+
+def broadcast_flat(flat_param: torch.Tensor, src: int = 0, group=None) -> torch.Tensor:
+    """Make every rank start from rank `src`'s trainable parameters."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(flat_param, src=src, group=group)
+    return flat_param
+
+
+class DataParallel:
+    """Couples a model (anything exposing .flat_grad) with a fused optimizer (anything exposing
+    .grad_scale / .step / .zero_grad): `sync_and_step()` = all-reduce(sum) -> scale 1/world -> AdamW."""
+
+    def __init__(self, model, optimizer, group=None):
+        self.model, self.optimizer, self.group = model, optimizer, group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.optimizer.grad_scale = 1.0 / self.world
+        if hasattr(model, "flat_param"):
+            broadcast_flat(model.flat_param, 0, group)
+
+    def sync_and_step(self):
+        allreduce_flat(self.model.flat_grad, self.group)
+        self.optimizer.step()

@@ -1,0 +1,43 @@
+"""Fused AdamW over the model's flat trainable bucket.
+
+Drop-in for the reference's optimizer (ref main.py:56-60: `torch.optim.AdamW(model.parameters(), lr,
+weight_decay)`, single param group -- weight decay also hits LayerNorm affine, biases and the query bank):
+same constructor keywords, `zero_grad()` / `step()`.  One HIP kernel touches (param, grad, m, v) once and
+refreshes the bf16 compute copy.  torch.optim.AdamW on `model.parameters()` also works (the parameters are
+ordinary f32 leaves); this class is the fast path.
+"""
+import torch
+
+from . import _lib, ops
+from .autograd import _attach_grads
+
+
+class FusedAdamW:
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        self.model = model
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), betas, float(eps), float(weight_decay)
+        self.exp_avg = torch.zeros_like(model.flat_param)
+        self.exp_avg_sq = torch.zeros_like(model.flat_param)
+        self.step_count = 0
+        self.grad_scale = 1.0          # set to 1/world_size by the data-parallel wrapper
+
+    def zero_grad(self, set_to_none: bool = False):
+        _attach_grads(self.model)
+        self.model.flat_grad.zero_()
+
+    @torch.no_grad()
+    def step(self):
+        m = self.model
+        _attach_grads(m)
+        self.step_count += 1
+        _lib.call("owl_adamw_step", ops.stream(), m.flat_param, m.flat_grad, self.exp_avg, self.exp_avg_sq, m.flat_bf16,
+                  m.flat_numel, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count,
+                  float(self.grad_scale))
+
+    def state_dict(self):
+        return dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, lr=self.lr, betas=self.betas,
+                    eps=self.eps, weight_decay=self.weight_decay)
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])

@@ -1,0 +1,43 @@
+"""smoke(): one tiny train step of the hot path on cuda:0 (HIP kernels through the C ABI), checked against
+the CPU oracle.  Imported only by __graft_entry__.smoke()."""
+import torch
+
+
+def smoke() -> None:
+    from oracle import owl_oracle as O           # checker only
+    from . import _lib, synth, weights
+    from .config import get_config
+    from .losses import PushPullLoss
+    from .models import OwlViT
+    from .optim import FusedAdamW
+
+    assert torch.cuda.is_available(), "smoke() needs a GPU"
+    _lib.load()                                    # fails loudly if libowlhip.so is missing
+    dev = torch.device("cuda", 0)
+    cfg = get_config("tiny")
+    Wnp = weights.make_weights(cfg)
+    B = 2
+    img = synth.make_images(cfg, B)
+    labels, boxes = synth.make_targets(cfg, B, max_boxes=6)
+    scales = synth.class_scales(cfg, labels)
+    model = OwlViT(cfg, Wnp, dev)
+    crit = PushPullLoss(cfg.n_classes, scales)
+    opt = FusedAdamW(model, lr=3e-6, weight_decay=0.1)
+    opt.zero_grad()
+    pb, _, ps, _ = model(torch.from_numpy(img).to(dev))
+    losses = crit(ps, [torch.from_numpy(l).to(dev) for l in labels], pb, [torch.from_numpy(b).to(dev) for b in boxes])
+    (losses["loss_ce"] + losses["loss_bg"] + losses["loss_bbox"] + losses["loss_giou"]).backward()
+    before = model.flat_param.clone()
+    opt.step()
+    torch.cuda.synchronize()
+    w = {k: torch.from_numpy(v) for k, v in Wnp.items()}
+    (rb, rs), lo, gref = O.train_step(cfg, w, torch.from_numpy(img), [torch.from_numpy(l) for l in labels],
+                                      [torch.from_numpy(b) for b in boxes], torch.from_numpy(scales))
+    eb = float((pb.detach().cpu() - rb).abs().max()); es = float((ps.detach().cpu() - rs).abs().max())
+    assert eb < 1e-2 and es < 1e-2, (eb, es)
+    for k, v in lo.items():
+        assert abs(float(losses[k]) - float(v)) <= 1e-2 + 2e-2 * abs(float(v)), (k, float(losses[k]), float(v))
+    g = model.p("box_head.dense1.weight").grad.cpu(); r = gref["box_head.dense1.weight"]
+    assert float((g * r).sum() / (g.norm() * r.norm())) > 0.99
+    assert float((model.flat_param - before).abs().max()) > 0, "optimizer did not move the parameters"
+    print(f"smoke ok: max|d boxes|={eb:.2e} max|d sims|={es:.2e} losses=" + str({k: round(float(v), 4) for k, v in losses.items()}))
