@@ -37,9 +37,19 @@ int owl_abi_version(void);
  * epi: 0 bias->bf16 | 1 bias+quick_gelu->bf16 (aux = pre-activation) | 2 bias+erf-gelu->bf16 |
  *      3 resid+acc+bias->f32 | 4 alpha*acc(+bias)->f32 | 5 atomicAdd f32 (split-K) |
  *      6 per-head transposed bf16 out_t[b][n][t] (m = b*Tp + t) | 8 acc*quick_gelu'(aux)->bf16 |
- *      9 acc*gelu'(aux)->bf16 | 10 out f32 += acc.
+ *      9 acc*gelu'(aux)->bf16 | 10 out f32 += acc | 11 split-K slab.
  * a_rows / w_rows clamp the tile loads; M, N guard the stores; K % 64 == 0.                      */
 int owl_gemm_nt_bf16(void* stream, int epi, const void* A, int64_t lda, int64_t a_rows, const void* W, int64_t ldw, int64_t w_rows, const float* bias, void* out, int64_t ldo, const float* resid, void* aux, int64_t ld_aux, int64_t M, int64_t N, int64_t K, float alpha, int splits, int64_t Tp);
+
+/* tile override for tests / tuning: 0 auto (256x256x64 8-wave tiles for large shapes, 128x128x64 otherwise), 128, 256 */
+int owl_gemm_set_tile(int tile);
+/* persistent scheduling (one workgroup per CU walks tiles with cross-tile prefetch): 1 on (default), 0 off */
+int owl_gemm_set_persistent(int on);
+int owl_gemm_debug_nostore(int on);
+int owl_gemm_debug_slots(int n);
+/* epi 11 = split-K partial slabs out[split][M][ldo] (f32, no atomics); reduce them with owl_slab_reduce */
+int owl_gemm_effective_splits(int64_t K, int splits);
+int owl_slab_reduce(void* stream, const float* slabs, float* out, int64_t n, int64_t slab_stride, int nsplit, int accumulate);
 
 /* ---- patch embedding (HF5:282-288 Conv2d k=s=patch, no bias; HF5:336-343 flatten + positions) ----
  * im2row-free: the A-operand loader gathers 16-byte runs of each patch row straight from the

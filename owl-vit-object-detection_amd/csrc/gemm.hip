@@ -4,116 +4,116 @@
 // patch-embed conv as an im2row-free GEMM; HF5:994-998 box head; ref src/models.py:25 class dense0;
 // and their dX / dW backward forms).
 //
-// CDNA4 structure: 128x128x64 block tile, 4 waves (2x2), each wave a 64x64 sub-tile as 2x2
-// v_mfma_f32_32x32x16_bf16 accumulators.  Operand tiles go HBM -> LDS by direct LDS-DMA
-// (global_load_lds_dwordx4, 1 KiB per wave-instruction), double-buffered, one barrier per K-step.
-// The LDS image of a [128 rows][64 k] bf16 tile is row-linear (the DMA destination is
-// lane-linear) with the 16-byte chunk index XOR-swizzled by ((row>>1)&7) -- applied to the per-lane
-// SOURCE address and again on the ds_read_b128 address -- which makes every ds_read_b128 lane group
-// conflict-free.  Blocks are remapped so that consecutive tiles of one A row-panel run on the same
-// XCD (private L2).
-#include "common.h"
+// CDNA4 structure (template <EPI, BM, BN, WM, WN>):
+//   * block tile BM x BN x 64, (BM/WM) x (BN/WN) waves, each wave a WM x WN sub-tile of
+//     v_mfma_f32_32x32x16_bf16 accumulators.  Two instantiations: 256x256 with 8 waves of 128x64
+//     (the workhorse: one K-step is 32 MFMAs per wave, long enough to cover the next tile's load
+//     latency, and 25 % less LDS traffic per FLOP) and 128x128 with 4 waves of 64x64 (small / thin shapes);
+//   * operand tiles go HBM -> LDS by direct LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction),
+//     double-buffered, ONE barrier per K-step; the next tile's DMA is issued before the current tile's MFMAs;
+//   * LDS image of a [rows][64 k] bf16 tile is row-linear (the DMA destination is lane-linear) with the
+//     16-byte chunk index XOR-swizzled by ((row>>1)&7) -- applied to the per-lane SOURCE address and again on
+//     the ds_read_b128 address -- which makes every ds_read_b128 lane group conflict-free;
+//   * blocks are remapped so that consecutive tiles of one A row-panel run on the same XCD (private L2).
+#include "gemm_common.h"
+#include <type_traits>
 
-enum {
-    EPI_BIAS_BF16 = 0,   // out bf16 = acc + bias
-    EPI_QGELU_BF16 = 1,  // u = acc + bias; out bf16 = u*sigmoid(1.702u); aux (optional) bf16 = u
-    EPI_GELU_BF16 = 2,   // erf GELU, aux (optional) bf16 = u
-    EPI_RESID_F32 = 3,   // out f32 = resid + acc + bias
-    EPI_F32 = 4,         // out f32 = alpha*acc (+ bias)
-    EPI_ATOMIC_F32 = 5,  // atomicAdd(out f32, alpha*acc)            (split-K dW)
-    EPI_TRANS_BF16 = 6,  // out_t[b][n/64][n%64][t] bf16 = acc + bias, m = b*Tp + t   (per-head transposed)
-    EPI_PATCH_F32 = 7,   // A gathered from image patches; out f32 [b*Tp + 1 + p][n] = acc + pos[1+p][n]
-    EPI_DQGELU_BF16 = 8, // out bf16 = acc * quick_gelu'(aux u)
-    EPI_DGELU_BF16 = 9,  // out bf16 = acc * gelu_erf'(aux u)
-    EPI_ACC_F32 = 10,    // out f32 += acc   (resid == out)
-};
+static constexpr int BK = 64;
 
-struct GemmP {
-    const bf16_t* A; int64_t lda; int64_t a_rows;
-    const bf16_t* W; int64_t ldw; int64_t w_rows;
-    const float* bias;
-    void* out; int64_t ldo;
-    const float* resid;
-    void* aux; int64_t ld_aux;
-    int64_t M, N, K;       // M,N: store guards; K multiple of 64
-    int tiles_m, tiles_n, kt_per_split;
-    float alpha;
-    // EPI_TRANS
-    int64_t Tp;            // rows per image
-    // EPI_PATCH
-    int64_t P, G, ps, S;   // patches / grid / patch size / image side
-    int ps_log2;
-    const float* pos;      // [T, N]
-};
+static int g_persistent = 1;
+extern "C" int owl_gemm_set_persistent(int on) { g_persistent = on; return 0; }
+static int g_debug_slots = 0;     // tuning experiments only: override the persistent grid size
+extern "C" int owl_gemm_debug_slots(int n) { g_debug_slots = n; return 0; }
+static int g_debug_nostore = 0;   // tuning experiments only: run the main loop but skip every epilogue store
+extern "C" int owl_gemm_debug_nostore(int on) { g_debug_nostore = on; return 0; }
 
-static constexpr int BM = 128, BN = 128, BK = 64;
-static constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB
-
-__device__ __forceinline__ float qgelu_f(float u) { return u / (1.0f + __expf(-1.702f * u)); }
-__device__ __forceinline__ float dqgelu_f(float u) {
-    float s = 1.0f / (1.0f + __expf(-1.702f * u));
-    return s * (1.0f + 1.702f * u * (1.0f - s));
-}
-__device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752f)); }
-__device__ __forceinline__ float dgelu_f(float u) {
-    return 0.5f * (1.0f + erff(u * 0.70710678118654752f)) + u * 0.39894228040143268f * __expf(-0.5f * u * u);
-}
-
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
+template <int EPI, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_nt_kernel(GemmP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr bool TRANS = (EPI == EPI_TRANS_BF16);
     constexpr bool PATCH = (EPI == EPI_PATCH_F32);
+    constexpr int NWN = BN / WN, NW = (BM / WM) * NWN;
+    constexpr int TI = WM / 32, TJ = WN / 32;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_Q = BM / 8 / NW, B_Q = BN / 8 / NW;   // LDS-DMA instructions per wave per stage
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-
-    // ---- XCD-aware tile mapping (bijective; blocks b, b+8, ... share an XCD) -----------------
-    const int ntile = p.tiles_m * p.tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = ntile >> 3, r = ntile & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tm = bid / p.tiles_n, tn = bid - tm * p.tiles_n;
-    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+    const int hi = lane >> 5;
     const int nk_all = (int)(p.K / BK);
-    const int kt0 = blockIdx.y * p.kt_per_split;
-    const int kt1 = min(nk_all, kt0 + p.kt_per_split);
-    if (kt0 >= kt1) return;
 
-    // ---- per-lane staging sources (row / swizzled chunk are K-step invariant) -----------------
-    const bf16_t* a_src[4];
-    const bf16_t* w_src[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int r = (w * 4 + q) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
-        int64_t am = m0 + r;
-        if (am >= p.a_rows) am = p.a_rows - 1;
-        if constexpr (PATCH) {
-            // A row = patch (b, py, px); chunk c covers 8 pixels of one patch row (ps % 8 == 0)
-            const int64_t b = am / p.P, pp = am - b * p.P;
-            const int64_t py = pp / p.G, px = pp - py * p.G;
-            // k-dependent part added per K-step; keep the (b, py, px) base here
-            a_src[q] = p.A + ((b * 3) * p.S + py * p.ps) * p.S + px * p.ps;  // + (ch*S + ky)*S + kx per K-step
-        } else {
-            a_src[q] = p.A + am * p.lda + c * 8;
-        }
-        int64_t wn = n0 + r;
-        if (wn >= p.w_rows) wn = p.w_rows - 1;
-        w_src[q] = p.W + wn * p.ldw + c * 8;
+    // ---- work items = (tile, K-split); persistent: this workgroup walks items item, item+step, ... of
+    //      its XCD's contiguous chunk, so the 32 CUs of an XCD always sit on 32 consecutive tiles --------
+    const int nitems = p.tiles_m * p.tiles_n * p.nsplit;
+    int item, item_end, item_step;
+    if (p.persistent) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, chunk = (nitems + 7) >> 3;
+        item = xcd * chunk + idx;
+        item_end = min(nitems, (xcd + 1) * chunk);
+        item_step = gridDim.x >> 3;
+    } else {
+        item = xcd_remap(blockIdx.x, nitems);
+        item_end = item + 1;
+        item_step = 1;
     }
+    if (item >= item_end) return;
 
-    auto stage = [&](int buf, int kt) {
-        unsigned char* base = lds + buf * (2 * TILE_BYTES);
+    int64_t m0, n0;
+    int split, kt0, kt1;
+    auto decode = [&](int it) {
+        const int tile = it / p.nsplit;
+        split = it - tile * p.nsplit;
+        const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+        m0 = (int64_t)tm * BM; n0 = (int64_t)tn * BN;
+        kt0 = split * p.kt_per_split;
+        kt1 = min(nk_all, kt0 + p.kt_per_split);
+    };
+
+    // ---- per-lane staging sources (row / swizzled chunk are K-step invariant) -----------------------
+    const bf16_t* a_src[A_Q];
+    const bf16_t* w_src[B_Q];
+    auto setup_src = [&]() {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int r0 = (w * 4 + q) * 8;
+        for (int q = 0; q < A_Q; q++) {
+            const int r = (w * A_Q + q) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            int64_t am = m0 + r;
+            if (am >= p.a_rows) am = p.a_rows - 1;
+            if constexpr (PATCH) {
+                const int64_t b = am / p.P, pp = am - b * p.P;
+                const int64_t py = pp / p.G, px = pp - py * p.G;
+                a_src[q] = p.A + ((b * 3) * p.S + py * p.ps) * p.S + px * p.ps;   // + (ch*S + ky)*S + kx per K-step
+            } else {
+                a_src[q] = p.A + am * p.lda + c * 8;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < B_Q; q++) {
+            const int r = (w * B_Q + q) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            int64_t wn = n0 + r;
+            if (wn >= p.w_rows) wn = p.w_rows - 1;
+            w_src[q] = p.W + wn * p.ldw + c * 8;
+        }
+    };
+
+    // bias slice of a tile (BN floats) rides along with the tile's FIRST stage into LDS (parity-double-buffered),
+    // so the epilogue reads it with ds_read and has no global load to wait for behind the prefetch DMA.
+    auto stage_bias = [&](int parity) {
+        if (p.bias && w == 0 && lane * 4 < BN) {
+            int64_t n = n0 + lane * 4;
+            if (n + 4 > p.N) n = p.N - 4;
+            __builtin_amdgcn_global_load_lds(GPTR(p.bias + n), LPTR(lds + 2 * STAGE + parity * (BN * 4)), 16, 0, 0);
+        }
+    };
+    auto stage = [&](int buf, int kt) {
+        unsigned char* base = lds + buf * STAGE;
+#pragma unroll
+        for (int q = 0; q < A_Q; q++) {
+            const int r0 = (w * A_Q + q) * 8;
             const bf16_t* ga;
             if constexpr (PATCH) {
-                // k = kt*64 + c*8 -> (channel, ky, kx); an 8-pixel chunk never crosses a patch row
-                // because ps is a power of two >= 8
+                // k = kt*64 + c*8 -> (channel, ky, kx); an 8-pixel chunk never crosses a patch row (ps = 2^n >= 8)
                 const int r = r0 + (lane >> 3);
                 const int c = (lane & 7) ^ ((r >> 1) & 7);
                 const int k = kt * BK + c * 8;
@@ -124,165 +124,214 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
                 ga = a_src[q] + (int64_t)kt * BK;
             }
             __builtin_amdgcn_global_load_lds(GPTR(ga), LPTR(base + r0 * 128), 16, 0, 0);
-            const bf16_t* gw = w_src[q] + (int64_t)kt * BK;
-            __builtin_amdgcn_global_load_lds(GPTR(gw), LPTR(base + TILE_BYTES + r0 * 128), 16, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < B_Q; q++) {
+            const int r0 = (w * B_Q + q) * 8;
+            __builtin_amdgcn_global_load_lds(GPTR(w_src[q] + (int64_t)kt * BK), LPTR(base + A_BYTES + r0 * 128), 16, 0, 0);
         }
     };
 
-    const int wr = w >> 1, wc = w & 1;
-    f32x16 acc[2][2];
+    const int wr = w / NWN, wc = w - wr * NWN;
+    const int wr_ = wr, wc_ = wc;
+    int a_off[TI], a_sw[TI], b_off[TJ], b_sw[TJ];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-
-    // fragment read offsets (bytes within a tile), K-chunk XOR applied per kc below
-    int a_off[2], b_off[2], a_sw[2], b_sw[2];
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int ra = wr * 64 + i * 32 + (lane & 31);
-        const int rb = wc * 64 + i * 32 + (lane & 31);
+    for (int i = 0; i < TI; i++) {
+        const int ra = wr * WM + i * 32 + (lane & 31);
         a_off[i] = ra * 128; a_sw[i] = (ra >> 1) & 7;
-        b_off[i] = rb * 128; b_sw[i] = (rb >> 1) & 7;
     }
-    const int hi = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < TJ; j++) {
+        const int rb = wc * WN + j * 32 + (lane & 31);
+        b_off[j] = A_BYTES + rb * 128; b_sw[j] = (rb >> 1) & 7;
+    }
 
+    // deferred bf16 epilogue state (256-wide tiles only: one workgroup per CU, nothing else hides the stores)
+    constexpr bool DEFER = (BM == 256) && (EPI == EPI_BIAS_BF16 || EPI == EPI_QGELU_BF16 || EPI == EPI_GELU_BF16 ||
+                                           EPI == EPI_DQGELU_BF16 || EPI == EPI_DGELU_BF16 || EPI == EPI_TRANS_BF16);
+    // register budget: 128 accumulators + 32 pending words fit 256 VGPRs; deferring the whole tile (64) spills.
+    // So the first half of the tile's chunks is stored at once (wide stores), the second half is trickled.
+    constexpr int NCH_ALL = TI * TJ * 2;               // 16-byte chunks per lane per tile (16)
+    constexpr int NCH = DEFER ? NCH_ALL / 2 : 1;       // deferred chunks (8): the rest is stored at once
+    uint4 pend[NCH];
+    int64_t pm0 = 0, pn0 = 0;
+    int pend_left = 0;                                  // chunks of the previous tile not yet stored (uniform)
+    bool pend_inner = true;                             // previous tile entirely inside [M, N] (uniform)
+    auto store_pend = [&](int cidx) {                  // cidx is a compile-time constant at every call site
+        if constexpr (DEFER) {
+            const int t = (cidx + NCH_ALL - NCH) >> 1, i = t / TJ, j = t - i * TJ;   // deferred chunks are the LAST ones
+            if (pend_inner) epi_store_chunk<EPI, false>(p, pend[cidx], pm0 + wr_ * WM + i * 32, pn0 + wc_ * WN + j * 32, cidx & 1, lane);
+            else epi_store_chunk<EPI, true>(p, pend[cidx], pm0 + wr_ * WM + i * 32, pn0 + wc_ * WN + j * 32, cidx & 1, lane);
+        }
+    };
+
+    decode(item);
+    setup_src();
     stage(0, kt0);
+    int tile_parity = 0;
+    stage_bias(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     int cur = 0;
-    for (int kt = kt0; kt < kt1; kt++) {
-        if (kt + 1 < kt1) stage(cur ^ 1, kt + 1);
-        const unsigned char* ta = lds + cur * (2 * TILE_BYTES);
-        const unsigned char* tb = ta + TILE_BYTES;
+    while (true) {
+        f32x16 acc[TI][TJ];
 #pragma unroll
-        for (int kc = 0; kc < 4; kc++) {
-            const int ch = kc * 2 + hi;
-            bf16x8 af[2], bfr[2];
+        for (int i = 0; i < TI; i++)
 #pragma unroll
-            for (int i = 0; i < 2; i++) {
-                af[i] = *(const bf16x8*)(ta + a_off[i] + ((ch ^ a_sw[i]) << 4));
-                bfr[i] = *(const bf16x8*)(tb + b_off[i] + ((ch ^ b_sw[i]) << 4));
+            for (int j = 0; j < TJ; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+        const int64_t cm0 = m0, cn0 = n0;
+        const int csplit = split, ckt0 = kt0, ckt1 = kt1;
+        const int next = item + item_step;
+        const bool has_next = next < item_end;
+        for (int kt = ckt0; kt < ckt1; kt++) {
+            const bool last = (kt + 1 == ckt1);
+            if (!last) {
+                stage(cur ^ 1, kt + 1);
+            } else if (has_next) {
+                // cross-tile prefetch: the next item's first K-tile flies while this item finishes + stores
+                decode(next);
+                setup_src();
+                stage(cur ^ 1, kt0);
+                stage_bias(tile_parity ^ 1);
             }
-#pragma unroll
-            for (int i = 0; i < 2; i++)
-#pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    if constexpr (TRANS)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-                    else  // swapped: D rows = n, cols = m  -> each lane owns 4 consecutive n of one m
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-                }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        cur ^= 1;
-    }
-
-    // ---- epilogue ----------------------------------------------------------------------------
-    const float alpha = p.alpha;
-    if constexpr (TRANS) {
-        // D[row = m_local][col = n_local]; lane: n = lane&31, m quads
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const int64_t n = n0 + wc * 64 + j * 32 + (lane & 31);
-                if (n >= p.N) continue;
-                const float bv = p.bias ? p.bias[n] : 0.f;
-                bf16_t* orow = (bf16_t*)p.out + n * p.Tp;   // + b * N * Tp + t
-#pragma unroll
-                for (int qd = 0; qd < 4; qd++) {
-                    const int64_t m = m0 + wr * 64 + i * 32 + 8 * qd + 4 * hi;
-                    if (m >= p.M) continue;
-                    const int64_t b = m / p.Tp, t = m - b * p.Tp;
-                    uint2 v;
-                    v.x = pack_bf2(acc[i][j][qd * 4 + 0] + bv, acc[i][j][qd * 4 + 1] + bv);
-                    v.y = pack_bf2(acc[i][j][qd * 4 + 2] + bv, acc[i][j][qd * 4 + 3] + bv);
-                    *(uint2*)(orow + b * p.N * p.Tp + t) = v;
-                }
-            }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int64_t m = m0 + wr * 64 + i * 32 + (lane & 31);
-            if (m >= p.M) continue;
-            int64_t orow_idx = m;
-            const float* posrow = nullptr;
-            if constexpr (PATCH) {
-                const int64_t b = m / p.P, pp = m - b * p.P;
-                orow_idx = b * p.Tp + 1 + pp;
-                posrow = p.pos + (1 + pp) * p.N;
-            }
-#pragma unroll
-            for (int j = 0; j < 2; j++)
-#pragma unroll
-                for (int qd = 0; qd < 4; qd++) {
-                    const int64_t n = n0 + wc * 64 + j * 32 + 8 * qd + 4 * hi;
-                    if (n >= p.N) continue;   // N is a multiple of 4 (checked on the host)
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] = acc[i][j][qd * 4 + e] * alpha;
-                    if (p.bias) {
-                        const float4 b4 = *(const float4*)(p.bias + n);
-                        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+            if constexpr (DEFER) {
+                // trickle the previous tile's output: 2 wide stores per K-step, hidden under this step's MFMAs
+                // 8 deferred chunks, one per K-step: 8 KiB per step per CU, well under the ~8 B/clk/CU store path
+                if (pend_left > 0) {
+                    switch (NCH - pend_left) {
+                        case 0: store_pend(0); break;
+                        case 1: store_pend(1); break;
+                        case 2: store_pend(2); break;
+                        case 3: store_pend(3); break;
+                        case 4: store_pend(4); break;
+                        case 5: store_pend(5); break;
+                        case 6: store_pend(6); break;
+                        default: store_pend(7); break;
                     }
-                    if constexpr (EPI == EPI_BIAS_BF16) {
-                        uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
-                        *(uint2*)((bf16_t*)p.out + orow_idx * p.ldo + n) = o;
-                    } else if constexpr (EPI == EPI_QGELU_BF16 || EPI == EPI_GELU_BF16) {
-                        if (p.aux) {
-                            uint2 a; a.x = pack_bf2(v[0], v[1]); a.y = pack_bf2(v[2], v[3]);
-                            *(uint2*)((bf16_t*)p.aux + orow_idx * p.ld_aux + n) = a;
+                    pend_left -= 1;
+                }
+            }
+            const unsigned char* tb = lds + cur * STAGE;
+#pragma unroll
+            for (int kc = 0; kc < 4; kc++) {
+                const int ch = kc * 2 + hi;
+                bf16x8 af[TI], bfr[TJ];
+#pragma unroll
+                for (int i = 0; i < TI; i++) af[i] = *(const bf16x8*)(tb + a_off[i] + ((ch ^ a_sw[i]) << 4));
+#pragma unroll
+                for (int j = 0; j < TJ; j++) bfr[j] = *(const bf16x8*)(tb + b_off[j] + ((ch ^ b_sw[j]) << 4));
+#pragma unroll
+                for (int i = 0; i < TI; i++)
+#pragma unroll
+                    for (int j = 0; j < TJ; j++) {
+                        if constexpr (TRANS)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                        else  // swapped: D rows = n, cols = m -> each lane owns 4 consecutive n of one m
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                    }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            cur ^= 1;
+        }
+        if constexpr (DEFER) {
+            // short tiles (< 8 K-steps): whatever of the previous tile is still pending goes out now
+            if (pend_left > 0) {
+#pragma unroll
+                for (int cdx = 0; cdx < NCH; cdx++)
+                    if (cdx >= NCH - pend_left) store_pend(cdx);
+            }
+            // element-wise epilogue in registers -> packed bf16, 16 bytes per lane; stores deferred into the next tile
+            static_assert(NCH == 8 || !DEFER, "slice schedule assumes 8 deferred chunks");
+            const bool inner = (cm0 + BM <= p.M) && (cn0 + BN <= p.N);   // wave-uniform: no per-lane guards needed
+            const float* lbias = (const float*)(lds + 2 * STAGE + tile_parity * (BN * 4)) + wc * WN;
+            auto run = [&](auto guard_tag) {
+                constexpr bool G = decltype(guard_tag)::value;
+#pragma unroll
+                for (int i = 0; i < TI; i++)
+#pragma unroll
+                    for (int j = 0; j < TJ; j++) {
+                        const int t = i * TJ + j;
+                        const int64_t mt = cm0 + wr * WM + i * 32, nt = cn0 + wc * WN + j * 32;
+                        if (2 * t < NCH_ALL - NCH) {   // not-deferred part of the tile (none when all 16 chunks are deferred)
+                            uint4 c0, c1;
+                            epi_tile_bf16<EPI, G>(p, acc[i][j], mt, nt, lane, c0, c1, lbias + j * 32);
+                            epi_store_chunk<EPI, G>(p, c0, mt, nt, 0, lane);
+                            epi_store_chunk<EPI, G>(p, c1, mt, nt, 1, lane);
+                        } else {                     // second half: keep packed in registers, trickle into the next tile
+                            epi_tile_bf16<EPI, G>(p, acc[i][j], mt, nt, lane, pend[2 * t - (NCH_ALL - NCH)], pend[2 * t - (NCH_ALL - NCH) + 1], lbias + j * 32);
                         }
-                        float g[4];
-#pragma unroll
-                        for (int e = 0; e < 4; e++) g[e] = (EPI == EPI_QGELU_BF16) ? qgelu_f(v[e]) : gelu_f(v[e]);
-                        uint2 o; o.x = pack_bf2(g[0], g[1]); o.y = pack_bf2(g[2], g[3]);
-                        *(uint2*)((bf16_t*)p.out + orow_idx * p.ldo + n) = o;
-                    } else if constexpr (EPI == EPI_DQGELU_BF16 || EPI == EPI_DGELU_BF16) {
-                        const uint2 a = *(const uint2*)((const bf16_t*)p.aux + orow_idx * p.ld_aux + n);
-                        float u[4] = {bf2f(a.x & 0xffff), bf2f(a.x >> 16), bf2f(a.y & 0xffff), bf2f(a.y >> 16)};
-#pragma unroll
-                        for (int e = 0; e < 4; e++) v[e] *= (EPI == EPI_DQGELU_BF16) ? dqgelu_f(u[e]) : dgelu_f(u[e]);
-                        uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
-                        *(uint2*)((bf16_t*)p.out + orow_idx * p.ldo + n) = o;
-                    } else if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_ACC_F32) {
-                        const float4 r4 = *(const float4*)(p.resid + orow_idx * p.ldo + n);
-                        float4 o = {r4.x + v[0], r4.y + v[1], r4.z + v[2], r4.w + v[3]};
-                        *(float4*)((float*)p.out + orow_idx * p.ldo + n) = o;
-                    } else if constexpr (EPI == EPI_F32) {
-                        float4 o = {v[0], v[1], v[2], v[3]};
-                        *(float4*)((float*)p.out + orow_idx * p.ldo + n) = o;
-                    } else if constexpr (EPI == EPI_PATCH_F32) {
-                        const float4 p4 = *(const float4*)(posrow + n);
-                        float4 o = {v[0] + p4.x, v[1] + p4.y, v[2] + p4.z, v[3] + p4.w};
-                        *(float4*)((float*)p.out + orow_idx * p.ldo + n) = o;
-                    } else if constexpr (EPI == EPI_ATOMIC_F32) {
-                        float* o = (float*)p.out + orow_idx * p.ldo + n;
-#pragma unroll
-                        for (int e = 0; e < 4; e++) atomicAdd(o + e, v[e]);
                     }
-                }
+            };
+            if (inner) run(std::false_type{}); else run(std::true_type{});
+            pend_inner = inner;
+            pm0 = cm0; pn0 = cn0; pend_left = NCH;
+            if (!has_next) {
+#pragma unroll
+                for (int cdx = 0; cdx < NCH; cdx++) store_pend(cdx);
+            }
+        } else {
+        // ---- epilogue AFTER the last barrier: buffer cur^1 was just consumed, and each wave stages through
+        //      the slice of it that only IT will DMA into next; the global stores then drain under the next
+        //      tile's first K-step (whose DMA is already in LDS buffer `cur`).
+            unsigned char* xb = lds + (cur ^ 1) * STAGE;
+            unsigned char* pieceA = xb + (w * A_Q * 8) * 128;
+            unsigned char* pieceB = xb + A_BYTES + (w * B_Q * 8) * 128;
+            static_assert(A_Q * 8 * 128 == 4096 && B_Q * 8 * 128 == 4096, "per-wave DMA slices must be 4 KiB each");
+            static_assert(TJ == 2 && TI % 2 == 0, "a pass is two 32x32 tiles");
+            if constexpr (TRANS) {
+#pragma unroll
+                for (int j = 0; j < TJ; j++)
+#pragma unroll
+                    for (int ip = 0; ip < TI / 2; ip++)
+                        epi_pass<EPI>(p, acc[2 * ip][j], acc[2 * ip + 1][j], pieceA, pieceB, cn0 + wc * WN + j * 32,
+                                      cm0 + wr * WM + ip * 64, lane, csplit);
+            } else {
+#pragma unroll
+                for (int i = 0; i < TI; i++)
+                    epi_pass<EPI>(p, acc[i][0], acc[i][1], pieceA, pieceB, cm0 + wr * WM + i * 32, cn0 + wc * WN, lane, csplit);
+            }
         }
+        if (!has_next) break;
+        item = next;
+        tile_parity ^= 1;
     }
 }
 
-template <int EPI>
-static int launch(hipStream_t s, const GemmP& p, int splits) {
+template <int EPI, int BM, int BN, int WM, int WN>
+static int launch_cfg(hipStream_t s, GemmP p, int splits) {
+    constexpr int threads = (BM / WM) * (BN / WN) * 64;
+    constexpr int lds_bytes = 2 * (BM + BN) * BK * 2 + 2 * BN * 4;   // 2 stages + 2 bias slices
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         attr_done = true;
     }
-    dim3 grid(p.tiles_m * p.tiles_n, splits);
-    hipLaunchKernelGGL(gemm_nt_kernel<EPI>, grid, dim3(256), 4 * TILE_BYTES, s, p);
+    p.tiles_m = (int)((p.M + BM - 1) / BM); p.tiles_n = (int)((p.N + BN - 1) / BN);
+    p.nsplit = splits;
+    if (g_debug_nostore) p.M = 0;
+    const int nitems = p.tiles_m * p.tiles_n * splits;
+    // persistent launch: one workgroup per CU-slot (blocks per CU limited by LDS), a multiple of 8 XCDs
+    const int slots = g_debug_slots ? g_debug_slots : 256 * (lds_bytes > 80 * 1024 ? 1 : 2);
+    p.persistent = (g_persistent && nitems > slots) ? 1 : 0;
+    dim3 grid(p.persistent ? slots : nitems);
+    hipLaunchKernelGGL((gemm_nt_kernel<EPI, BM, BN, WM, WN>), grid, dim3(threads), lds_bytes, s, p);
     OWL_LAUNCH_CHECK();
     return 0;
+}
+
+static int g_force_tile = 0;   // 0 auto, 128, 256 (tests / tuning)
+extern "C" int owl_gemm_set_tile(int tile) { g_force_tile = tile; return 0; }
+
+template <int EPI>
+static int launch(hipStream_t s, const GemmP& p, int splits) {
+    const bool big = g_force_tile ? (g_force_tile == 256) : (p.M >= 512 && p.N >= 256);
+    if (big) return launch_cfg<EPI, 256, 256, 128, 64>(s, p, splits);
+    return launch_cfg<EPI, 128, 128, 64, 64>(s, p, splits);
 }
 
 extern "C" int owl_gemm_nt_bf16(void* stream, int epi, const void* A, int64_t lda, int64_t a_rows, const void* W,
@@ -291,7 +340,7 @@ extern "C" int owl_gemm_nt_bf16(void* stream, int epi, const void* A, int64_t ld
                                 float alpha, int splits, int64_t Tp) {
     OWL_CHECK_ARG(A && W && out, "owl_gemm_nt_bf16: null pointer");
     OWL_CHECK_ARG(K > 0 && K % BK == 0, "owl_gemm_nt_bf16: K=%lld must be a positive multiple of 64", (long long)K);
-    OWL_CHECK_ARG(M > 0 && N > 0 && N % 4 == 0, "owl_gemm_nt_bf16: bad M=%lld N=%lld (N %% 4 == 0)", (long long)M, (long long)N);
+    OWL_CHECK_ARG(M > 0 && N > 0 && N % 8 == 0, "owl_gemm_nt_bf16: bad M=%lld N=%lld (N %% 8 == 0)", (long long)M, (long long)N);
     OWL_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0, "owl_gemm_nt_bf16: lda/ldw must be multiples of 8 elements");
     OWL_CHECK_ARG(a_rows > 0 && w_rows > 0, "owl_gemm_nt_bf16: a_rows / w_rows");
     OWL_CHECK_ARG(splits >= 1, "owl_gemm_nt_bf16: splits");
@@ -300,35 +349,58 @@ extern "C" int owl_gemm_nt_bf16(void* stream, int epi, const void* A, int64_t ld
     p.W = (const bf16_t*)W; p.ldw = ldw; p.w_rows = w_rows;
     p.bias = bias; p.out = out; p.ldo = ldo; p.resid = resid; p.aux = aux; p.ld_aux = ld_aux;
     p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.Tp = Tp;
-    p.tiles_m = (int)((M + BM - 1) / BM); p.tiles_n = (int)((N + BN - 1) / BN);
+    p.slab_stride = M * ldo;
     const int nk = (int)(K / BK);
     if (splits > nk) splits = nk;
     p.kt_per_split = (nk + splits - 1) / splits;
     splits = (nk + p.kt_per_split - 1) / p.kt_per_split;
     hipStream_t s = (hipStream_t)stream;
+    const bool split_ok = (epi == EPI_ATOMIC_F32 || epi == EPI_SLAB_F32);
+    OWL_CHECK_ARG(splits == 1 || split_ok, "owl_gemm_nt_bf16: split-K needs the atomic or slab epilogue");
     switch (epi) {
-        case EPI_BIAS_BF16: OWL_CHECK_ARG(splits == 1, "split-K needs the atomic epilogue"); return launch<EPI_BIAS_BF16>(s, p, 1);
-        case EPI_QGELU_BF16: OWL_CHECK_ARG(splits == 1, "split-K needs the atomic epilogue"); return launch<EPI_QGELU_BF16>(s, p, 1);
-        case EPI_GELU_BF16: OWL_CHECK_ARG(splits == 1, "split-K needs the atomic epilogue"); return launch<EPI_GELU_BF16>(s, p, 1);
-        case EPI_RESID_F32:
-            OWL_CHECK_ARG(splits == 1 && resid, "EPI_RESID_F32 needs resid, no split-K");
-            return launch<EPI_RESID_F32>(s, p, 1);
-        case EPI_ACC_F32:
-            OWL_CHECK_ARG(splits == 1, "no split-K"); p.resid = (const float*)out;
-            return launch<EPI_ACC_F32>(s, p, 1);
-        case EPI_F32: OWL_CHECK_ARG(splits == 1, "split-K needs the atomic epilogue"); return launch<EPI_F32>(s, p, 1);
-        case EPI_ATOMIC_F32:
-            OWL_CHECK_ARG(!bias, "atomic epilogue takes no bias");
-            return launch<EPI_ATOMIC_F32>(s, p, splits);
+        case EPI_BIAS_BF16: return launch<EPI_BIAS_BF16>(s, p, 1);
+        case EPI_QGELU_BF16: return launch<EPI_QGELU_BF16>(s, p, 1);
+        case EPI_GELU_BF16: return launch<EPI_GELU_BF16>(s, p, 1);
+        case EPI_RESID_F32: OWL_CHECK_ARG(resid, "EPI_RESID_F32 needs resid"); return launch<EPI_RESID_F32>(s, p, 1);
+        case EPI_ACC_F32: p.resid = (const float*)out; return launch<EPI_ACC_F32>(s, p, 1);
+        case EPI_F32: return launch<EPI_F32>(s, p, 1);
+        case EPI_ATOMIC_F32: OWL_CHECK_ARG(!bias, "atomic epilogue takes no bias"); return launch<EPI_ATOMIC_F32>(s, p, splits);
+        case EPI_SLAB_F32: OWL_CHECK_ARG(!bias, "slab epilogue takes no bias"); return launch<EPI_SLAB_F32>(s, p, splits);
         case EPI_TRANS_BF16:
-            OWL_CHECK_ARG(splits == 1 && Tp > 0 && Tp % 4 == 0 && N % 64 == 0, "EPI_TRANS_BF16: Tp %% 4, N %% 64");
+            OWL_CHECK_ARG(Tp > 0 && Tp % 4 == 0 && N % 64 == 0, "EPI_TRANS_BF16: Tp %% 4, N %% 64");
             return launch<EPI_TRANS_BF16>(s, p, 1);
-        case EPI_DQGELU_BF16:
-            OWL_CHECK_ARG(splits == 1 && aux, "EPI_DQGELU needs aux"); return launch<EPI_DQGELU_BF16>(s, p, 1);
-        case EPI_DGELU_BF16:
-            OWL_CHECK_ARG(splits == 1 && aux, "EPI_DGELU needs aux"); return launch<EPI_DGELU_BF16>(s, p, 1);
+        case EPI_DQGELU_BF16: OWL_CHECK_ARG(aux, "EPI_DQGELU needs aux"); return launch<EPI_DQGELU_BF16>(s, p, 1);
+        case EPI_DGELU_BF16: OWL_CHECK_ARG(aux, "EPI_DGELU needs aux"); return launch<EPI_DGELU_BF16>(s, p, 1);
         default: owl_set_error("owl_gemm_nt_bf16: unknown epilogue %d", epi); return -1;
     }
+}
+
+// number of split-K slabs the call above will actually write for (K, splits): callers size the slab buffer with it
+extern "C" int owl_gemm_effective_splits(int64_t K, int splits) {
+    const int nk = (int)(K / BK);
+    if (splits > nk) splits = nk;
+    if (splits < 1) splits = 1;
+    const int per = (nk + splits - 1) / splits;
+    return (nk + per - 1) / per;
+}
+
+// out[i] (+)= sum_s slab[s][i]  -- deterministic split-K reduction (accumulate = 1 adds into out)
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, float* out, int64_t n, int64_t stride, int nsplit, int accumulate) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    float4 a = accumulate ? *(const float4*)(out + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < nsplit; s++) {
+        const float4 v = *(const float4*)(slabs + (int64_t)s * stride + i);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    *(float4*)(out + i) = a;
+}
+
+extern "C" int owl_slab_reduce(void* stream, const float* slabs, float* out, int64_t n, int64_t slab_stride, int nsplit, int accumulate) {
+    OWL_CHECK_ARG(slabs && out && n > 0 && n % 4 == 0 && nsplit >= 1, "owl_slab_reduce: bad args (n %% 4 == 0)");
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, slabs, out, n, slab_stride, nsplit, accumulate);
+    OWL_LAUNCH_CHECK();
+    return 0;
 }
 
 // Patch-embed: X[b*Tp + 1 + p, :] = W_pe . vec(patch(b,p)) + pos[1+p]   (no bias; HF5:282-288,336-343)
@@ -345,7 +417,6 @@ extern "C" int owl_patch_embed_bf16(void* stream, const void* image_bf16, const 
     p.bias = nullptr; p.out = x_out; p.ldo = D; p.M = B * P; p.N = D; p.K = K; p.alpha = 1.f;
     p.Tp = Tp; p.P = P; p.G = G; p.ps = ps; p.S = S; p.pos = pos;
     p.ps_log2 = 0; while ((1LL << p.ps_log2) < ps) p.ps_log2++;
-    p.tiles_m = (int)((p.M + BM - 1) / BM); p.tiles_n = (int)((D + BN - 1) / BN);
     p.kt_per_split = (int)(K / BK);
     return launch<EPI_PATCH_F32>((hipStream_t)stream, p, 1);
 }

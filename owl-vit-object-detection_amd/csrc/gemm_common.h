@@ -1,0 +1,243 @@
+// Shared pieces of the bf16 MFMA GEMM family: epilogue ids, kernel parameters, per-accumulator-tile
+// epilogues (used identically by the 128x128 and the 256x256 block-tile kernels).
+#pragma once
+#include "common.h"
+
+enum {
+    EPI_BIAS_BF16 = 0,   // out bf16 = acc + bias
+    EPI_QGELU_BF16 = 1,  // u = acc + bias; out bf16 = u*sigmoid(1.702u); aux (optional) bf16 = u
+    EPI_GELU_BF16 = 2,   // erf GELU, aux (optional) bf16 = u
+    EPI_RESID_F32 = 3,   // out f32 = resid + acc + bias
+    EPI_F32 = 4,         // out f32 = alpha*acc (+ bias)
+    EPI_ATOMIC_F32 = 5,  // atomicAdd(out f32, alpha*acc)            (split-K)
+    EPI_TRANS_BF16 = 6,  // out_t[b][n][t] bf16 = acc + bias, m = b*Tp + t   (per-head transposed)
+    EPI_PATCH_F32 = 7,   // A gathered from image patches; out f32 [b*Tp + 1 + p][n] = acc + pos[1+p][n]
+    EPI_DQGELU_BF16 = 8, // out bf16 = acc * quick_gelu'(aux u)
+    EPI_DGELU_BF16 = 9,  // out bf16 = acc * gelu_erf'(aux u)
+    EPI_ACC_F32 = 10,    // out f32 += acc   (resid == out)
+    EPI_SLAB_F32 = 11,   // split-K partial: out f32 [split][M][N] = alpha*acc   (reduced by owl_slab_reduce)
+};
+
+struct GemmP {
+    const bf16_t* A; int64_t lda; int64_t a_rows;
+    const bf16_t* W; int64_t ldw; int64_t w_rows;
+    const float* bias;
+    void* out; int64_t ldo;
+    const float* resid;
+    void* aux; int64_t ld_aux;
+    int64_t M, N, K;       // M,N: store guards; K multiple of 64
+    int tiles_m, tiles_n, kt_per_split, nsplit, persistent;
+    float alpha;
+    int64_t Tp;            // EPI_TRANS: rows per image
+    int64_t P, G, ps, S;   // EPI_PATCH: patches / grid / patch size / image side
+    int ps_log2;
+    const float* pos;      // [T, N]
+    int64_t slab_stride;   // EPI_SLAB: elements per split slab
+};
+
+__device__ __forceinline__ float sigmoid1702_f(float u) {   // 1 / (1 + exp(-1.702 u)) with v_exp / v_rcp
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * u));
+}
+__device__ __forceinline__ float qgelu_f(float u) { return u * sigmoid1702_f(u); }
+__device__ __forceinline__ float dqgelu_f(float u) {
+    const float s = sigmoid1702_f(u);
+    return s * (1.0f + 1.702f * u * (1.0f - s));
+}
+__device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float u) {
+    return 0.5f * (1.0f + erff(u * 0.70710678118654752f)) + u * 0.39894228040143268f * __expf(-0.5f * u * u);
+}
+
+// ---- XCD-aware bijective tile remap (blocks b, b+8, ... share an XCD / L2) -------------------------
+__device__ __forceinline__ int xcd_remap(int bid, int ntile) {
+    const int q = ntile >> 3, r = ntile & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// ---- element-wise epilogue of ONE (row, 4 consecutive columns) quad -----------------------------------
+// v[4] = raw accumulators of output row `orow` (store row, already remapped for PATCH) at columns n..n+3.
+template <int EPI>
+__device__ __forceinline__ void epi_quad(const GemmP& p, int64_t orow, const float* posrow, int64_t n, float (&v)[4], int split) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) v[e] *= p.alpha;
+    if (p.bias) {
+        const float4 b4 = *(const float4*)(p.bias + n);
+        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+    }
+    if constexpr (EPI == EPI_BIAS_BF16) {
+        uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+        *(uint2*)((bf16_t*)p.out + orow * p.ldo + n) = o;
+    } else if constexpr (EPI == EPI_QGELU_BF16 || EPI == EPI_GELU_BF16) {
+        if (p.aux) {
+            uint2 a; a.x = pack_bf2(v[0], v[1]); a.y = pack_bf2(v[2], v[3]);
+            *(uint2*)((bf16_t*)p.aux + orow * p.ld_aux + n) = a;
+        }
+        float g[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) g[e] = (EPI == EPI_QGELU_BF16) ? qgelu_f(v[e]) : gelu_f(v[e]);
+        uint2 o; o.x = pack_bf2(g[0], g[1]); o.y = pack_bf2(g[2], g[3]);
+        *(uint2*)((bf16_t*)p.out + orow * p.ldo + n) = o;
+    } else if constexpr (EPI == EPI_DQGELU_BF16 || EPI == EPI_DGELU_BF16) {
+        const uint2 a = *(const uint2*)((const bf16_t*)p.aux + orow * p.ld_aux + n);
+        const float u[4] = {bf2f(a.x & 0xffff), bf2f(a.x >> 16), bf2f(a.y & 0xffff), bf2f(a.y >> 16)};
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] *= (EPI == EPI_DQGELU_BF16) ? dqgelu_f(u[e]) : dgelu_f(u[e]);
+        uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+        *(uint2*)((bf16_t*)p.out + orow * p.ldo + n) = o;
+    } else if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_ACC_F32) {
+        const float4 r4 = *(const float4*)(p.resid + orow * p.ldo + n);
+        *(float4*)((float*)p.out + orow * p.ldo + n) = make_float4(r4.x + v[0], r4.y + v[1], r4.z + v[2], r4.w + v[3]);
+    } else if constexpr (EPI == EPI_F32) {
+        *(float4*)((float*)p.out + orow * p.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+    } else if constexpr (EPI == EPI_SLAB_F32) {
+        *(float4*)((float*)p.out + (int64_t)split * p.slab_stride + orow * p.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+    } else if constexpr (EPI == EPI_PATCH_F32) {
+        const float4 p4 = *(const float4*)(posrow + n);
+        *(float4*)((float*)p.out + orow * p.ldo + n) = make_float4(v[0] + p4.x, v[1] + p4.y, v[2] + p4.z, v[3] + p4.w);
+    } else if constexpr (EPI == EPI_ATOMIC_F32) {
+        float* o = (float*)p.out + orow * p.ldo + n;
+#pragma unroll
+        for (int e = 0; e < 4; e++) atomicAdd(o + e, v[e]);
+    }
+}
+
+// ---- LDS-staged, fully coalesced epilogue of one PASS = two side-by-side 32x32 accumulator tiles --------
+// The accumulator layout gives a lane 4 consecutive elements of 16 different rows; stored directly that is 32
+// partial cache lines per store instruction (measured: ~40 % of the whole GEMM at K = 768).  Instead the wave
+// writes the pass as a [32 rows][64 cols] f32 image into its PRIVATE 8 KiB of LDS (the two 4 KiB pieces it
+// itself DMA-fills for the next K-tile -- free after the barrier, no cross-wave hazard), 16-byte chunks
+// XOR-swizzled by (row & 15) (conflict-free ds_write_b128 / ds_read_b128), then reads it back row-contiguous:
+// one wave-instruction = 4 rows x 256 B, so every global access of the epilogue (stores, residual / aux
+// loads) covers whole cache lines.
+//   t0 / t1 : the two accumulator tiles (columns 0-31 / 32-63 of the pass image)
+//   TRANS = false: image rows = output rows m (row_base + r), image cols = output cols n (col_base + c)
+//   TRANS = true : image rows = output cols n (row_base + r), image cols = token rows m (col_base + c)
+template <int EPI>
+__device__ __forceinline__ void epi_pass(const GemmP& p, const f32x16& t0, const f32x16& t1, unsigned char* pieceA,
+                                         unsigned char* pieceB, int64_t row_base, int64_t col_base, int lane, int split) {
+    constexpr bool TRANS = (EPI == EPI_TRANS_BF16);
+    const int hi = lane >> 5, r = lane & 31;
+    unsigned char* wrow = (r < 16 ? pieceA : pieceB) + (r & 15) * 256;
+#pragma unroll
+    for (int qd = 0; qd < 4; qd++) {
+        const int c0 = 2 * qd + hi, c1 = 8 + c0;
+        *(float4*)(wrow + ((c0 ^ (r & 15)) << 4)) = make_float4(t0[qd * 4 + 0], t0[qd * 4 + 1], t0[qd * 4 + 2], t0[qd * 4 + 3]);
+        *(float4*)(wrow + ((c1 ^ (r & 15)) << 4)) = make_float4(t1[qd * 4 + 0], t1[qd * 4 + 1], t1[qd * 4 + 2], t1[qd * 4 + 3]);
+    }
+    const int ch = lane & 15;
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const int row = it * 4 + (lane >> 4);
+        const unsigned char* rrow = (row < 16 ? pieceA : pieceB) + (row & 15) * 256;
+        const float4 f = *(const float4*)(rrow + ((ch ^ (row & 15)) << 4));
+        float v[4] = {f.x, f.y, f.z, f.w};
+        if constexpr (!TRANS) {
+            const int64_t m = row_base + row, n = col_base + ch * 4;
+            if (m >= p.M || n >= p.N) continue;
+            int64_t orow = m;
+            const float* posrow = nullptr;
+            if constexpr (EPI == EPI_PATCH_F32) {
+                const int64_t b = m / p.P, pp = m - b * p.P;
+                orow = b * p.Tp + 1 + pp;
+                posrow = p.pos + (1 + pp) * p.N;
+            }
+            epi_quad<EPI>(p, orow, posrow, n, v, split);
+        } else {
+            const int64_t n = row_base + row, m = col_base + ch * 4;
+            if (n >= p.N || m >= p.M) continue;
+            const float bv = p.bias ? p.bias[n] : 0.f;
+            const int64_t b = m / p.Tp, t = m - b * p.Tp;
+            uint2 o;
+            o.x = pack_bf2(v[0] + bv, v[1] + bv);
+            o.y = pack_bf2(v[2] + bv, v[3] + bv);
+            *(uint2*)((bf16_t*)p.out + (b * p.N + n) * p.Tp + t) = o;
+        }
+    }
+}
+
+// ---- register-resident bf16 epilogue of ONE 32x32 accumulator tile (deferred wide stores) --------------
+// Store instructions are issue-bound on CDNA4 (~64 cycles per wave-instruction per CU whatever the width), so
+// the bf16 epilogues (a) build 16-byte-per-lane stores: the 32x32 accumulator gives a lane 4 consecutive
+// outputs per register quad and the other half-wave the adjacent 4 -- one v_permlane32_swap per packed word
+// pairs them into 8 consecutive outputs per lane; (b) do NOT store here: the two 16-byte chunks per tile are
+// returned to the caller, which issues them a couple per K-step inside the NEXT tile's main loop.
+//   non-TRANS (swapped operands): lane owns output row m = m_tile + (lane&31); chunk c covers columns
+//       n_tile + 16*c + 8*hi + {0..7}
+//   TRANS (natural operands): lane owns output column n = n_tile + (lane&31); chunk c covers token rows
+//       m_tile + 16*c + 8*hi + {0..7}
+template <int EPI, bool GUARD>
+__device__ __forceinline__ void epi_tile_bf16(const GemmP& p, const f32x16& acc, int64_t m_tile, int64_t n_tile, int lane,
+                                              uint4& chunk0, uint4& chunk1, const float* lds_bias) {
+    constexpr bool TRANS = (EPI == EPI_TRANS_BF16);
+    const int hi = lane >> 5;
+    unsigned w[8];   // packed words, quad qd -> w[2*qd], w[2*qd+1]
+    if constexpr (TRANS) {
+        const int64_t n = n_tile + (lane & 31);
+        float bv = 0.f;
+        if (p.bias) bv = lds_bias[lane & 31];              // this tile's bias slice, staged in LDS
+#pragma unroll
+        for (int qd = 0; qd < 4; qd++) {
+            w[2 * qd] = pack_bf2(acc[qd * 4 + 0] + bv, acc[qd * 4 + 1] + bv);
+            w[2 * qd + 1] = pack_bf2(acc[qd * 4 + 2] + bv, acc[qd * 4 + 3] + bv);
+        }
+    } else {
+        const int64_t m = m_tile + (lane & 31);
+        const bool m_ok = !GUARD || m < p.M;
+        const bf16_t* aux_row = (const bf16_t*)p.aux + m * p.ld_aux + n_tile + 4 * hi;
+        const float* bias_p = lds_bias + 4 * hi;           // this tile's bias slice, staged in LDS
+#pragma unroll
+        for (int qd = 0; qd < 4; qd++) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = acc[qd * 4 + e] * p.alpha;
+            const bool n_ok = !GUARD || (n_tile + 8 * qd + 4 * hi) < p.N;
+            const bool ok = m_ok && n_ok;
+            if (p.bias) {                                  // wave-uniform
+                const float4 b4 = *(const float4*)(bias_p + 8 * qd);
+                v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+            }
+            if constexpr (EPI == EPI_QGELU_BF16 || EPI == EPI_GELU_BF16) {
+                if (p.aux) {                               // wave-uniform; pre-activation save (trainable layer only)
+                    uint2 a; a.x = pack_bf2(v[0], v[1]); a.y = pack_bf2(v[2], v[3]);
+                    if (ok) *(uint2*)((bf16_t*)aux_row + 8 * qd) = a;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = (EPI == EPI_QGELU_BF16) ? qgelu_f(v[e]) : gelu_f(v[e]);
+            } else if constexpr (EPI == EPI_DQGELU_BF16 || EPI == EPI_DGELU_BF16) {
+                uint2 a = make_uint2(0u, 0u);
+                if (ok) a = *(const uint2*)(aux_row + 8 * qd);
+                const float u[4] = {bf2f(a.x & 0xffff), bf2f(a.x >> 16), bf2f(a.y & 0xffff), bf2f(a.y >> 16)};
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] *= (EPI == EPI_DQGELU_BF16) ? dqgelu_f(u[e]) : dgelu_f(u[e]);
+            }
+            w[2 * qd] = pack_bf2(v[0], v[1]);
+            w[2 * qd + 1] = pack_bf2(v[2], v[3]);
+        }
+    }
+    // pair quads (0,1) and (2,3) across the half-waves: X = even quad word, Y = odd quad word;
+    // v_permlane32_swap: lanes 32-63 of X <-> lanes 0-31 of Y
+    unsigned x[4] = {w[0], w[1], w[4], w[5]}, y[4] = {w[2], w[3], w[6], w[7]};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        auto r = __builtin_amdgcn_permlane32_swap(x[k], y[k], false, false);
+        x[k] = r[0]; y[k] = r[1];
+    }
+    chunk0 = make_uint4(x[0], x[1], y[0], y[1]);
+    chunk1 = make_uint4(x[2], x[3], y[2], y[3]);
+}
+
+// issue one deferred 16-byte chunk (c = 0/1 within the tile)
+template <int EPI, bool GUARD>
+__device__ __forceinline__ void epi_store_chunk(const GemmP& p, const uint4& ch, int64_t m_tile, int64_t n_tile, int c, int lane) {
+    const int hi = lane >> 5;
+    if constexpr (EPI == EPI_TRANS_BF16) {
+        const int64_t n = n_tile + (lane & 31), m = m_tile + 16 * c + 8 * hi;
+        if (GUARD && (n >= p.N || m >= p.M)) return;
+        const int64_t b = m / p.Tp, t = m - b * p.Tp;
+        *(uint4*)((bf16_t*)p.out + (b * p.N + n) * p.Tp + t) = ch;
+    } else {
+        const int64_t m = m_tile + (lane & 31), n = n_tile + 16 * c + 8 * hi;
+        if (GUARD && (m >= p.M || n >= p.N)) return;
+        *(uint4*)((bf16_t*)p.out + m * p.ldo + n) = ch;
+    }
+}

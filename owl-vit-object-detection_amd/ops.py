@@ -8,7 +8,7 @@ import torch
 from . import _lib
 
 EPI_BIAS_BF16, EPI_QGELU_BF16, EPI_GELU_BF16, EPI_RESID_F32, EPI_F32, EPI_ATOMIC_F32 = 0, 1, 2, 3, 4, 5
-EPI_TRANS_BF16, EPI_PATCH_F32, EPI_DQGELU_BF16, EPI_DGELU_BF16, EPI_ACC_F32 = 6, 7, 8, 9, 10
+EPI_TRANS_BF16, EPI_PATCH_F32, EPI_DQGELU_BF16, EPI_DGELU_BF16, EPI_ACC_F32, EPI_SLAB_F32 = 6, 7, 8, 9, 10, 11
 
 ROW_PAD = 128
 

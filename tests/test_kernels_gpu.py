@@ -34,8 +34,17 @@ def qgelu(x):
     return x * torch.sigmoid(1.702 * x)
 
 
+@pytest.fixture(params=[128, 256], ids=["tile128", "tile256"])
+def gemm_tile(request):
+    """Run the GEMM tests on both block-tile instantiations (128x128 4-wave, 256x256 8-wave)."""
+    from owl_vit_object_detection_amd import _lib
+    _lib.call("owl_gemm_set_tile", request.param)
+    yield request.param
+    _lib.call("owl_gemm_set_tile", 0)
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 192, 128), (2048, 768, 768), (128, 128, 64), (1000, 3072, 256)])
-def test_gemm_bias_bf16(M, N, K):
+def test_gemm_bias_bf16(M, N, K, gemm_tile):
     A = ops.zeros_rows(M, K, torch.bfloat16, DEV)
     A[:M] = rnd(M, K).bfloat16()
     W = rnd(N, K, scale=0.1, seed=1).bfloat16()
@@ -47,7 +56,7 @@ def test_gemm_bias_bf16(M, N, K):
     assert float(out[M:].abs().max()) == 0.0 if out.shape[0] > M else True
 
 
-def test_gemm_epilogues():
+def test_gemm_epilogues(gemm_tile):
     M, N, K = 300, 256, 192
     A = ops.zeros_rows(M, K, torch.bfloat16, DEV); A[:M] = rnd(M, K).bfloat16()
     W = rnd(N, K, scale=0.1, seed=1).bfloat16()
@@ -78,6 +87,14 @@ def test_gemm_epilogues():
     o32.zero_()
     ops.gemm(ops.EPI_ATOMIC_F32, A, W, o32, M=M, splits=3)
     report("atomic", o32[:M], acc, 1e-3, 1e-4)
+    # split-K slabs + deterministic reduce
+    from owl_vit_object_detection_amd import _lib
+    ns = _lib.load().owl_gemm_effective_splits(K, 2)
+    slabs = torch.zeros(ns, M, N, device=DEV)
+    ops.gemm(ops.EPI_SLAB_F32, A, W, slabs, M=M, splits=2, ldo=N)
+    tgt = torch.ones(M, N, device=DEV)
+    _lib.call("owl_slab_reduce", ops.stream(), slabs, tgt, M * N, M * N, ns, 1)
+    report("slab", tgt, acc + 1.0, 1e-3, 1e-4)
     # activation-derivative epilogues
     upre = ops.zeros_rows(M, N, torch.bfloat16, DEV); upre[:M] = rnd(M, N, seed=9).bfloat16()
     uf = upre[:M].float()
@@ -91,7 +108,7 @@ def test_gemm_epilogues():
     report("dgelu", out[:M], acc * g2, 2e-2, 1e-2)
 
 
-def test_gemm_transposed_epilogue():
+def test_gemm_transposed_epilogue(gemm_tile):
     B, Tp, T, K, N = 2, 152, 150, 128, 192          # 3 heads of 64
     M = B * Tp
     A = ops.zeros_rows(M, K, torch.bfloat16, DEV); A[:M] = rnd(M, K).bfloat16()
@@ -102,7 +119,7 @@ def test_gemm_transposed_epilogue():
     report("trans", out, ref, 2e-2, 1e-2)
 
 
-def test_patch_embed():
+def test_patch_embed(gemm_tile):
     B, S, ps, D = 3, 96, 16, 128
     G = S // ps; P = G * G; T = P + 1; Tp = (T + 7) // 8 * 8
     img = rnd(B, 3, S, S).bfloat16()
