@@ -103,8 +103,13 @@ int owl_box_pairwise(void* stream, const float* boxes1, const float* boxes2, flo
  * buffers the caller zeroes once per step -- they are views of the flat gradient bucket.              */
 int owl_layernorm_bwd(void* stream, const void* dy, int dy_bf16, const float* x, const float* stats, const float* gamma, const float* dres, float* dx, float* dgamma, float* dbeta, int64_t rows, int64_t D);
 int owl_merge_ln_bwd(void* stream, const float* dfeats, const float* x, const float* cls_ln, const float* stats1, const float* stats2, const float* g1, const float* b1, const float* g2, float* dx, float* dcls_ws, float* dg1, float* db1, float* dg2, float* db2, int64_t B, int64_t P, int64_t Tp, int64_t D);
-int owl_class_sims_bwd(void* stream, const float* dsims, const float* sims, const unsigned char* argmax, const float* inv_norm, const float* e, const float* qhat32, const float* queries, void* de_bf16, float* dqhat_ws, float* dqueries, int64_t rows, int64_t Dt, int64_t C);
-int owl_box_final_bwd(void* stream, const float* dboxes, const float* sig, const void* h1_bf16, const void* u1_bf16, const float* w2, void* du1_bf16, float* dw2, float* db2, int64_t rows, int64_t D);
+/* class head backward, row-parallel part: de (bf16 [rows,Dt]), routed upstream G (bf16 [rows,32]) and a bf16 copy of e;
+ * dqhat[32,Dt] = G^T e is then a split-K owl_gemm_nt_bf16, and owl_query_normalize_bwd maps it onto dqueries            */
+int owl_class_sims_bwd(void* stream, const float* dsims, const float* sims, const unsigned char* argmax, const float* inv_norm, const float* e, const float* qhat32, void* de_bf16, void* g_bf16, void* e_bf16, int64_t rows, int64_t Dt, int64_t C);
+int owl_query_normalize_bwd(void* stream, const float* dqhat, const float* queries, float* dqueries, int64_t nq, int64_t Dt);
+/* dw2 [4,D] and db2 [4] must be contiguous (dw2 then db2); partials = f32 [owl_box_final_bwd_blocks(rows)][4*D+4] */
+int owl_box_final_bwd_blocks(int64_t rows);
+int owl_box_final_bwd(void* stream, const float* dboxes, const float* sig, const void* h1_bf16, const void* u1_bf16, const float* w2, void* du1_bf16, float* partials, float* dw2_db2, int64_t rows, int64_t D);
 int owl_transpose_colsum_bf16(void* stream, const void* in, int64_t ld_in, void* out_t, int64_t ld_out, float* colsum, int64_t R, int64_t C);
 int owl_colsum_f32(void* stream, const float* in, float* colsum, int64_t R, int64_t C);
 

@@ -11,7 +11,7 @@ all-reduce + optimizer step; the Function therefore returns no per-parameter ten
 """
 import torch
 
-from . import ops
+from . import _lib, ops
 
 
 def _attach_grads(model):
@@ -73,6 +73,9 @@ def _bws(model, B):
     wide = max(3 * D, I)
     ws = dict(
         de=z(Mh, Dt, bf, dev), dqhat=torch.zeros(32, Dt, device=dev), du1=z(Mh, D, bf, dev), du0=z(Mh, D, bf, dev),
+        g32=z(Mh, 32, bf, dev), e_bf=z(Mh, Dt, bf, dev),
+        box_part=torch.zeros(_lib.load().owl_box_final_bwd_blocks(Mh), 4 * D + 4, device=dev),
+        slab=torch.zeros(_slab_elems(cfg), device=dev),
         dfeats=z(Mh, D, f32, dev), dcls=torch.zeros(B, D, device=dev),
         dx=z(M, D, f32, dev), dxb=z(M, D, bf, dev), du=z(M, I, bf, dev), dh=z(M, D, bf, dev), dxm=z(M, D, f32, dev),
         datt=z(M, D, bf, dev), dattT=torch.zeros(B * D * Tp + 256, dtype=bf, device=dev), dqkv=z(M, 3 * D, bf, dev),
@@ -88,9 +91,18 @@ def _bws(model, B):
 
 
 def _split_k(n_rows_out, n_cols_out, k):
-    """Split the (long) token contraction so that the dW GEMM fills the chip: ~1k workgroups."""
-    tiles = ((n_rows_out + 127) // 128) * ((n_cols_out + 127) // 128)
-    return max(1, min(k // 64, (1024 + tiles - 1) // tiles))
+    """Split the (long) token contraction so that a dW GEMM gives every CU about one work item."""
+    t = 256 if (n_rows_out >= 512 and n_cols_out >= 256) else 128          # tile the C side picks (gemm.hip `launch`)
+    tiles = ((n_rows_out + t - 1) // t) * ((n_cols_out + t - 1) // t)
+    slots = 256 if t == 256 else 512
+    return max(1, min(k // 64, slots // tiles))
+
+
+def _slab_elems(cfg):
+    """f32 elements of the split-K slab scratch: max over the dW shapes of splits * n_out * n_in."""
+    D, I, Dt = cfg.hidden, cfg.mlp, cfg.text_dim
+    shapes = [(3 * D, D), (D, D), (I, D), (D, I), (Dt, D), (32, Dt)]
+    return max(_split_k(a, b, 1 << 30) * a * b for a, b in shapes)
 
 
 def backward_impl(model, B, d_boxes, d_sims, sims):
@@ -113,25 +125,31 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
         ops.transpose_bf16(tv(name), out, rows, cols)
         return out
 
-    def dW(dy, x, grad_w, n_out, n_in, rows, rows_pad, grad_b=None):
-        """grad_w[n_out, n_in] += dy[rows, n_out]^T x[rows, n_in];  grad_b += colsum(dy)  (one pass each).
+    def dW(dy, x, grad_w, n_out, n_in, rows, rows_pad, grad_b=None, accumulate=1):
+        """grad_w[n_out, n_in] (+)= dy[rows, n_out]^T x[rows, n_in];  grad_b += colsum(dy).
+        Token-major operand copies (transposes) -> split-K GEMM into f32 slabs -> deterministic slab reduction.
         Pad columns [rows, rows_pad) of the scratch stay zero: never written, buffers start zeroed."""
         tA, tB = (bw["tAh"], bw["tBh"]) if rows == Mh else (bw["tA"], bw["tB"])
         ld = tA.shape[1]
         assert ld == rows_pad
         ops.transpose_colsum(dy, tA, grad_b, rows, n_out, ld_in=dy.shape[-1], ld_out=ld)
         ops.transpose_colsum(x, tB, None, rows, n_in, ld_in=x.shape[-1], ld_out=ld)
-        ops.gemm(ops.EPI_ATOMIC_F32, tA, tB, grad_w, M=n_out, N=n_in, K=rows_pad, lda=ld, ldw=ld, ldo=n_in,
-                 a_rows=n_out, w_rows=n_in, splits=_split_k(n_out, n_in, rows_pad))
+        want = _split_k(n_out, n_in, rows_pad)
+        ns = _lib.load().owl_gemm_effective_splits(rows_pad, want)
+        ops.gemm(ops.EPI_SLAB_F32, tA, tB, bw["slab"], M=n_out, N=n_in, K=rows_pad, lda=ld, ldw=ld, ldo=n_in,
+                 a_rows=n_out, w_rows=n_in, splits=want)
+        _lib.call("owl_slab_reduce", ops.stream(), bw["slab"], grad_w, n_out * n_in, n_out * n_in, ns, accumulate)
 
     # ---- class head ---------------------------------------------------------------------------------
-    ops.class_sims_bwd(d_sims, sims, ws["argmax"], ws["inv_norm"], ws["e"], ws["qhat"], P_["queries"], bw["de"], bw["dqhat"],
-                       G("queries"), Mh, Dt, C)
+    ops.class_sims_bwd(d_sims, sims, ws["argmax"], ws["inv_norm"], ws["e"], ws["qhat"], bw["de"], bw["g32"], bw["e_bf"], Mh, Dt, C)
+    dW(bw["g32"], bw["e_bf"], bw["dqhat"], 32, Dt, Mh, Mhp, None, accumulate=0)          # dqhat = G^T e
+    _lib.call("owl_query_normalize_bwd", ops.stream(), bw["dqhat"], P_["queries"], G("queries"), cfg.queries, Dt)
     dW(bw["de"], ws["feats"], G("class_predictor.dense0.weight"), Dt, D, Mh, Mhp, G("class_predictor.dense0.bias"))
     ops.gemm(ops.EPI_F32, bw["de"], wT("class_predictor.dense0.weight", Dt, D), bw["dfeats"], M=Mh, N=D, K=Dt)
     # ---- box head -------------------------------------------------------------------------------------
-    ops.box_final_bwd(d_boxes, ws["sig"], ws["hb1"], ws["ub1"], P_["box_head.dense2.weight"], bw["du1"],
-                      G("box_head.dense2.weight"), G("box_head.dense2.bias"), Mh, D)
+    gw2, gb2 = G("box_head.dense2.weight"), G("box_head.dense2.bias")
+    assert gb2.data_ptr() == gw2.data_ptr() + 4 * gw2.numel(), "dense2 weight/bias grads must be adjacent in the flat bucket"
+    ops.box_final_bwd(d_boxes, ws["sig"], ws["hb1"], ws["ub1"], P_["box_head.dense2.weight"], bw["du1"], bw["box_part"], gw2, Mh, D)
     dW(bw["du1"], ws["hb0"], G("box_head.dense1.weight"), D, D, Mh, Mhp, G("box_head.dense1.bias"))
     ops.gemm(ops.EPI_DGELU_BF16, bw["du1"], wT("box_head.dense1.weight", D, D), bw["du0"], aux=ws["ub0"], M=Mh, N=D, K=D)
     dW(bw["du0"], ws["feats"], G("box_head.dense0.weight"), D, D, Mh, Mhp, G("box_head.dense0.bias"))

@@ -236,51 +236,46 @@ extern "C" int owl_merge_ln_bwd(void* stream, const float* dfeats, const float* 
 // ---------------------------------------------------------------------------------------------------
 // class head backward (ref src/models.py:25-36): s_c = inv * (e . qhat_j*), inv = 1/(|e|+1e-6)
 //   de = inv * sum_c g_c qhat_{j*c} - (sum_c g_c s_c) * inv * e/|e| ;  dqhat_j += sum_rows [j = j*] g_c inv e
-// workgroup = (RPB rows) x (256-column chunk of Dt): thread t owns column chunk*256 + t; dqhat partials
-// for the chunk accumulate in LDS and are flushed with one atomic per (query, column) per workgroup.
+// One wave per row (row-parallel, no serial loop): writes de (bf16) and the routed, scaled upstream
+// G[r, j] = g_c * inv_r * [j == 3c + argmax] (bf16 [rows, 32]); dqhat = G^T e is then an ordinary split-K GEMM.
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void class_sims_bwd_kernel(const float* __restrict__ dsims, const float* __restrict__ sims,
                                                              const unsigned char* __restrict__ argmax, const float* __restrict__ inv_norm,
                                                              const float* __restrict__ e, const float* __restrict__ qhat, bf16_t* de,
-                                                             float* dqhat, int64_t rows, int Dt, int C, int rows_per_block) {
-    __shared__ float lq[32][256];
-    __shared__ float acc[32][256];
-    __shared__ float rowg[32];     // g_c * inv for the current row, by query j (0 elsewhere)
-    __shared__ float rowscal[2];
-    const int t = threadIdx.x;
-    const int k = blockIdx.y * 256 + t;
-    const bool kv = k < Dt;
-    for (int j = 0; j < 32; j++) { lq[j][t] = kv ? qhat[j * Dt + k] : 0.f; acc[j][t] = 0.f; }
+                                                             bf16_t* G, bf16_t* e_bf16, int64_t rows, int Dt, int C) {
+    extern __shared__ __attribute__((aligned(16))) float lq[];     // qhat [32][Dt]
+    for (int i = threadIdx.x; i < 32 * (Dt >> 2); i += 256) ((float4*)lq)[i] = ((const float4*)qhat)[i];
     __syncthreads();
-    const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block, r_end = min(rows, r_begin + rows_per_block);
-    for (int64_t r = r_begin; r < r_end; r++) {
-        if (t < 32) {
-            const int j = t, c = j / 3;
-            float gj = 0.f;
-            if (c < C && (int)argmax[r * C + c] == j - 3 * c) gj = dsims[r * C + c] * inv_norm[r];
-            rowg[j] = gj;
-            float gs = (j < C) ? dsims[r * C + j] * sims[r * C + j] : 0.f;
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) gs += __shfl_xor(gs, o, 64);
-            if (j == 0) { rowscal[0] = gs; rowscal[1] = inv_norm[r]; }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + w) * 16;
+    for (int64_t r = row0; r < min(rows, row0 + 16); r++) {
+        const float inv = inv_norm[r];
+        // lanes 0..31 <-> query j
+        float gj = 0.f, gs = 0.f;
+        if (lane < 32) {
+            const int c = lane / 3;
+            if (c < C && (int)argmax[r * C + c] == lane - 3 * c) gj = dsims[r * C + c] * inv;
+            if (lane < C) gs = dsims[r * C + lane] * sims[r * C + lane];
         }
-        __syncthreads();
-        const float inv = rowscal[1];
+        gs = wave_sum(gs);
+        if (lane < 32) G[r * 32 + lane] = f2bf(gj);
         const float nrm = 1.0f / inv - 1e-6f;
-        const float coef_e = rowscal[0] * inv / nrm;
-        if (kv) {
-            const float ev = e[r * Dt + k];
-            float d = -coef_e * ev;
-            for (int j = 0; j < 3 * C; j++) {
-                const float gj = rowg[j];
-                if (gj != 0.f) { d += gj * lq[j][t]; acc[j][t] += gj * ev; }
+        const float coef_e = gs * inv / nrm;
+        for (int k4 = lane; k4 < (Dt >> 2); k4 += 64) {
+            const float4 ev = ((const float4*)(e + r * Dt))[k4];
+            float4 d = make_float4(-coef_e * ev.x, -coef_e * ev.y, -coef_e * ev.z, -coef_e * ev.w);
+            for (int c = 0; c < C; c++) {
+                const int j = 3 * c + (int)argmax[r * C + c];
+                const float g = __shfl(gj, j, 64);
+                const float4 q = ((const float4*)(lq + j * Dt))[k4];
+                d.x += g * q.x; d.y += g * q.y; d.z += g * q.z; d.w += g * q.w;
             }
-            de[r * Dt + k] = f2bf(d);
+            uint2 o; o.x = pack_bf2(d.x, d.y); o.y = pack_bf2(d.z, d.w);
+            ((uint2*)(de + r * Dt))[k4] = o;
+            uint2 eb; eb.x = pack_bf2(ev.x, ev.y); eb.y = pack_bf2(ev.z, ev.w);
+            ((uint2*)(e_bf16 + r * Dt))[k4] = eb;
         }
-        __syncthreads();
     }
-    if (kv)
-        for (int j = 0; j < 3 * C; j++) atomicAdd(dqhat + j * Dt + k, acc[j][t]);
 }
 
 // dQ from dqhat: qhat = Q/|Q| + 1e-6  ->  dQ = (dqhat - (dqhat . Qn) Qn) / |Q|,  Qn = Q/|Q|
@@ -297,18 +292,24 @@ __global__ __launch_bounds__(64) void qhat_bwd_kernel(const float* __restrict__ 
 }
 
 extern "C" int owl_class_sims_bwd(void* stream, const float* dsims, const float* sims, const unsigned char* argmax, const float* inv_norm,
-                                  const float* e, const float* qhat32, const float* queries, void* de_bf16, float* dqhat_ws,
-                                  float* dqueries, int64_t rows, int64_t Dt, int64_t C) {
-    OWL_CHECK_ARG(dsims && sims && argmax && inv_norm && e && qhat32 && queries && de_bf16 && dqhat_ws && dqueries, "owl_class_sims_bwd: null pointer");
-    OWL_CHECK_ARG(3 * C <= 32, "owl_class_sims_bwd: 3*C <= 32");
-    hipStream_t s = (hipStream_t)stream;
-    hipError_t er = hipMemsetAsync(dqhat_ws, 0, (size_t)(32 * Dt) * sizeof(float), s);
-    OWL_CHECK_ARG(er == hipSuccess, "owl_class_sims_bwd: memset failed");
-    const int rpb = 256;
-    hipLaunchKernelGGL(class_sims_bwd_kernel, dim3((unsigned)((rows + rpb - 1) / rpb), (unsigned)((Dt + 255) / 256)), dim3(256), 0, s, dsims, sims, argmax, inv_norm, e,
-                       qhat32, (bf16_t*)de_bf16, dqhat_ws, rows, (int)Dt, (int)C, rpb);
+                                  const float* e, const float* qhat32, void* de_bf16, void* g_bf16, void* e_bf16, int64_t rows,
+                                  int64_t Dt, int64_t C) {
+    OWL_CHECK_ARG(dsims && sims && argmax && inv_norm && e && qhat32 && de_bf16 && g_bf16 && e_bf16, "owl_class_sims_bwd: null pointer");
+    OWL_CHECK_ARG(3 * C <= 32 && Dt % 4 == 0, "owl_class_sims_bwd: 3*C <= 32, Dt %% 4");
+    const size_t shmem = (size_t)32 * Dt * sizeof(float);
+    OWL_CHECK_ARG(shmem <= 150 * 1024, "owl_class_sims_bwd: Dt too large for LDS");
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)class_sims_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_done = true; }
+    hipLaunchKernelGGL(class_sims_bwd_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(256), shmem, (hipStream_t)stream, dsims, sims, argmax,
+                       inv_norm, e, qhat32, (bf16_t*)de_bf16, (bf16_t*)g_bf16, (bf16_t*)e_bf16, rows, (int)Dt, (int)C);
     OWL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(qhat_bwd_kernel, dim3((unsigned)(3 * C)), dim3(64), 0, s, dqhat_ws, queries, dqueries, (int)Dt);
+    return 0;
+}
+
+// dqueries += d(qhat -> Q) of dqhat (f32 [32, Dt], rows < nq used)
+extern "C" int owl_query_normalize_bwd(void* stream, const float* dqhat, const float* queries, float* dqueries, int64_t nq, int64_t Dt) {
+    OWL_CHECK_ARG(dqhat && queries && dqueries && nq >= 1 && nq <= 32, "owl_query_normalize_bwd: bad args");
+    hipLaunchKernelGGL(qhat_bwd_kernel, dim3((unsigned)nq), dim3(64), 0, (hipStream_t)stream, dqhat, queries, dqueries, (int)Dt);
     OWL_LAUNCH_CHECK();
     return 0;
 }
@@ -323,7 +324,7 @@ __device__ __forceinline__ float dgelu_erf(float u) {
 
 __global__ __launch_bounds__(256) void box_final_bwd_kernel(const float* __restrict__ dboxes, const float* __restrict__ sig,
                                                             const bf16_t* __restrict__ h1, const bf16_t* __restrict__ u1,
-                                                            const float* __restrict__ w2, bf16_t* du1, float* dw2, float* db2,
+                                                            const float* __restrict__ w2, bf16_t* du1, float* part,
                                                             int64_t rows, int D, int rows_per_block) {
     __shared__ float4 dpre_s[256];
     const int t = threadIdx.x;
@@ -362,26 +363,40 @@ __global__ __launch_bounds__(256) void box_final_bwd_kernel(const float* __restr
             }
         }
     }
+    // per-workgroup partials [nblk][4*D + 4] (reduced deterministically by owl_slab_reduce)
+    float* mypart = part + (int64_t)blockIdx.x * (4 * D + 4);
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         const int col = t + c * 256;
         if (col < D)
 #pragma unroll
-            for (int k = 0; k < 4; k++) atomicAdd(dw2 + k * D + col, accw[k][c]);
+            for (int k = 0; k < 4; k++) mypart[k * D + col] = accw[k][c];
     }
+    __shared__ float4 redb[4];
     accb.x = wave_sum(accb.x); accb.y = wave_sum(accb.y); accb.z = wave_sum(accb.z); accb.w = wave_sum(accb.w);
-    if ((t & 63) == 0) { atomicAdd(db2 + 0, accb.x); atomicAdd(db2 + 1, accb.y); atomicAdd(db2 + 2, accb.z); atomicAdd(db2 + 3, accb.w); }
+    if ((t & 63) == 0) redb[t >> 6] = accb;
+    __syncthreads();
+    if (t == 0) {
+        const float4 a0 = redb[0], a1 = redb[1], a2 = redb[2], a3 = redb[3];
+        *(float4*)(mypart + 4 * D) = make_float4(a0.x + a1.x + a2.x + a3.x, a0.y + a1.y + a2.y + a3.y, a0.z + a1.z + a2.z + a3.z, a0.w + a1.w + a2.w + a3.w);
+    }
 }
 
+// partials: f32 workspace [owl_box_final_bwd_blocks(rows)][4*D + 4]; dw2 [4,D] and db2 [4] must be CONTIGUOUS
+// (dw2 followed by db2, as in the flat gradient bucket) -- they are accumulated by one deterministic reduce.
+extern "C" int owl_box_final_bwd_blocks(int64_t rows) { return (int)((rows + 63) / 64); }
+
 extern "C" int owl_box_final_bwd(void* stream, const float* dboxes, const float* sig, const void* h1_bf16, const void* u1_bf16,
-                                 const float* w2, void* du1_bf16, float* dw2, float* db2, int64_t rows, int64_t D) {
-    OWL_CHECK_ARG(dboxes && sig && h1_bf16 && u1_bf16 && w2 && du1_bf16 && dw2 && db2, "owl_box_final_bwd: null pointer");
-    OWL_CHECK_ARG(D <= 1024, "owl_box_final_bwd: D <= 1024");
-    const int rpb = 256;
-    hipLaunchKernelGGL(box_final_bwd_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, dboxes, sig,
-                       (const bf16_t*)h1_bf16, (const bf16_t*)u1_bf16, w2, (bf16_t*)du1_bf16, dw2, db2, rows, (int)D, rpb);
+                                 const float* w2, void* du1_bf16, float* partials, float* dw2_db2, int64_t rows, int64_t D) {
+    OWL_CHECK_ARG(dboxes && sig && h1_bf16 && u1_bf16 && w2 && du1_bf16 && partials && dw2_db2, "owl_box_final_bwd: null pointer");
+    OWL_CHECK_ARG(D <= 1024 && D % 4 == 0, "owl_box_final_bwd: D <= 1024, D %% 4");
+    const int rpb = 64;
+    const int nblk = (int)((rows + rpb - 1) / rpb);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(box_final_bwd_kernel, dim3((unsigned)nblk), dim3(256), 0, s, dboxes, sig, (const bf16_t*)h1_bf16,
+                       (const bf16_t*)u1_bf16, w2, (bf16_t*)du1_bf16, partials, rows, (int)D, rpb);
     OWL_LAUNCH_CHECK();
-    return 0;
+    return owl_slab_reduce_impl(s, partials, dw2_db2, 4 * D + 4, 4 * D + 4, nblk, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------

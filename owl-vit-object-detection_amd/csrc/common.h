@@ -39,6 +39,8 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // ---- error plumbing (thread-local last error) ----------------------------
 void owl_set_error(const char* fmt, ...);
+// out[i] (+)= sum_s slabs[s*stride + i]  (gemm.hip; shared with backward.hip)
+int owl_slab_reduce_impl(hipStream_t s, const float* slabs, float* out, int64_t n, int64_t slab_stride, int nsplit, int accumulate);
 #define OWL_CHECK_ARG(cond, ...)                  \
     do {                                          \
         if (!(cond)) {                            \

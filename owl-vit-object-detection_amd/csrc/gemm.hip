@@ -396,11 +396,15 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     *(float4*)(out + i) = a;
 }
 
-extern "C" int owl_slab_reduce(void* stream, const float* slabs, float* out, int64_t n, int64_t slab_stride, int nsplit, int accumulate) {
-    OWL_CHECK_ARG(slabs && out && n > 0 && n % 4 == 0 && nsplit >= 1, "owl_slab_reduce: bad args (n %% 4 == 0)");
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, slabs, out, n, slab_stride, nsplit, accumulate);
+int owl_slab_reduce_impl(hipStream_t s, const float* slabs, float* out, int64_t n, int64_t slab_stride, int nsplit, int accumulate) {
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, slabs, out, n, slab_stride, nsplit, accumulate);
     OWL_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int owl_slab_reduce(void* stream, const float* slabs, float* out, int64_t n, int64_t slab_stride, int nsplit, int accumulate) {
+    OWL_CHECK_ARG(slabs && out && n > 0 && n % 4 == 0 && nsplit >= 1, "owl_slab_reduce: bad args (n %% 4 == 0)");
+    return owl_slab_reduce_impl((hipStream_t)stream, slabs, out, n, slab_stride, nsplit, accumulate);
 }
 
 // Patch-embed: X[b*Tp + 1 + p, :] = W_pe . vec(patch(b,p)) + pos[1+p]   (no bias; HF5:282-288,336-343)

@@ -122,12 +122,12 @@ def merge_ln_bwd(dfeats, x, cls_ln, st1, st2, g1, b1, g2, dx, dcls_ws, dg1, db1,
     _lib.call("owl_merge_ln_bwd", stream(), dfeats, x, cls_ln, st1, st2, g1, b1, g2, dx, dcls_ws, dg1, db1, dg2, db2, B, P, Tp, D)
 
 
-def class_sims_bwd(dsims, sims, argmax, inv_norm, e, qhat32, queries, de, dqhat_ws, dqueries, rows, Dt, C):
-    _lib.call("owl_class_sims_bwd", stream(), dsims, sims, argmax, inv_norm, e, qhat32, queries, de, dqhat_ws, dqueries, rows, Dt, C)
+def class_sims_bwd(dsims, sims, argmax, inv_norm, e, qhat32, de, g32, e_bf16, rows, Dt, C):
+    _lib.call("owl_class_sims_bwd", stream(), dsims, sims, argmax, inv_norm, e, qhat32, de, g32, e_bf16, rows, Dt, C)
 
 
-def box_final_bwd(dboxes, sig, h1, u1, w2, du1, dw2, db2, rows, D):
-    _lib.call("owl_box_final_bwd", stream(), dboxes, sig, h1, u1, w2, du1, dw2, db2, rows, D)
+def box_final_bwd(dboxes, sig, h1, u1, w2, du1, partials, dw2_db2, rows, D):
+    _lib.call("owl_box_final_bwd", stream(), dboxes, sig, h1, u1, w2, du1, partials, dw2_db2, rows, D)
 
 
 def transpose_colsum(src, dst, colsum, R, C, ld_in=None, ld_out=None):
