@@ -60,6 +60,9 @@ int owl_cls_rows(void* stream, float* x, const float* cls, const float* pos, int
 
 /* ---- LayerNorm (HF5:484-486, 721-723; eps 1e-5).  out bf16 or f32 (may alias x); stats = (mean,rstd) */
 int owl_layernorm_fwd(void* stream, const float* x, const float* gamma, const float* beta, void* out, int out_bf16, float* stats, int64_t rows, int64_t D, float eps);
+/* fused residual add: x_out = x + delta (bf16 output of the previous branch's GEMM, HF5:500,507 `residual + hidden_states`),
+ * out = LN(x_out).  x_out may alias x.                                                                              */
+int owl_add_layernorm_fwd(void* stream, const float* x, const void* delta_bf16, float* x_out, const float* gamma, const float* beta, void* out, int out_bf16, float* stats, int64_t rows, int64_t D, float eps);
 
 /* ---- fused self-attention forward (HF5:377-402): softmax(Q K^T * scale) V, dh = 64 -----------------
  * q, k row-major [B*Tp, ld_qk] (head h at column h*64); vt = V^T per head [B][..][64][Tp] as written
@@ -70,8 +73,9 @@ int owl_attention_fwd_bf16(void* stream, const void* q, const void* k, int64_t l
  * transposed copies ([B][3D][Tp] / [B][D][Tp], epilogue 6), O and dO row-major [B*Tp,D]; writes dqkv [B*Tp,3D]. */
 int owl_attention_bwd_bf16(void* stream, const void* qkv, const void* qkvT, const void* dO, const void* dOT, const void* O, const float* lse, float* dvec_ws, void* dqkv, int64_t B, int64_t H, int64_t T, int64_t Tp, float scale);
 
-/* ---- post_layernorm on all tokens + class-token merge + post_post_layernorm (ref src/models.py:80-86) */
-int owl_merge_ln_fwd(void* stream, const float* x, const float* g1, const float* b1, const float* g2, const float* b2, float* cls_ln, void* feats_bf16, float* stats1, float* stats2, int64_t B, int64_t P, int64_t Tp, int64_t D, float eps);
+/* ---- post_layernorm on all tokens + class-token merge + post_post_layernorm (ref src/models.py:80-86);
+ * optional fused final residual add (delta_bf16 -> x_out = x + delta, may alias x)                      */
+int owl_merge_ln_fwd(void* stream, const float* x, const void* delta_bf16, float* x_out, const float* g1, const float* b1, const float* g2, const float* b2, float* cls_ln, void* feats_bf16, float* stats1, float* stats2, int64_t B, int64_t P, int64_t Tp, int64_t D, float eps);
 
 /* ---- heads -------------------------------------------------------------------------------------- */
 /* qhat = Q/|Q| + 1e-6 (ref src/models.py:31-33, eps placement literal); padded to 32 rows        */

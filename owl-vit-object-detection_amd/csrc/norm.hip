@@ -22,11 +22,14 @@ __device__ __forceinline__ void row_stats(const float4 (&v)[NV], int nvec, int l
     rstd = rsqrtf(wave_sum(q) / (float)D + eps);
 }
 
-// y = LN(x) * gamma + beta ; out bf16 (OUT_BF16) or f32 (may alias x); stats[row] = {mean, rstd}
+// y = LN(x [+ delta]) * gamma + beta ; out bf16 (OUT_BF16) or f32 (may alias x); stats[row] = {mean, rstd}.
+// With `delta` (bf16 GEMM output of the previous residual branch) the residual add is fused here:
+// x_new = x + delta is written to x_out (f32, may alias x) -- the GEMM epilogue then stores 2 bytes per
+// element instead of reading and writing 4 (the f32 residual epilogue was HBM/issue-bound).
 template <bool OUT_BF16>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* x, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, void* out, float2* stats,
-                                                     int64_t rows, int D, float eps) {
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* x, const bf16_t* __restrict__ delta, float* x_out,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta, void* out,
+                                                     float2* stats, int64_t rows, int D, float eps) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -35,7 +38,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* x, const float
     float4 v[LN_MAXV];
 #pragma unroll
     for (int i = 0; i < LN_MAXV; i++)
-        if (lane + i * 64 < nvec) v[i] = xr[lane + i * 64];
+        if (lane + i * 64 < nvec) {
+            v[i] = xr[lane + i * 64];
+            if (delta) {
+                const uint2 u = ((const uint2*)(delta + row * D))[lane + i * 64];
+                v[i].x += bf2f(u.x & 0xffff); v[i].y += bf2f(u.x >> 16); v[i].z += bf2f(u.y & 0xffff); v[i].w += bf2f(u.y >> 16);
+                ((float4*)(x_out + row * D))[lane + i * 64] = v[i];
+            }
+        }
     float mean, rstd;
     row_stats<LN_MAXV>(v, nvec, lane, D, mean, rstd, eps);
     if (stats && lane == 0) stats[row] = make_float2(mean, rstd);
@@ -56,17 +66,30 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* x, const float
     }
 }
 
-extern "C" int owl_layernorm_fwd(void* stream, const float* x, const float* gamma, const float* beta, void* out,
-                                 int out_bf16, float* stats, int64_t rows, int64_t D, float eps) {
+static int ln_launch(void* stream, const float* x, const void* delta, float* x_out, const float* gamma, const float* beta, void* out,
+                     int out_bf16, float* stats, int64_t rows, int64_t D, float eps) {
     OWL_CHECK_ARG(x && gamma && beta && out, "owl_layernorm_fwd: null pointer");
     OWL_CHECK_ARG(D % 4 == 0 && D <= 256 * LN_MAXV, "owl_layernorm_fwd: D=%lld must be a multiple of 4 and <= 1024", (long long)D);
+    OWL_CHECK_ARG((delta == nullptr) || (x_out != nullptr), "owl_add_layernorm_fwd: x_out required with delta");
     dim3 grid((unsigned)((rows + 3) / 4));
     if (out_bf16)
-        hipLaunchKernelGGL(ln_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, gamma, beta, out, (float2*)stats, rows, (int)D, eps);
+        hipLaunchKernelGGL(ln_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)delta, x_out, gamma, beta, out, (float2*)stats, rows, (int)D, eps);
     else
-        hipLaunchKernelGGL(ln_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, gamma, beta, out, (float2*)stats, rows, (int)D, eps);
+        hipLaunchKernelGGL(ln_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)delta, x_out, gamma, beta, out, (float2*)stats, rows, (int)D, eps);
     OWL_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int owl_layernorm_fwd(void* stream, const float* x, const float* gamma, const float* beta, void* out,
+                                 int out_bf16, float* stats, int64_t rows, int64_t D, float eps) {
+    return ln_launch(stream, x, nullptr, nullptr, gamma, beta, out, out_bf16, stats, rows, D, eps);
+}
+
+// x_out = x + delta (bf16);  out = LN(x_out)
+extern "C" int owl_add_layernorm_fwd(void* stream, const float* x, const void* delta_bf16, float* x_out, const float* gamma,
+                                     const float* beta, void* out, int out_bf16, float* stats, int64_t rows, int64_t D, float eps) {
+    OWL_CHECK_ARG(delta_bf16, "owl_add_layernorm_fwd: null delta");
+    return ln_launch(stream, x, delta_bf16, x_out, gamma, beta, out, out_bf16, stats, rows, D, eps);
 }
 
 // Class-token rows: X[b*Tp + 0, :] = class_embedding + pos[0]   (HF5:338-343)
@@ -88,7 +111,7 @@ extern "C" int owl_cls_rows(void* stream, float* x, const float* cls, const floa
 // ---- class-token merge + second LN (ref src/models.py:80-86) -------------------------------------
 // cls_ln[b,:] = LN1(X[b,0,:]) ;  feats[b*P + p, :] = LN2( LN1(X[b,1+p,:]) * cls_ln[b,:] )
 // stats1[b*Tp + t] = (mean, rstd) of LN1 on token t (t = 0 written by the cls pass), stats2[b*P+p] of LN2.
-__global__ __launch_bounds__(256) void merge_ln_kernel(const float* __restrict__ x, const float* __restrict__ cls_ln,
+__global__ __launch_bounds__(256) void merge_ln_kernel(const float* x, const bf16_t* __restrict__ delta, float* x_out, const float* __restrict__ cls_ln,
                                                        const float* __restrict__ g1, const float* __restrict__ b1,
                                                        const float* __restrict__ g2, const float* __restrict__ b2,
                                                        bf16_t* feats, float2* stats1, float2* stats2, int64_t B,
@@ -98,12 +121,20 @@ __global__ __launch_bounds__(256) void merge_ln_kernel(const float* __restrict__
     if (row >= B * P) return;
     const int64_t b = row / P, pp = row - b * P;
     const int nvec = D >> 2;
-    const float4* xr = (const float4*)(x + (b * Tp + 1 + pp) * D);
+    const int64_t xrow = b * Tp + 1 + pp;
+    const float4* xr = (const float4*)(x + xrow * D);
     const float4* cr = (const float4*)(cls_ln + b * D);
     float4 v[LN_MAXV];
 #pragma unroll
     for (int i = 0; i < LN_MAXV; i++)
-        if (lane + i * 64 < nvec) v[i] = xr[lane + i * 64];
+        if (lane + i * 64 < nvec) {
+            v[i] = xr[lane + i * 64];
+            if (delta) {
+                const uint2 u = ((const uint2*)(delta + xrow * D))[lane + i * 64];
+                v[i].x += bf2f(u.x & 0xffff); v[i].y += bf2f(u.x >> 16); v[i].z += bf2f(u.y & 0xffff); v[i].w += bf2f(u.y >> 16);
+                ((float4*)(x_out + xrow * D))[lane + i * 64] = v[i];
+            }
+        }
     float mean, rstd;
     row_stats<LN_MAXV>(v, nvec, lane, D, mean, rstd, eps);
     if (stats1 && lane == 0) stats1[b * Tp + 1 + pp] = make_float2(mean, rstd);
@@ -135,7 +166,7 @@ __global__ __launch_bounds__(256) void merge_ln_kernel(const float* __restrict__
 }
 
 // cls pass: one wave per image
-__global__ __launch_bounds__(64) void cls_ln_kernel(const float* __restrict__ x, const float* __restrict__ g1,
+__global__ __launch_bounds__(64) void cls_ln_kernel(const float* x, const bf16_t* __restrict__ delta, float* x_out, const float* __restrict__ g1,
                                                     const float* __restrict__ b1, float* cls_ln, float2* stats1,
                                                     int64_t Tp, int D, float eps) {
     const int lane = threadIdx.x;
@@ -145,7 +176,14 @@ __global__ __launch_bounds__(64) void cls_ln_kernel(const float* __restrict__ x,
     float4 v[LN_MAXV];
 #pragma unroll
     for (int i = 0; i < LN_MAXV; i++)
-        if (lane + i * 64 < nvec) v[i] = xr[lane + i * 64];
+        if (lane + i * 64 < nvec) {
+            v[i] = xr[lane + i * 64];
+            if (delta) {
+                const uint2 u = ((const uint2*)(delta + b * Tp * D))[lane + i * 64];
+                v[i].x += bf2f(u.x & 0xffff); v[i].y += bf2f(u.x >> 16); v[i].z += bf2f(u.y & 0xffff); v[i].w += bf2f(u.y >> 16);
+                ((float4*)(x_out + b * Tp * D))[lane + i * 64] = v[i];
+            }
+        }
     float mean, rstd;
     row_stats<LN_MAXV>(v, nvec, lane, D, mean, rstd, eps);
     if (stats1 && lane == 0) stats1[b * Tp] = make_float2(mean, rstd);
@@ -160,15 +198,16 @@ __global__ __launch_bounds__(64) void cls_ln_kernel(const float* __restrict__ x,
     }
 }
 
-extern "C" int owl_merge_ln_fwd(void* stream, const float* x, const float* g1, const float* b1, const float* g2,
-                                const float* b2, float* cls_ln, void* feats_bf16, float* stats1, float* stats2,
+extern "C" int owl_merge_ln_fwd(void* stream, const float* x, const void* delta_bf16, float* x_out, const float* g1, const float* b1,
+                                const float* g2, const float* b2, float* cls_ln, void* feats_bf16, float* stats1, float* stats2,
                                 int64_t B, int64_t P, int64_t Tp, int64_t D, float eps) {
     OWL_CHECK_ARG(x && g1 && b1 && g2 && b2 && cls_ln && feats_bf16, "owl_merge_ln_fwd: null pointer");
     OWL_CHECK_ARG(D % 4 == 0 && D <= 256 * LN_MAXV, "owl_merge_ln_fwd: D must be a multiple of 4 and <= 1024");
+    OWL_CHECK_ARG((delta_bf16 == nullptr) || (x_out != nullptr), "owl_merge_ln_fwd: x_out required with delta");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(cls_ln_kernel, dim3((unsigned)B), dim3(64), 0, s, x, g1, b1, cls_ln, (float2*)stats1, Tp, (int)D, eps);
+    hipLaunchKernelGGL(cls_ln_kernel, dim3((unsigned)B), dim3(64), 0, s, x, (const bf16_t*)delta_bf16, x_out, g1, b1, cls_ln, (float2*)stats1, Tp, (int)D, eps);
     OWL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(merge_ln_kernel, dim3((unsigned)((B * P + 3) / 4)), dim3(256), 0, s, x, cls_ln, g1, b1, g2, b2,
+    hipLaunchKernelGGL(merge_ln_kernel, dim3((unsigned)((B * P + 3) / 4)), dim3(256), 0, s, x, (const bf16_t*)delta_bf16, x_out, cls_ln, g1, b1, g2, b2,
                        (bf16_t*)feats_bf16, (float2*)stats1, (float2*)stats2, B, P, Tp, (int)D, eps);
     OWL_LAUNCH_CHECK();
     return 0;

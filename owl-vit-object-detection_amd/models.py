@@ -172,7 +172,7 @@ class OwlViT(nn.Module):
         ws = dict(
             x=z(M, D, f32, dev), h=z(M, D, bf, dev), qkv=z(M, 3 * D, bf, dev),
             qkvT=torch.zeros(B * 3 * D * Tp + 256, dtype=bf, device=dev),   # [B][3D][Tp] (+ slack for tile over-read)
-            att=z(M, D, bf, dev), g=z(M, I, bf, dev),
+            att=z(M, D, bf, dev), g=z(M, I, bf, dev), d1=z(M, D, bf, dev), d2=z(M, D, bf, dev),
             # trainable-layer saves
             x_in=z(M, D, f32, dev), x_mid=z(M, D, f32, dev), h1=z(M, D, bf, dev), h2=z(M, D, bf, dev), u=z(M, I, bf, dev),
             st1=torch.zeros(M, 2, device=dev), st2=torch.zeros(M, 2, device=dev), lse=torch.zeros(B, cfg.heads, Tp, device=dev),
@@ -219,15 +219,22 @@ class OwlViT(nn.Module):
 
         scale = cfg.head_dim ** -0.5
         qkv, qkvT, att, g = ws["qkv"], ws["qkvT"], ws["att"], ws["g"]
+        d1, d2 = ws["d1"], ws["d2"]
+        xs = x                  # residual stream BEFORE the pending MLP-branch delta is added
+        pending = None          # bf16 output of the previous layer's fc2, not yet added to the residual stream
         for i in range(cfg.layers):
             lw = self._layer_weights(i)
             sv = save and i == cfg.trainable_layer()
             h = ws["h1"] if sv else ws["h"]
-            x_src = x
-            if sv:
-                ws["x_in"].copy_(x)
-                x_src = ws["x_in"]
-            ops.layernorm(x_src, lw["g1"], lw["be1"], h, M, D, ws["st1"] if sv else None, cfg.ln_eps)
+            # Residual adds (HF5:500,507) live in the LayerNorm kernels: the GEMM in front of each emits a bf16
+            # delta through the fast deferred-store epilogue, and LN does x += delta while it normalises.
+            x_cur = ws["x_in"] if sv else xs
+            if pending is None:
+                if sv:
+                    x_cur.copy_(xs)
+                ops.layernorm(x_cur, lw["g1"], lw["be1"], h, M, D, ws["st1"] if sv else None, cfg.ln_eps)
+            else:
+                ops.layernorm(xs, lw["g1"], lw["be1"], h, M, D, ws["st1"] if sv else None, cfg.ln_eps, delta=pending, x_out=x_cur)
             if sv:   # row-major q,k,v and per-head transposed q,k,v (backward operands)
                 ops.gemm(ops.EPI_BIAS_BF16, h, lw["wqkv"], qkv, bias=lw["bqkv"], M=M, N=3 * D, K=D, ldo=3 * D)
                 ops.gemm(ops.EPI_TRANS_BF16, h, lw["wqkv"], qkvT, bias=lw["bqkv"], M=M, N=3 * D, K=D, Tp=Tp)
@@ -237,18 +244,21 @@ class OwlViT(nn.Module):
                 ops.gemm(ops.EPI_TRANS_BF16, h, lw["wqkv"][2 * D:], qkvT, bias=lw["bqkv"][2 * D:], M=M, N=D, K=D, Tp=Tp, w_rows=D)
                 vt, vt_stride = qkvT, D * Tp
             ops.attention_fwd(qkv, qkv[:, D:], 3 * D, vt, vt_stride, att, D, ws["lse"] if sv else None, B, H, T, Tp, scale)
-            x_dst = ws["x_mid"] if sv else x
-            ops.gemm(ops.EPI_RESID_F32, att, lw["wo"], x_dst, bias=lw["bo"], resid=x_src, M=M, N=D, K=D)
+            ops.gemm(ops.EPI_BIAS_BF16, att, lw["wo"], d1, bias=lw["bo"], M=M, N=D, K=D)
+            x_mid = ws["x_mid"] if sv else x_cur
             h2 = ws["h2"] if sv else ws["h"]
-            ops.layernorm(x_dst, lw["g2"], lw["be2"], h2, M, D, ws["st2"] if sv else None, cfg.ln_eps)
+            ops.layernorm(x_cur, lw["g2"], lw["be2"], h2, M, D, ws["st2"] if sv else None, cfg.ln_eps, delta=d1, x_out=x_mid)
             ops.gemm(ops.EPI_QGELU_BF16, h2, lw["w1"], g, bias=lw["b1"], aux=ws["u"] if sv else None, M=M, N=I, K=D)
-            ops.gemm(ops.EPI_RESID_F32, g, lw["w2"], x, bias=lw["b2"], resid=x_dst, M=M, N=D, K=I)
+            ops.gemm(ops.EPI_BIAS_BF16, g, lw["w2"], d2, bias=lw["b2"], M=M, N=D, K=I)
+            pending, xs = d2, x_mid
 
-        # ---- post_layernorm (all tokens) * class token -> post_post_layernorm (ref src/models.py:80-86)
+        # ---- final residual add + post_layernorm (all tokens) * class token -> post_post_layernorm
+        #      (ref src/models.py:80-86); the final residual stream is materialised in `x` for the backward
         feats = ws["feats"]
         tv = lambda n: self._tview(n)
-        ops.merge_ln(x, P_["backbone.post_layernorm.weight"], P_["backbone.post_layernorm.bias"], P_["post_post_layernorm.weight"],
-                     P_["post_post_layernorm.bias"], ws["cls_ln"], feats, ws["st_post"], ws["st_pp"], B, P, Tp, D, cfg.ln_eps)
+        ops.merge_ln(xs, P_["backbone.post_layernorm.weight"], P_["backbone.post_layernorm.bias"], P_["post_post_layernorm.weight"],
+                     P_["post_post_layernorm.bias"], ws["cls_ln"], feats, ws["st_post"], ws["st_pp"], B, P, Tp, D, cfg.ln_eps,
+                     delta=pending, x_out=x)
         # ---- box head (HF5:983-999) + bias / sigmoid / corners ---------------------------------------
         ops.gemm(ops.EPI_GELU_BF16, feats, tv("box_head.dense0.weight"), ws["hb0"], bias=P_["box_head.dense0.bias"],
                  aux=ws["ub0"] if save else None, M=Mh, N=D, K=D)

@@ -66,10 +66,16 @@ def cls_rows(x, cls, pos, B, Tp, D):
     _lib.call("owl_cls_rows", stream(), x, cls, pos, B, Tp, D)
 
 
-def layernorm(x, gamma, beta, out, rows, D, stats=None, eps=1e-5):
+def layernorm(x, gamma, beta, out, rows, D, stats=None, eps=1e-5, delta=None, x_out=None):
+    """out = LN(x) -- or, with `delta` (bf16), x_out = x + delta and out = LN(x_out) in one pass."""
     _chk(x, torch.float32, "x"); _chk(gamma, torch.float32, "gamma"); _chk(beta, torch.float32, "beta")
-    _lib.call("owl_layernorm_fwd", stream(), x, gamma, beta, out, 1 if out.dtype == torch.bfloat16 else 0, stats,
-              rows, D, float(eps))
+    ob = 1 if out.dtype == torch.bfloat16 else 0
+    if delta is None:
+        _lib.call("owl_layernorm_fwd", stream(), x, gamma, beta, out, ob, stats, rows, D, float(eps))
+    else:
+        _chk(delta, torch.bfloat16, "delta")
+        _lib.call("owl_add_layernorm_fwd", stream(), x, delta, x_out if x_out is not None else x, gamma, beta, out, ob, stats,
+                  rows, D, float(eps))
     return out
 
 
@@ -79,8 +85,9 @@ def attention_fwd(q, k, ld_qk, vt, vt_img_stride, out, ld_out, lse, B, H, T, Tp,
     return out
 
 
-def merge_ln(x, g1, b1, g2, b2, cls_ln, feats, stats1, stats2, B, P, Tp, D, eps=1e-5):
-    _lib.call("owl_merge_ln_fwd", stream(), x, g1, b1, g2, b2, cls_ln, feats, stats1, stats2, B, P, Tp, D, float(eps))
+def merge_ln(x, g1, b1, g2, b2, cls_ln, feats, stats1, stats2, B, P, Tp, D, eps=1e-5, delta=None, x_out=None):
+    _lib.call("owl_merge_ln_fwd", stream(), x, delta, (x_out if x_out is not None else x) if delta is not None else None,
+              g1, b1, g2, b2, cls_ln, feats, stats1, stats2, B, P, Tp, D, float(eps))
 
 
 def query_normalize(queries, qhat32, qnorm, nq, Dt):

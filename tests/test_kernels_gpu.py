@@ -149,6 +149,13 @@ def test_layernorm(D):
     x2 = x.clone()
     ops.layernorm(x2, g, b, x2, rows, D)          # in place f32
     report("ln f32 inplace", x2, ref, 1e-5, 1e-5)
+    # fused residual add: x_out = x + delta, out = LN(x_out)
+    delta = (0.5 * rnd(rows, D, seed=7)).bfloat16()
+    x3 = x.clone(); out3 = torch.zeros(rows, D, dtype=torch.bfloat16, device=DEV)
+    ops.layernorm(x3, g, b, out3, rows, D, delta=delta)            # x3 updated in place
+    xs = x + delta.float()
+    report("add-ln x_out", x3, xs, 1e-6, 1e-6)
+    report("add-ln out", out3, F.layer_norm(xs, (D,), g, b, 1e-5), 2e-2, 1e-2)
 
 
 def test_merge_ln():
@@ -164,6 +171,15 @@ def test_merge_ln():
     ops.merge_ln(x, g1, b1, g2, b2, cls_ln, feats, s1, s2, B, P, Tp, D)
     report("merge feats", feats[: B * P].view(B, P, D), ref, 2e-2, 1e-2)
     report("cls_ln", cls_ln, y[:, 0], 1e-5, 1e-5)
+    # with the fused final residual add
+    delta = torch.zeros(B * Tp, D, dtype=torch.bfloat16, device=DEV)
+    delta.view(B, Tp, D)[:, :T] = (0.3 * rnd(B, T, D, seed=9)).bfloat16()
+    xo = torch.zeros_like(x)
+    ops.merge_ln(x, g1, b1, g2, b2, cls_ln, feats, s1, s2, B, P, Tp, D, delta=delta, x_out=xo)
+    xs = xv[:, :T] + delta.view(B, Tp, D)[:, :T].float()
+    y2 = F.layer_norm(xs, (D,), g1, b1, 1e-5)
+    report("merge+add x_out", xo.view(B, Tp, D)[:, :T], xs, 1e-6, 1e-6)
+    report("merge+add feats", feats[: B * P].view(B, P, D), F.layer_norm(y2[:, 1:] * y2[:, :1], (D,), g2, b2, 1e-5), 2e-2, 1e-2)
 
 
 def _attn_case(B, H, T, seed):
