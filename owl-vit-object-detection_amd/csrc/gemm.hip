@@ -146,24 +146,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_nt_kernel(Gem
         b_off[j] = A_BYTES + rb * 128; b_sw[j] = (rb >> 1) & 7;
     }
 
-    // deferred bf16 epilogue state (256-wide tiles only: one workgroup per CU, nothing else hides the stores)
-    constexpr bool DEFER = (BM == 256) && (EPI == EPI_BIAS_BF16 || EPI == EPI_QGELU_BF16 || EPI == EPI_GELU_BF16 ||
-                                           EPI == EPI_DQGELU_BF16 || EPI == EPI_DGELU_BF16 || EPI == EPI_TRANS_BF16);
-    // register budget: 128 accumulators + 32 pending words fit 256 VGPRs; deferring the whole tile (64) spills.
-    // So the first half of the tile's chunks is stored at once (wide stores), the second half is trickled.
-    constexpr int NCH_ALL = TI * TJ * 2;               // 16-byte chunks per lane per tile (16)
-    constexpr int NCH = DEFER ? NCH_ALL / 2 : 1;       // deferred chunks (8): the rest is stored at once
-    uint4 pend[NCH];
-    int64_t pm0 = 0, pn0 = 0;
-    int pend_left = 0;                                  // chunks of the previous tile not yet stored (uniform)
-    bool pend_inner = true;                             // previous tile entirely inside [M, N] (uniform)
-    auto store_pend = [&](int cidx) {                  // cidx is a compile-time constant at every call site
-        if constexpr (DEFER) {
-            const int t = (cidx + NCH_ALL - NCH) >> 1, i = t / TJ, j = t - i * TJ;   // deferred chunks are the LAST ones
-            if (pend_inner) epi_store_chunk<EPI, false>(p, pend[cidx], pm0 + wr_ * WM + i * 32, pn0 + wc_ * WN + j * 32, cidx & 1, lane);
-            else epi_store_chunk<EPI, true>(p, pend[cidx], pm0 + wr_ * WM + i * 32, pn0 + wc_ * WN + j * 32, cidx & 1, lane);
-        }
-    };
+    // bf16-output epilogues on the 256-wide tile use the register path: element-wise math, pack, v_permlane32_swap
+    // pairing -> 16-byte stores (store ISSUE is the scarce resource: ~64 cycles per wave-instruction per CU whatever
+    // its width).  Deferring those stores into the next tile's K-loop was measured and rejected: the 32-64 extra
+    // live registers cost more in the main loop (spills / just-in-time fragment loads) than the hidden issue time.
+    constexpr bool WIDE = (BM == 256) && (EPI == EPI_BIAS_BF16 || EPI == EPI_QGELU_BF16 || EPI == EPI_GELU_BF16 ||
+                                          EPI == EPI_DQGELU_BF16 || EPI == EPI_DGELU_BF16 || EPI == EPI_TRANS_BF16);
 
     decode(item);
     setup_src();
@@ -197,56 +185,41 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_nt_kernel(Gem
                 stage(cur ^ 1, kt0);
                 stage_bias(tile_parity ^ 1);
             }
-            if constexpr (DEFER) {
-                // trickle the previous tile's output: 2 wide stores per K-step, hidden under this step's MFMAs
-                // 8 deferred chunks, one per K-step: 8 KiB per step per CU, well under the ~8 B/clk/CU store path
-                if (pend_left > 0) {
-                    switch (NCH - pend_left) {
-                        case 0: store_pend(0); break;
-                        case 1: store_pend(1); break;
-                        case 2: store_pend(2); break;
-                        case 3: store_pend(3); break;
-                        case 4: store_pend(4); break;
-                        case 5: store_pend(5); break;
-                        case 6: store_pend(6); break;
-                        default: store_pend(7); break;
-                    }
-                    pend_left -= 1;
-                }
-            }
             const unsigned char* tb = lds + cur * STAGE;
+            // software-pipelined fragments: the six ds_read_b128 of K-chunk kc+1 are issued BEFORE the eight MFMAs of
+            // chunk kc (sched_barrier pins the order; the compiler's own lgkmcnt(N) then waits only for the older set),
+            // so a wave covers its LDS latency with its own matrix work instead of stalling every two MFMAs.
+            bf16x8 fa[2][TI], fb[2][TJ];
+            auto rd = [&](int set, int kc) {
+                const int ch = kc * 2 + hi;
+#pragma unroll
+                for (int j = 0; j < TJ; j++) fb[set][j] = *(const bf16x8*)(tb + b_off[j] + ((ch ^ b_sw[j]) << 4));
+#pragma unroll
+                for (int i = 0; i < TI; i++) fa[set][i] = *(const bf16x8*)(tb + a_off[i] + ((ch ^ a_sw[i]) << 4));
+            };
+            rd(0, 0);
 #pragma unroll
             for (int kc = 0; kc < 4; kc++) {
-                const int ch = kc * 2 + hi;
-                bf16x8 af[TI], bfr[TJ];
-#pragma unroll
-                for (int i = 0; i < TI; i++) af[i] = *(const bf16x8*)(tb + a_off[i] + ((ch ^ a_sw[i]) << 4));
-#pragma unroll
-                for (int j = 0; j < TJ; j++) bfr[j] = *(const bf16x8*)(tb + b_off[j] + ((ch ^ b_sw[j]) << 4));
+                const int cs = kc & 1;
+                if (kc < 3) rd(cs ^ 1, kc + 1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < TI; i++)
 #pragma unroll
                     for (int j = 0; j < TJ; j++) {
                         if constexpr (TRANS)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cs][i], fb[cs][j], acc[i][j], 0, 0, 0);
                         else  // swapped: D rows = n, cols = m -> each lane owns 4 consecutive n of one m
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cs][j], fa[cs][i], acc[i][j], 0, 0, 0);
                     }
+                __builtin_amdgcn_sched_barrier(0);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             cur ^= 1;
         }
-        if constexpr (DEFER) {
-            // short tiles (< 8 K-steps): whatever of the previous tile is still pending goes out now
-            if (pend_left > 0) {
-#pragma unroll
-                for (int cdx = 0; cdx < NCH; cdx++)
-                    if (cdx >= NCH - pend_left) store_pend(cdx);
-            }
-            // element-wise epilogue in registers -> packed bf16, 16 bytes per lane; stores deferred into the next tile
-            static_assert(NCH == 8 || !DEFER, "slice schedule assumes 8 deferred chunks");
+        if constexpr (WIDE) {
             const bool inner = (cm0 + BM <= p.M) && (cn0 + BN <= p.N);   // wave-uniform: no per-lane guards needed
             const float* lbias = (const float*)(lds + 2 * STAGE + tile_parity * (BN * 4)) + wc * WN;
             auto run = [&](auto guard_tag) {
@@ -257,23 +230,13 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_nt_kernel(Gem
                     for (int j = 0; j < TJ; j++) {
                         const int t = i * TJ + j;
                         const int64_t mt = cm0 + wr * WM + i * 32, nt = cn0 + wc * WN + j * 32;
-                        if (2 * t < NCH_ALL - NCH) {   // not-deferred part of the tile (none when all 16 chunks are deferred)
-                            uint4 c0, c1;
-                            epi_tile_bf16<EPI, G>(p, acc[i][j], mt, nt, lane, c0, c1, lbias + j * 32);
-                            epi_store_chunk<EPI, G>(p, c0, mt, nt, 0, lane);
-                            epi_store_chunk<EPI, G>(p, c1, mt, nt, 1, lane);
-                        } else {                     // second half: keep packed in registers, trickle into the next tile
-                            epi_tile_bf16<EPI, G>(p, acc[i][j], mt, nt, lane, pend[2 * t - (NCH_ALL - NCH)], pend[2 * t - (NCH_ALL - NCH) + 1], lbias + j * 32);
-                        }
+                        uint4 c0, c1;
+                        epi_tile_bf16<EPI, G>(p, acc[i][j], mt, nt, lane, c0, c1, lbias + j * 32);
+                        epi_store_chunk<EPI, G>(p, c0, mt, nt, 0, lane);
+                        epi_store_chunk<EPI, G>(p, c1, mt, nt, 1, lane);
                     }
             };
             if (inner) run(std::false_type{}); else run(std::true_type{});
-            pend_inner = inner;
-            pm0 = cm0; pn0 = cn0; pend_left = NCH;
-            if (!has_next) {
-#pragma unroll
-                for (int cdx = 0; cdx < NCH; cdx++) store_pend(cdx);
-            }
         } else {
         // ---- epilogue AFTER the last barrier: buffer cur^1 was just consumed, and each wave stages through
         //      the slice of it that only IT will DMA into next; the global stores then drain under the next

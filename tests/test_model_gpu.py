@@ -104,11 +104,12 @@ def _grad_report(grads, ref, tag):
     return worst, worst_cos
 
 
-@pytest.mark.parametrize("cname,B", [("tiny", 1), ("tiny", 3), ("small", 2)])
+@pytest.mark.parametrize("cname,B", [("tiny", 1), ("tiny", 3), ("small", 2), ("owlvit-base-patch16", 1)])
 def test_backward_chain_matches_oracle_given_same_upstream(cname, B):
     """Backward kernels in isolation: identical upstream (d_boxes, d_sims) into the HIP backward and into
     the oracle's autograd -- removes the loss's 1/|sim| amplification of bf16 forward noise."""
     cfg = get_config(cname)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))     # the oracle's CPU backward at full B/16 size
     Wnp = weights.make_weights(cfg)
     img = synth.make_images(cfg, B)
     g = torch.Generator().manual_seed(5)
@@ -198,4 +199,5 @@ def test_train_step_b16_matches_reference_fixture_f2(golden_dir):
                           # init), 100x smaller than the rest -- a 64-element sample of them is bf16 noise; norm checked above
         head = torch.from_numpy(g["gradhead/" + n])
         cos = float((gr.reshape(-1)[:64] * head).sum() / (gr.reshape(-1)[:64].norm() * head.norm() + 1e-20))
-        assert cos > 0.95, (n, cos)   # 64-element sample of an end-to-end gradient (loss-amplified bf16 noise)
+        assert cos > 0.9, (n, cos)    # 64-element sample of an end-to-end gradient (loss-amplified bf16 noise);
+                                      # the strict all-element check is test_backward_chain_...[owlvit-base-patch16-1]
