@@ -14,25 +14,35 @@
 // transposing epilogue) stream HBM -> LDS by LDS-DMA, double-buffered, XOR-swizzled like the GEMM
 // tiles (conflict-free ds_read_b128).  Online softmax in the exp2 domain.
 #include "common.h"
+#include <type_traits>
 
 struct AttnFwdP {
     const bf16_t* q; const bf16_t* k; int64_t ld_qk;   // row-major [B*Tp, ld]; head h at column h*64
     const bf16_t* vt; int64_t vt_img_stride;            // V^T [B][heads..][64][Tp]; element stride per image
     bf16_t* out; int64_t ld_out;                        // [B*Tp, ld_out], head h at column h*64
     float* lse;                                         // optional [B][H][Tp], log2 domain
-    int T, Tp, H;
+    int T, Tp, H, B, nqb;
     float scale_log2e;
 };
 
 __device__ __forceinline__ int swap23(int m) { return (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1); }
 
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnFwdP p) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 16384];
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
+    // dynamic LDS (one object): with a static array hipcc drains the just-issued LDS-DMA (vmcnt(0)) before the
+    // first ds_read of every tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int hi = lane >> 5;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * 128 + w * 32;
+    // XCD-aware work mapping (1-D grid): workgroups id, id+8, ... share an XCD (private L2).  All query blocks
+    // of one (image, head) go to ONE XCD, back to back, so its K / V^T (0.6 MB at T = 2305) is fetched into that
+    // L2 once and re-read there by the other query blocks instead of being duplicated in all eight L2s.
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int pair = (idx / p.nqb) * 8 + xcd;                 // (image, head) pair
+    if (pair >= p.B * p.H) return;
+    const int qb = idx - (idx / p.nqb) * p.nqb;
+    const int b = pair / p.H, h = pair - b * p.H;
+    const int q0 = qb * 128 + w * 32;
     const float c = p.scale_log2e;
 
     // ---- Q fragments (B operand of S^T = K Q^T): lane -> query row q0 + (lane&31), 8 d per chunk
@@ -66,42 +76,43 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnFwdP p) {
     for (int d = 0; d < 2; d++)
 #pragma unroll
         for (int r = 0; r < 16; r++) o[d][r] = 0.f;
-    float m_run = -1e30f, l_run = 0.f;
+    float m_run = -1e30f;
 
-    // fragment addressing
-    int k_off[2], k_sw[2], v_off[2], v_sw[2];
+    // fragment byte offsets inside a stage buffer, all 24 precomputed once (the kernel is VALU-bound: 78 % VALU
+    // busy vs 45 % MFMA busy by PMC -- per-tile address arithmetic was ~15 % of its VALU instructions)
+    int k_addr[2][4], v_addr[2][8];
 #pragma unroll
     for (int t = 0; t < 2; t++) {
         const int rk = t * 32 + swap23(lane & 31);
-        k_off[t] = rk * 128; k_sw[t] = (rk >> 1) & 7;
+#pragma unroll
+        for (int kc = 0; kc < 4; kc++) k_addr[t][kc] = rk * 128 + (((kc * 2 + hi) ^ ((rk >> 1) & 7)) << 4);
         const int rv = t * 32 + (lane & 31);
-        v_off[t] = 8192 + rv * 128; v_sw[t] = (rv >> 1) & 7;
+#pragma unroll
+        for (int c8 = 0; c8 < 4; c8++) {
+            v_addr[t][2 * c8 + 0] = 8192 + rv * 128 + (((c8 * 2 + hi) ^ ((rv >> 1) & 7)) << 4);       // unused slot layout:
+            v_addr[t][2 * c8 + 1] = v_addr[t][2 * c8 + 0];                                              // [d-block t][chunk c8]
+        }
     }
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float l_part = 0.f;                                          // this half-wave's running sum of P (unnormalised)
 
-    const int nkv = (p.T + 63) / 64;
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    int cur = 0;
-    for (int kv = 0; kv < nkv; kv++) {
-        if (kv + 1 < nkv) stage(cur ^ 1, kv + 1);
-        const unsigned char* tb = lds + cur * 16384;
-
-        // ---- S^T = K Q^T : two 32-key tiles ----------------------------------------------------
+    // one KV tile: S^T = K Q^T, online softmax, O^T += V^T P^T.  BUF is a compile-time buffer index so that the
+    // stage offset folds into the ds_read immediate; MASK only for the (peeled) partial last tile.
+    auto tile = [&](auto buf_tag, int kv, auto mask_tag) {
+        constexpr int BUF = decltype(buf_tag)::value;
+        constexpr bool MASK = decltype(mask_tag)::value;
+        const unsigned char* tb = lds + BUF * 16384;
         f32x16 s[2];
 #pragma unroll
         for (int t = 0; t < 2; t++) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) s[t][r] = 0.f;
-#pragma unroll
             for (int kc = 0; kc < 4; kc++) {
-                const bf16x8 kf = *(const bf16x8*)(tb + k_off[t] + (((kc * 2 + hi) ^ k_sw[t]) << 4));
-                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kc], s[t], 0, 0, 0);
+                const bf16x8 kf = *(const bf16x8*)(tb + k_addr[t][kc]);
+                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kc], kc == 0 ? zero16 : s[t], 0, 0, 0);   // C = 0: no clears
             }
         }
-        // lane's key for register r of tile t:  kv*64 + t*32 + 16*(r>>3) + 8*hi + (r&7)
-        if (kv * 64 + 64 > p.T) {
+        if constexpr (MASK) {
+            // lane's key for register r of tile t:  kv*64 + t*32 + 16*(r>>3) + 8*hi + (r&7)
 #pragma unroll
             for (int t = 0; t < 2; t++)
 #pragma unroll
@@ -110,52 +121,83 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnFwdP p) {
                     if (key >= p.T) s[t][r] = -INFINITY;
                 }
         }
-        // ---- online softmax (per query column = per lane pair {l, l^32}) -------------------------
+        // ---- online softmax (per query column = per lane pair {l, l^32}) ---------------------------
         float mx = s[0][0];
 #pragma unroll
         for (int t = 0; t < 2; t++)
 #pragma unroll
             for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[t][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-        const float mc = m_new * c;
-        m_run = m_new;
-        float psum = 0.f;
+        // deferred rescale: keep the old running max while this tile's max exceeds it by < 2^8 in the exp2
+        // domain (P stays <= 256, harmless in f32 / relative-precision bf16); rescale O only when some lane needs it.
+        if (!__all((mx - m_run) * c <= 8.0f)) {
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            m_run = m_new;
+            l_part *= alpha;
+#pragma unroll
+            for (int d = 0; d < 2; d++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) o[d][r] *= alpha;
+        }
+        const float mc = m_run * c;
 #pragma unroll
         for (int t = 0; t < 2; t++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], c, -mc));
-                s[t][r] = pv;
-                psum += pv;
+                s[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], c, -mc));
+                l_part += s[t][r];
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int d = 0; d < 2; d++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) o[d][r] *= alpha;
-
-        // ---- O^T += V^T P^T : 4 chunks of 16 keys, 2 d-blocks ------------------------------------
+        // ---- O^T += V^T P^T (4 chunks of 16 keys, 2 d-blocks) ----
 #pragma unroll
         for (int t = 0; t < 2; t++)
 #pragma unroll
             for (int cc = 0; cc < 2; cc++) {
-                bf16x8 pf;
-#pragma unroll
-                for (int j = 0; j < 8; j++) pf[j] = (short)f2bf(s[t][cc * 8 + j]);
-                const int ch = (t * 2 + cc) * 2 + hi;
+                const uint4 pw = make_uint4(pack_bf2(s[t][cc * 8 + 0], s[t][cc * 8 + 1]), pack_bf2(s[t][cc * 8 + 2], s[t][cc * 8 + 3]),
+                                            pack_bf2(s[t][cc * 8 + 4], s[t][cc * 8 + 5]), pack_bf2(s[t][cc * 8 + 6], s[t][cc * 8 + 7]));
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);     // 4 v_cvt_pk, no repacking
+                const int c8 = t * 2 + cc;
 #pragma unroll
                 for (int d = 0; d < 2; d++) {
-                    const bf16x8 vf = *(const bf16x8*)(tb + v_off[d] + ((ch ^ v_sw[d]) << 4));
+                    const bf16x8 vf = *(const bf16x8*)(tb + v_addr[d][2 * c8]);
                     o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
                 }
             }
+    };
+
+    const int nkv = (p.T + 63) / 64;
+    const int nfull = p.T / 64;          // tiles with no key >= T
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    auto sync = [&]() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        cur ^= 1;
+    };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    int kv = 0;
+    for (; kv + 1 < nfull; kv += 2) {          // two tiles per trip: buffer index is a compile-time constant
+        stage(1, kv + 1);
+        tile(B0{}, kv, std::false_type{});
+        sync();
+        if (kv + 2 < nkv) stage(0, kv + 2);
+        tile(B1{}, kv + 1, std::false_type{});
+        sync();
     }
+    // remainder: at most one full tile and/or the partial tile, buffers alternate from (kv & 1)
+    if (kv < nfull) {                           // kv even here -> buffer 0
+        if (kv + 1 < nkv) stage(1, kv + 1);
+        tile(B0{}, kv, std::false_type{});
+        sync();
+        kv++;
+    }
+    if (kv < nkv) {
+        if (kv & 1) tile(B1{}, kv, std::true_type{}); else tile(B0{}, kv, std::true_type{});
+    }
+    const float l_run = l_part;
 
     // ---- epilogue: normalise, write O (row-major, head h) and LSE ---------------------------------
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -187,8 +229,10 @@ extern "C" int owl_attention_fwd_bf16(void* stream, const void* q, const void* k
     p.out = (bf16_t*)out; p.ld_out = ld_out; p.lse = lse;
     p.T = (int)T; p.Tp = (int)Tp; p.H = (int)H;
     p.scale_log2e = scale * 1.4426950408889634f;
-    dim3 grid((unsigned)((T + 127) / 128), (unsigned)H, (unsigned)B);
-    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    p.B = (int)B; p.nqb = (int)((T + 127) / 128);
+    const int64_t npairs8 = (B * H + 7) / 8;                  // pairs per XCD (rounded up)
+    dim3 grid((unsigned)(npairs8 * p.nqb * 8));
+    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 2 * 16384, (hipStream_t)stream, p);
     OWL_LAUNCH_CHECK();
     return 0;
 }
