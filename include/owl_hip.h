@@ -69,6 +69,8 @@ int owl_add_layernorm_fwd(void* stream, const float* x, const void* delta_bf16, 
  * by epilogue 6; out row-major [B*Tp, ld_out]; lse optional [B,H,Tp] (log2 domain).               */
 int owl_attention_fwd_bf16(void* stream, const void* q, const void* k, int64_t ld_qk, const void* vt, int64_t vt_img_stride, void* out, int64_t ld_out, float* lse, int64_t B, int64_t H, int64_t T, int64_t Tp, float scale);
 
+/* tuning / race-hunting switches (bit 0: always rescale, bit 1: plain block mapping, bit 2: lgkmcnt(0) before barriers) */
+int owl_attention_debug(int flags);
 /* backward of the above for the trainable layer: qkv row-major [B*Tp,3D] (q|k|v), qkvT / dOT per-head
  * transposed copies ([B][3D][Tp] / [B][D][Tp], epilogue 6), O and dO row-major [B*Tp,D]; writes dqkv [B*Tp,3D]. */
 int owl_attention_bwd_bf16(void* stream, const void* qkv, const void* qkvT, const void* dO, const void* dOT, const void* O, const float* lse, float* dvec_ws, void* dqkv, int64_t B, int64_t H, int64_t T, int64_t Tp, float scale);

@@ -21,7 +21,7 @@ struct AttnFwdP {
     const bf16_t* vt; int64_t vt_img_stride;            // V^T [B][heads..][64][Tp]; element stride per image
     bf16_t* out; int64_t ld_out;                        // [B*Tp, ld_out], head h at column h*64
     float* lse;                                         // optional [B][H][Tp], log2 domain
-    int T, Tp, H, B, nqb;
+    int T, Tp, H, B, nqb, dbg;
     float scale_log2e;
 };
 
@@ -37,8 +37,9 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
     // XCD-aware work mapping (1-D grid): workgroups id, id+8, ... share an XCD (private L2).  All query blocks
     // of one (image, head) go to ONE XCD, back to back, so its K / V^T (0.6 MB at T = 2305) is fetched into that
     // L2 once and re-read there by the other query blocks instead of being duplicated in all eight L2s.
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int pair = (idx / p.nqb) * 8 + xcd;                 // (image, head) pair
+    int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    if (p.dbg & 2) { xcd = 0; idx = blockIdx.x; }
+    const int pair = (p.dbg & 2) ? (idx / p.nqb) : (idx / p.nqb) * 8 + xcd;                 // (image, head) pair
     if (pair >= p.B * p.H) return;
     const int qb = idx - (idx / p.nqb) * p.nqb;
     const int b = pair / p.H, h = pair - b * p.H;
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         // deferred rescale: keep the old running max while this tile's max exceeds it by < 2^8 in the exp2
         // domain (P stays <= 256, harmless in f32 / relative-precision bf16); rescale O only when some lane needs it.
-        if (!__all((mx - m_run) * c <= 8.0f)) {
+        if ((p.dbg & 1) || !__all((mx - m_run) * c <= 8.0f)) {
             const float m_new = fmaxf(m_run, mx);
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
             m_run = m_new;
@@ -168,11 +169,15 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
     const int nkv = (p.T + 63) / 64;
     const int nfull = p.T / 64;          // tiles with no key >= T
     stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    // Every wave must have its LDS reads RETURNED (lgkmcnt(0)), not merely issued, before the barrier: hipcc may
+    // sink the MFMAs that consume the tile's last ds_reads below the barrier, and under a loaded LDS pipeline such a
+    // read can still be queued when another wave's post-barrier LDS-DMA (250-400 cycles, L2-warm) lands in the same
+    // buffer.  Observed as run-to-run differences in ~3 % of rows; tests/test_determinism_gpu.py guards it.
     auto sync = [&]() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
@@ -218,6 +223,9 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
     }
 }
 
+static int g_attn_dbg = 0;
+extern "C" int owl_attention_debug(int flags) { g_attn_dbg = flags; return 0; }
+
 extern "C" int owl_attention_fwd_bf16(void* stream, const void* q, const void* k, int64_t ld_qk, const void* vt,
                                       int64_t vt_img_stride, void* out, int64_t ld_out, float* lse, int64_t B,
                                       int64_t H, int64_t T, int64_t Tp, float scale) {
@@ -229,7 +237,7 @@ extern "C" int owl_attention_fwd_bf16(void* stream, const void* q, const void* k
     p.out = (bf16_t*)out; p.ld_out = ld_out; p.lse = lse;
     p.T = (int)T; p.Tp = (int)Tp; p.H = (int)H;
     p.scale_log2e = scale * 1.4426950408889634f;
-    p.B = (int)B; p.nqb = (int)((T + 127) / 128);
+    p.B = (int)B; p.nqb = (int)((T + 127) / 128); p.dbg = g_attn_dbg;
     const int64_t npairs8 = (B * H + 7) / 8;                  // pairs per XCD (rounded up)
     dim3 grid((unsigned)(npairs8 * p.nqb * 8));
     hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 2 * 16384, (hipStream_t)stream, p);

@@ -10,7 +10,9 @@
 //     (the workhorse: one K-step is 32 MFMAs per wave, long enough to cover the next tile's load
 //     latency, and 25 % less LDS traffic per FLOP) and 128x128 with 4 waves of 64x64 (small / thin shapes);
 //   * operand tiles go HBM -> LDS by direct LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction),
-//     double-buffered, ONE barrier per K-step; the next tile's DMA is issued before the current tile's MFMAs;
+//     double-buffered, ONE barrier per K-step (preceded by vmcnt(0) AND lgkmcnt(0): LDS reads must have returned,
+//     not just issued, before another wave may DMA into that buffer); the next tile's DMA is issued before the
+//     current tile's MFMAs;
 //   * LDS image of a [rows][64 k] bf16 tile is row-linear (the DMA destination is lane-linear) with the
 //     16-byte chunk index XOR-swizzled by ((row>>1)&7) -- applied to the per-lane SOURCE address and again on
 //     the ds_read_b128 address -- which makes every ds_read_b128 lane group conflict-free;
@@ -158,7 +160,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_nt_kernel(Gem
     stage(0, kt0);
     int tile_parity = 0;
     stage_bias(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     int cur = 0;
@@ -214,7 +216,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_nt_kernel(Gem
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             cur ^= 1;

@@ -1,0 +1,82 @@
+"""Bitwise run-to-run determinism of the LDS-DMA pipelined kernels.  A tolerance test cannot see an LDS race
+(a wave reading a buffer another wave's DMA is already refilling corrupts a few rows by ~1e-2); identical
+inputs must give identical bits, every run, and an image's result must not depend on its batch neighbours."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from owl_vit_object_detection_amd import ops  # noqa: E402
+
+DEV = "cuda"
+
+
+def test_attention_fwd_bitwise_repeatable_and_batch_independent():
+    torch.manual_seed(0)
+    H, T, B = 12, 2305, 8
+    Tp = (T + 7) // 8 * 8; D = H * 64; M = B * Tp
+    qkv = torch.zeros(ops.pad_rows(M), 3 * D, device=DEV, dtype=torch.bfloat16)
+    qkv[:M] = torch.randn(M, 3 * D, device=DEV).bfloat16()
+    vt = torch.zeros(B * H * 64 * Tp + 128, device=DEV, dtype=torch.bfloat16)
+    vt[: B * H * 64 * Tp] = torch.randn(B * H * 64 * Tp, device=DEV).bfloat16()
+
+    def run():
+        out = torch.zeros(ops.pad_rows(M), D, device=DEV, dtype=torch.bfloat16)
+        ops.attention_fwd(qkv, qkv[:, D:], 3 * D, vt, H * 64 * Tp, out, D, None, B, H, T, Tp, 0.125)
+        torch.cuda.synchronize()
+        return out
+
+    ref = run()
+    for _ in range(15):
+        assert torch.equal(run(), ref)
+    for b in (0, 3, 7):       # the same image alone in a batch of one
+        q1 = torch.zeros(ops.pad_rows(Tp), 3 * D, device=DEV, dtype=torch.bfloat16); q1[:Tp] = qkv[b * Tp:(b + 1) * Tp]
+        v1 = torch.zeros(H * 64 * Tp + 128, device=DEV, dtype=torch.bfloat16); v1[: H * 64 * Tp] = vt[b * H * 64 * Tp:(b + 1) * H * 64 * Tp]
+        o1 = torch.zeros(ops.pad_rows(Tp), D, device=DEV, dtype=torch.bfloat16)
+        ops.attention_fwd(q1, q1[:, D:], 3 * D, v1, H * 64 * Tp, o1, D, None, 1, H, T, Tp, 0.125)
+        assert torch.equal(o1[:T], ref[b * Tp: b * Tp + T]), b
+
+
+@pytest.mark.parametrize("N,K,epi", [(3072, 768, ops.EPI_QGELU_BF16), (768, 3072, ops.EPI_BIAS_BF16), (1536, 768, ops.EPI_BIAS_BF16)])
+def test_gemm_bitwise_repeatable(N, K, epi):
+    torch.manual_seed(1)
+    M = 8 * 2312
+    A = torch.zeros(ops.pad_rows(M), K, device=DEV, dtype=torch.bfloat16); A[:M] = torch.randn(M, K, device=DEV).bfloat16()
+    W = (torch.randn(N, K, device=DEV) * 0.05).bfloat16(); bias = torch.randn(N, device=DEV)
+
+    def run():
+        out = torch.zeros(ops.pad_rows(M), N, device=DEV, dtype=torch.bfloat16)
+        ops.gemm(epi, A, W, out, bias=bias, M=M)
+        torch.cuda.synchronize()
+        return out
+
+    ref = run()
+    for _ in range(10):
+        assert torch.equal(run(), ref)
+
+
+def test_attention_bwd_bitwise_repeatable():
+    torch.manual_seed(2)
+    H, T, B = 4, 577, 3
+    Tp = (T + 7) // 8 * 8; D = H * 64; M = B * Tp
+    qkv = torch.zeros(ops.pad_rows(M), 3 * D, device=DEV, dtype=torch.bfloat16); qkv[:M] = torch.randn(M, 3 * D, device=DEV).bfloat16()
+    qkvT = torch.zeros(B * 3 * D * Tp + 256, device=DEV, dtype=torch.bfloat16)
+    qkvT[: B * 3 * D * Tp].view(B, 3 * D, Tp)[:] = qkv[:M].view(B, Tp, 3 * D).transpose(1, 2)
+    O = torch.zeros(ops.pad_rows(M), D, device=DEV, dtype=torch.bfloat16)
+    lse = torch.zeros(B, H, Tp, device=DEV)
+    ops.attention_fwd(qkv, qkv[:, D:], 3 * D, qkvT[2 * D * Tp:], 3 * D * Tp, O, D, lse, B, H, T, Tp, 0.125)
+    dO = torch.zeros(ops.pad_rows(M), D, device=DEV, dtype=torch.bfloat16); dO[:M] = (0.1 * torch.randn(M, D, device=DEV)).bfloat16()
+    dO.view(-1, D)[:M].view(B, Tp, D)[:, T:] = 0
+    dOT = torch.zeros(B * D * Tp + 256, device=DEV, dtype=torch.bfloat16)
+    dOT[: B * D * Tp].view(B, D, Tp)[:] = dO[:M].view(B, Tp, D).transpose(1, 2)
+
+    def run():
+        dqkv = torch.zeros(ops.pad_rows(M), 3 * D, device=DEV, dtype=torch.bfloat16)
+        dvec = torch.zeros(B, H, Tp, device=DEV)
+        ops.attention_bwd(qkv, qkvT, dO, dOT, O, lse, dvec, dqkv, B, H, T, Tp, 0.125)
+        torch.cuda.synchronize()
+        return dqkv
+
+    ref = run()
+    for _ in range(10):
+        assert torch.equal(run(), ref)
