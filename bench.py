@@ -171,7 +171,8 @@ def main():
         attn_flops = 4.0 * B * cfg.heads * cfg.tokens * cfg.tokens * cfg.head_dim          # QK^T + PV per launch
         achieved = attn_flops / (attn_ms * 1e-3) / 1e12
         out = {
-            "metric": "train images/sec, OWL-ViT-B/16 768x768" if not args.forward_only else "forward images/sec, OWL-ViT-B/16 768x768",
+            "metric": ("forward" if args.forward_only else "train") + " images/sec, "
+                      + ("OWL-ViT-B/16 768x768" if cfg.name == "owlvit-base-patch16" else f"{cfg.name} {cfg.image_size}x{cfg.image_size}"),
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic (CLIP-normalised uniform-u8 pixels, 1-16 boxes/image, 10 classes; random-init weights)",

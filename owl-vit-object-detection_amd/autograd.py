@@ -43,10 +43,6 @@ def _attach_grads(model):
 class OwlViTFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, image, *params):
-        cfg = model.cfg
-        if cfg.trainable_layer() != cfg.layers - 1:
-            raise NotImplementedError(
-                "backward through frozen layers above the trainable one (layers.11 of a deeper model) is not built yet")
         boxes, sims = model._forward_impl(image, save=True)
         ctx.model = model
         ctx.B = image.shape[0]
@@ -159,33 +155,49 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
                      P_["backbone.post_layernorm.bias"], P_["post_post_layernorm.weight"], bw["dx"], bw["dcls"],
                      G("backbone.post_layernorm.weight"), G("backbone.post_layernorm.bias"), G("post_post_layernorm.weight"),
                      G("post_post_layernorm.bias"), B, P, Tp, D)
+    scale = cfg.head_dim ** -0.5
+    # ---- frozen layers ABOVE the trainable one (literal "layers.11" rule on a deeper model): dX only ----------
+    for i in range(cfg.layers - 1, cfg.trainable_layer(), -1):
+        Ls, fz = model._layer_ws(B, i), model._fz
+        pre = f"backbone.encoder.layers.{i}."
+        ops.cast_bf16(bw["dx"], bw["dxb"])
+        ops.gemm(ops.EPI_DQGELU_BF16, bw["dxb"], fz[f"{i}.w2T"], bw["du"], aux=Ls["u"], M=M, N=I, K=D)
+        ops.gemm(ops.EPI_BIAS_BF16, bw["du"], fz[f"{i}.w1T"], bw["dh"], M=M, N=D, K=I)
+        ops.layernorm_bwd(bw["dh"], Ls["x_mid"], Ls["st2"], P_[pre + "layer_norm2.weight"], bw["dx"], bw["dxm"], None, None, M, D)
+        ops.cast_bf16(bw["dxm"], bw["dxb"])
+        ops.gemm(ops.EPI_BIAS_BF16, bw["dxb"], fz[f"{i}.woT"], bw["datt"], M=M, N=D, K=D)
+        ops.gemm(ops.EPI_TRANS_BF16, bw["dxb"], fz[f"{i}.woT"], bw["dattT"], M=M, N=D, K=D, Tp=Tp)
+        ops.attention_bwd(Ls["qkv"], Ls["qkvT"], bw["datt"], bw["dattT"], Ls["att"], Ls["lse"], bw["dvec"], bw["dqkv"], B, H, T, Tp, scale)
+        ops.gemm(ops.EPI_BIAS_BF16, bw["dqkv"], fz[f"{i}.wqkvT"], bw["dh"], M=M, N=D, K=3 * D)
+        ops.layernorm_bwd(bw["dh"], Ls["x_in"], Ls["st1"], P_[pre + "layer_norm1.weight"], bw["dxm"], bw["dx"], None, None, M, D)
+    Lt = model._layer_ws(B, cfg.trainable_layer())
     # ---- trainable encoder layer: MLP ---------------------------------------------------------------------
     ops.cast_bf16(bw["dx"], bw["dxb"])
     ops.colsum_f32(bw["dx"], G(tl + "mlp.fc2.bias"), M, D)
-    dW(bw["dxb"], ws["g"], G(tl + "mlp.fc2.weight"), D, I, M, Mp)
-    ops.gemm(ops.EPI_DQGELU_BF16, bw["dxb"], wT(tl + "mlp.fc2.weight", D, I), bw["du"], aux=ws["u"], M=M, N=I, K=D)
-    dW(bw["du"], ws["h2"], G(tl + "mlp.fc1.weight"), I, D, M, Mp, G(tl + "mlp.fc1.bias"))
+    dW(bw["dxb"], Lt["g"], G(tl + "mlp.fc2.weight"), D, I, M, Mp)
+    ops.gemm(ops.EPI_DQGELU_BF16, bw["dxb"], wT(tl + "mlp.fc2.weight", D, I), bw["du"], aux=Lt["u"], M=M, N=I, K=D)
+    dW(bw["du"], Lt["h2"], G(tl + "mlp.fc1.weight"), I, D, M, Mp, G(tl + "mlp.fc1.bias"))
     ops.gemm(ops.EPI_BIAS_BF16, bw["du"], wT(tl + "mlp.fc1.weight", I, D), bw["dh"], M=M, N=D, K=I)
-    ops.layernorm_bwd(bw["dh"], ws["x_mid"], ws["st2"], P_[tl + "layer_norm2.weight"], bw["dx"], bw["dxm"],
+    ops.layernorm_bwd(bw["dh"], Lt["x_mid"], Lt["st2"], P_[tl + "layer_norm2.weight"], bw["dx"], bw["dxm"],
                       G(tl + "layer_norm2.weight"), G(tl + "layer_norm2.bias"), M, D)
     # ---- trainable encoder layer: attention -----------------------------------------------------------------
     ops.cast_bf16(bw["dxm"], bw["dxb"])
     ops.colsum_f32(bw["dxm"], G(tl + "self_attn.out_proj.bias"), M, D)
-    dW(bw["dxb"], ws["att"], G(tl + "self_attn.out_proj.weight"), D, D, M, Mp)
+    dW(bw["dxb"], Lt["att"], G(tl + "self_attn.out_proj.weight"), D, D, M, Mp)
     woT = wT(tl + "self_attn.out_proj.weight", D, D)
     ops.gemm(ops.EPI_BIAS_BF16, bw["dxb"], woT, bw["datt"], M=M, N=D, K=D)
     ops.gemm(ops.EPI_TRANS_BF16, bw["dxb"], woT, bw["dattT"], M=M, N=D, K=D, Tp=Tp)
-    ops.attention_bwd(ws["qkv"], ws["qkvT"], bw["datt"], bw["dattT"], ws["att"], ws["lse"], bw["dvec"], bw["dqkv"], B, H, T, Tp,
+    ops.attention_bwd(Lt["qkv"], Lt["qkvT"], bw["datt"], bw["dattT"], Lt["att"], Lt["lse"], bw["dvec"], bw["dqkv"], B, H, T, Tp,
                       cfg.head_dim ** -0.5)
     o = model.flat_offsets[tl + "self_attn.q_proj.weight"]
     g_wqkv = model.flat_grad[o: o + 3 * D * D].view(3 * D, D)
     ob = model.flat_offsets[tl + "self_attn.q_proj.bias"]
     g_bqkv = model.flat_grad[ob: ob + 3 * D]
-    dW(bw["dqkv"], ws["h1"], g_wqkv, 3 * D, D, M, Mp, g_bqkv)
+    dW(bw["dqkv"], Lt["h1"], g_wqkv, 3 * D, D, M, Mp, g_bqkv)
     wqkv = model.flat_bf16[o: o + 3 * D * D].view(3 * D, D)
     wqkvT = bw["wT"][: 3 * D * D].view(D, 3 * D)
     ops.transpose_bf16(wqkv, wqkvT, 3 * D, D)
     ops.gemm(ops.EPI_BIAS_BF16, bw["dqkv"], wqkvT, bw["dh"], M=M, N=D, K=3 * D)
     # everything below layer_norm1 is frozen: only its affine parameters need gradients
-    ops.layernorm_bwd(bw["dh"], ws["x_in"], ws["st1"], P_[tl + "layer_norm1.weight"], None, None,
+    ops.layernorm_bwd(bw["dh"], Lt["x_in"], Lt["st1"], P_[tl + "layer_norm1.weight"], None, None,
                       G(tl + "layer_norm1.weight"), G(tl + "layer_norm1.bias"), M, D)

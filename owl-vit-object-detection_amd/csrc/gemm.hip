@@ -372,20 +372,51 @@ extern "C" int owl_slab_reduce(void* stream, const float* slabs, float* out, int
     return owl_slab_reduce_impl((hipStream_t)stream, slabs, out, n, slab_stride, nsplit, accumulate);
 }
 
+// im2row for patch sizes the fused loader cannot take (L/14: 14-pixel rows are 28 bytes, not 16-byte chunks):
+// patches[b*P + p, k] = image[b, c, py*ps + ky, px*ps + kx], k = (c*ps + ky)*ps + kx, zero-padded to Kpad.
+__global__ __launch_bounds__(256) void im2row_kernel(const bf16_t* __restrict__ img, bf16_t* __restrict__ out, int64_t B, int S, int ps,
+                                                     int G, int K, int Kpad) {
+    const int64_t row = blockIdx.x;                  // b*P + p
+    const int64_t P = (int64_t)G * G;
+    const int64_t b = row / P; const int pp = (int)(row - b * P);
+    const int py = pp / G, px = pp - py * G;
+    for (int k = threadIdx.x; k < Kpad; k += 256) {
+        bf16_t v = 0;
+        if (k < K) {
+            const int c = k / (ps * ps), rem = k - c * ps * ps, ky = rem / ps, kx = rem - ky * ps;
+            v = img[((b * 3 + c) * S + py * ps + ky) * (int64_t)S + px * ps + kx];
+        }
+        out[row * Kpad + k] = v;
+    }
+}
+
 // Patch-embed: X[b*Tp + 1 + p, :] = W_pe . vec(patch(b,p)) + pos[1+p]   (no bias; HF5:282-288,336-343)
+// Power-of-two patch sizes: im2row-free (the A loader gathers 16-byte runs of patch rows straight from the image).
+// Otherwise: `scratch` (bf16 [B*P (row-padded to 128), Kpad]) receives an explicit im2row and w_pe must be [D, Kpad]
+// with zero columns beyond 3*ps*ps; Kpad = 3*ps*ps rounded up to 64.
 extern "C" int owl_patch_embed_bf16(void* stream, const void* image_bf16, const void* w_pe, const float* pos,
-                                    float* x_out, int64_t B, int64_t S, int64_t ps, int64_t D, int64_t Tp) {
+                                    float* x_out, void* scratch, int64_t B, int64_t S, int64_t ps, int64_t D, int64_t Tp) {
     OWL_CHECK_ARG(image_bf16 && w_pe && pos && x_out, "owl_patch_embed_bf16: null pointer");
-    OWL_CHECK_ARG(ps >= 8 && (ps & (ps - 1)) == 0 && S % ps == 0,
-                  "owl_patch_embed_bf16: fused loader needs a power-of-two patch size >= 8 (got %lld)", (long long)ps);
+    OWL_CHECK_ARG(S % ps == 0, "owl_patch_embed_bf16: image side must be a multiple of the patch size");
     const int64_t G = S / ps, P = G * G, K = 3 * ps * ps;
-    OWL_CHECK_ARG(K % BK == 0 && D % 4 == 0 && Tp >= P + 1, "owl_patch_embed_bf16: K %% 64, D %% 4, Tp");
+    OWL_CHECK_ARG(D % 8 == 0 && Tp >= P + 1, "owl_patch_embed_bf16: D %% 8, Tp");
+    const bool fused = ps >= 8 && (ps & (ps - 1)) == 0 && K % BK == 0;
     GemmP p{};
-    p.A = (const bf16_t*)image_bf16; p.lda = 0; p.a_rows = B * P;
-    p.W = (const bf16_t*)w_pe; p.ldw = K; p.w_rows = D;
-    p.bias = nullptr; p.out = x_out; p.ldo = D; p.M = B * P; p.N = D; p.K = K; p.alpha = 1.f;
+    p.bias = nullptr; p.out = x_out; p.ldo = D; p.M = B * P; p.N = D; p.alpha = 1.f;
     p.Tp = Tp; p.P = P; p.G = G; p.ps = ps; p.S = S; p.pos = pos;
-    p.ps_log2 = 0; while ((1LL << p.ps_log2) < ps) p.ps_log2++;
-    p.kt_per_split = (int)(K / BK);
-    return launch<EPI_PATCH_F32>((hipStream_t)stream, p, 1);
+    p.W = (const bf16_t*)w_pe; p.w_rows = D; p.a_rows = B * P;
+    if (fused) {
+        p.A = (const bf16_t*)image_bf16; p.lda = 0; p.ldw = K; p.K = K;
+        p.ps_log2 = 0; while ((1LL << p.ps_log2) < ps) p.ps_log2++;
+        p.kt_per_split = (int)(K / BK);
+        return launch<EPI_PATCH_F32>((hipStream_t)stream, p, 1);
+    }
+    OWL_CHECK_ARG(scratch, "owl_patch_embed_bf16: patch size %lld needs the im2row scratch buffer", (long long)ps);
+    const int64_t Kpad = (K + BK - 1) / BK * BK;
+    hipLaunchKernelGGL(im2row_kernel, dim3((unsigned)(B * P)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)image_bf16, (bf16_t*)scratch,
+                       B, (int)S, (int)ps, (int)G, (int)K, (int)Kpad);
+    OWL_LAUNCH_CHECK();
+    p.A = (const bf16_t*)scratch; p.lda = Kpad; p.ldw = Kpad; p.K = Kpad;
+    p.kt_per_split = (int)(Kpad / BK);
+    return launch<EPI_PATCHM_F32>((hipStream_t)stream, p, 1);
 }

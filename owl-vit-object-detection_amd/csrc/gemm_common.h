@@ -16,6 +16,7 @@ enum {
     EPI_DGELU_BF16 = 9,  // out bf16 = acc * gelu_erf'(aux u)
     EPI_ACC_F32 = 10,    // out f32 += acc   (resid == out)
     EPI_SLAB_F32 = 11,   // split-K partial: out f32 [split][M][N] = alpha*acc   (reduced by owl_slab_reduce)
+    EPI_PATCHM_F32 = 12, // as EPI_PATCH_F32 but A is an explicit im2row matrix (patch sizes that are not 2^n, e.g. L/14)
 };
 
 struct GemmP {
@@ -91,7 +92,7 @@ __device__ __forceinline__ void epi_quad(const GemmP& p, int64_t orow, const flo
         *(float4*)((float*)p.out + orow * p.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
     } else if constexpr (EPI == EPI_SLAB_F32) {
         *(float4*)((float*)p.out + (int64_t)split * p.slab_stride + orow * p.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
-    } else if constexpr (EPI == EPI_PATCH_F32) {
+    } else if constexpr (EPI == EPI_PATCH_F32 || EPI == EPI_PATCHM_F32) {
         const float4 p4 = *(const float4*)(posrow + n);
         *(float4*)((float*)p.out + orow * p.ldo + n) = make_float4(v[0] + p4.x, v[1] + p4.y, v[2] + p4.z, v[3] + p4.w);
     } else if constexpr (EPI == EPI_ATOMIC_F32) {
@@ -136,7 +137,7 @@ __device__ __forceinline__ void epi_pass(const GemmP& p, const f32x16& t0, const
             if (m >= p.M || n >= p.N) continue;
             int64_t orow = m;
             const float* posrow = nullptr;
-            if constexpr (EPI == EPI_PATCH_F32) {
+            if constexpr (EPI == EPI_PATCH_F32 || EPI == EPI_PATCHM_F32) {
                 const int64_t b = m / p.P, pp = m - b * p.P;
                 orow = b * p.Tp + 1 + pp;
                 posrow = p.pos + (1 + pp) * p.N;

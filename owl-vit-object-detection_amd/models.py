@@ -108,7 +108,14 @@ class OwlViT(nn.Module):
         self._fz = {}
         P_ = self._byname
         with torch.no_grad():
-            self._fz["w_pe"] = P_["backbone.embeddings.patch_embedding.weight"].reshape(D, -1).to(torch.bfloat16).contiguous()
+            wpe = P_["backbone.embeddings.patch_embedding.weight"].reshape(D, -1)
+            ps = cfg.patch_size
+            self._patch_fused = ps >= 8 and (ps & (ps - 1)) == 0 and cfg.patch_k % 64 == 0
+            if not self._patch_fused:     # L/14: explicit im2row, K zero-padded to a multiple of 64
+                kpad = (cfg.patch_k + 63) // 64 * 64
+                wpe = torch.cat([wpe, torch.zeros(D, kpad - cfg.patch_k, device=wpe.device)], 1)
+            self._patch_kpad = wpe.shape[1]
+            self._fz["w_pe"] = wpe.to(torch.bfloat16).contiguous()
             for i in range(cfg.layers):
                 if i == cfg.trainable_layer():
                     continue
@@ -118,6 +125,11 @@ class OwlViT(nn.Module):
                 self._fz[f"{i}.wo"] = P_[pre + "self_attn.out_proj.weight"].to(torch.bfloat16).contiguous()
                 self._fz[f"{i}.w1"] = P_[pre + "mlp.fc1.weight"].to(torch.bfloat16).contiguous()
                 self._fz[f"{i}.w2"] = P_[pre + "mlp.fc2.weight"].to(torch.bfloat16).contiguous()
+                if i > cfg.trainable_layer():
+                    # frozen layers ABOVE the trainable one (the literal "layers.11" rule on a deeper model, ref
+                    # src/models.py:175): the backward passes through them (dX only) -> static transposed copies
+                    for k in ("wqkv", "wo", "w1", "w2"):
+                        self._fz[f"{i}.{k}T"] = self._fz[f"{i}.{k}"].t().contiguous()
         self.box_bias = box_bias_table(cfg.grid).to(self.device_)
         self._ws = {}
         self._saved = None
@@ -173,9 +185,7 @@ class OwlViT(nn.Module):
             x=z(M, D, f32, dev), h=z(M, D, bf, dev), qkv=z(M, 3 * D, bf, dev),
             qkvT=torch.zeros(B * 3 * D * Tp + 256, dtype=bf, device=dev),   # [B][3D][Tp] (+ slack for tile over-read)
             att=z(M, D, bf, dev), g=z(M, I, bf, dev), d1=z(M, D, bf, dev), d2=z(M, D, bf, dev),
-            # trainable-layer saves
-            x_in=z(M, D, f32, dev), x_mid=z(M, D, f32, dev), h1=z(M, D, bf, dev), h2=z(M, D, bf, dev), u=z(M, I, bf, dev),
-            st1=torch.zeros(M, 2, device=dev), st2=torch.zeros(M, 2, device=dev), lse=torch.zeros(B, cfg.heads, Tp, device=dev),
+            im2row=None if self._patch_fused else z(Mh, self._patch_kpad, bf, dev),
             # heads
             cls_ln=torch.zeros(B, D, device=dev), feats=z(Mh, D, bf, dev), st_post=torch.zeros(M, 2, device=dev),
             st_pp=torch.zeros(Mh, 2, device=dev), hb0=z(Mh, D, bf, dev), ub0=z(Mh, D, bf, dev), hb1=z(Mh, D, bf, dev),
@@ -186,6 +196,24 @@ class OwlViT(nn.Module):
         )
         self._ws[B] = ws
         return ws
+
+    def _layer_ws(self, B: int, i: int):
+        """Saved activations of layer i (i >= trainable layer) for the backward; allocated once per batch size."""
+        key = ("layer", B, i)
+        if key in self._ws:
+            return self._ws[key]
+        cfg, dev = self.cfg, self.device_
+        D, I, Tp = cfg.hidden, cfg.mlp, cfg.tokens_padded
+        M = B * Tp
+        bf, f32 = torch.bfloat16, torch.float32
+        z = ops.zeros_rows
+        L = dict(x_in=z(M, D, f32, dev), x_mid=z(M, D, f32, dev), st1=torch.zeros(M, 2, device=dev), st2=torch.zeros(M, 2, device=dev),
+                 qkv=z(M, 3 * D, bf, dev), qkvT=torch.zeros(B * 3 * D * Tp + 256, dtype=bf, device=dev), att=z(M, D, bf, dev),
+                 lse=torch.zeros(B, cfg.heads, Tp, device=dev), u=z(M, I, bf, dev))
+        if i == cfg.trainable_layer():   # dW operands
+            L.update(h1=z(M, D, bf, dev), h2=z(M, D, bf, dev), g=z(M, I, bf, dev))
+        self._ws[key] = L
+        return L
 
     def refresh_compute_weights(self):
         """bf16 copies of the trainable tensors (one cast over the flat bucket)."""
@@ -213,7 +241,7 @@ class OwlViT(nn.Module):
 
         x = ws["x"]
         ops.patch_embed(img, self._fz["w_pe"], P_["backbone.embeddings.position_embedding.weight"], x, B, cfg.image_size,
-                        cfg.patch_size, D, Tp)
+                        cfg.patch_size, D, Tp, scratch=ws["im2row"])
         ops.cls_rows(x, P_["backbone.embeddings.class_embedding"], P_["backbone.embeddings.position_embedding.weight"], B, Tp, D)
         ops.layernorm(x, P_["backbone.pre_layernorm.weight"], P_["backbone.pre_layernorm.bias"], x, M, D, eps=cfg.ln_eps)
 
@@ -222,34 +250,41 @@ class OwlViT(nn.Module):
         d1, d2 = ws["d1"], ws["d2"]
         xs = x                  # residual stream BEFORE the pending MLP-branch delta is added
         pending = None          # bf16 output of the previous layer's fc2, not yet added to the residual stream
+        tl = cfg.trainable_layer()
         for i in range(cfg.layers):
             lw = self._layer_weights(i)
-            sv = save and i == cfg.trainable_layer()
-            h = ws["h1"] if sv else ws["h"]
+            sv = save and i >= tl          # the backward passes through this layer: keep its activations
+            full = sv and i == tl          # ... and, for the trainable layer, the dW operands too
+            Ls = self._layer_ws(B, i) if sv else None
+            h = Ls["h1"] if full else ws["h"]
             # Residual adds (HF5:500,507) live in the LayerNorm kernels: the GEMM in front of each emits a bf16
-            # delta through the fast deferred-store epilogue, and LN does x += delta while it normalises.
-            x_cur = ws["x_in"] if sv else xs
+            # delta through the fast wide-store epilogue, and LN does x += delta while it normalises.
+            x_cur = Ls["x_in"] if sv else xs
             if pending is None:
                 if sv:
                     x_cur.copy_(xs)
-                ops.layernorm(x_cur, lw["g1"], lw["be1"], h, M, D, ws["st1"] if sv else None, cfg.ln_eps)
+                ops.layernorm(x_cur, lw["g1"], lw["be1"], h, M, D, Ls["st1"] if sv else None, cfg.ln_eps)
             else:
-                ops.layernorm(xs, lw["g1"], lw["be1"], h, M, D, ws["st1"] if sv else None, cfg.ln_eps, delta=pending, x_out=x_cur)
-            if sv:   # row-major q,k,v and per-head transposed q,k,v (backward operands)
-                ops.gemm(ops.EPI_BIAS_BF16, h, lw["wqkv"], qkv, bias=lw["bqkv"], M=M, N=3 * D, K=D, ldo=3 * D)
-                ops.gemm(ops.EPI_TRANS_BF16, h, lw["wqkv"], qkvT, bias=lw["bqkv"], M=M, N=3 * D, K=D, Tp=Tp)
-                vt, vt_stride = qkvT[2 * D * Tp:], 3 * D * Tp
+                ops.layernorm(xs, lw["g1"], lw["be1"], h, M, D, Ls["st1"] if sv else None, cfg.ln_eps, delta=pending, x_out=x_cur)
+            if sv:   # row-major q,k,v and per-head transposed q,k,v (attention-backward operands)
+                qkv_l, qkvT_l = Ls["qkv"], Ls["qkvT"]
+                ops.gemm(ops.EPI_BIAS_BF16, h, lw["wqkv"], qkv_l, bias=lw["bqkv"], M=M, N=3 * D, K=D, ldo=3 * D)
+                ops.gemm(ops.EPI_TRANS_BF16, h, lw["wqkv"], qkvT_l, bias=lw["bqkv"], M=M, N=3 * D, K=D, Tp=Tp)
+                vt, vt_stride = qkvT_l[2 * D * Tp:], 3 * D * Tp
             else:    # row-major q,k ; V only transposed
+                qkv_l = qkv
                 ops.gemm(ops.EPI_BIAS_BF16, h, lw["wqkv"], qkv, bias=lw["bqkv"], M=M, N=2 * D, K=D, ldo=3 * D, w_rows=2 * D)
                 ops.gemm(ops.EPI_TRANS_BF16, h, lw["wqkv"][2 * D:], qkvT, bias=lw["bqkv"][2 * D:], M=M, N=D, K=D, Tp=Tp, w_rows=D)
                 vt, vt_stride = qkvT, D * Tp
-            ops.attention_fwd(qkv, qkv[:, D:], 3 * D, vt, vt_stride, att, D, ws["lse"] if sv else None, B, H, T, Tp, scale)
-            ops.gemm(ops.EPI_BIAS_BF16, att, lw["wo"], d1, bias=lw["bo"], M=M, N=D, K=D)
-            x_mid = ws["x_mid"] if sv else x_cur
-            h2 = ws["h2"] if sv else ws["h"]
-            ops.layernorm(x_cur, lw["g2"], lw["be2"], h2, M, D, ws["st2"] if sv else None, cfg.ln_eps, delta=d1, x_out=x_mid)
-            ops.gemm(ops.EPI_QGELU_BF16, h2, lw["w1"], g, bias=lw["b1"], aux=ws["u"] if sv else None, M=M, N=I, K=D)
-            ops.gemm(ops.EPI_BIAS_BF16, g, lw["w2"], d2, bias=lw["b2"], M=M, N=D, K=I)
+            att_l = Ls["att"] if sv else att
+            ops.attention_fwd(qkv_l, qkv_l[:, D:], 3 * D, vt, vt_stride, att_l, D, Ls["lse"] if sv else None, B, H, T, Tp, scale)
+            ops.gemm(ops.EPI_BIAS_BF16, att_l, lw["wo"], d1, bias=lw["bo"], M=M, N=D, K=D)
+            x_mid = Ls["x_mid"] if sv else x_cur
+            h2 = Ls["h2"] if full else ws["h"]
+            ops.layernorm(x_cur, lw["g2"], lw["be2"], h2, M, D, Ls["st2"] if sv else None, cfg.ln_eps, delta=d1, x_out=x_mid)
+            g_l = Ls["g"] if full else g
+            ops.gemm(ops.EPI_QGELU_BF16, h2, lw["w1"], g_l, bias=lw["b1"], aux=Ls["u"] if sv else None, M=M, N=I, K=D)
+            ops.gemm(ops.EPI_BIAS_BF16, g_l, lw["w2"], d2, bias=lw["b2"], M=M, N=D, K=I)
             pending, xs = d2, x_mid
 
         # ---- final residual add + post_layernorm (all tokens) * class token -> post_post_layernorm

@@ -104,7 +104,7 @@ def _grad_report(grads, ref, tag):
     return worst, worst_cos
 
 
-@pytest.mark.parametrize("cname,B", [("tiny", 1), ("tiny", 3), ("small", 2), ("owlvit-base-patch16", 1)])
+@pytest.mark.parametrize("cname,B", [("tiny", 1), ("tiny", 3), ("small", 2), ("tiny-l14", 2), ("owlvit-base-patch16", 1), ("owlvit-large-patch14", 1)])
 def test_backward_chain_matches_oracle_given_same_upstream(cname, B):
     """Backward kernels in isolation: identical upstream (d_boxes, d_sims) into the HIP backward and into
     the oracle's autograd -- removes the loss's 1/|sim| amplification of bf16 forward noise."""
@@ -160,9 +160,11 @@ def test_train_step_matches_oracle(cname, B):
     assert worst_cos > 0.99
 
 
-def test_train_step_matches_reference_fixture_f1(golden_dir):
-    cfg = get_config("tiny")
-    g = np.load(os.path.join(golden_dir, "f1_tiny.npz"))
+@pytest.mark.parametrize("cname", ["tiny", "tiny-l14"])
+def test_train_step_matches_reference_fixture_f1(golden_dir, cname):
+    """tiny-l14 has two frozen layers ABOVE the trainable layer 11 -> exercises the dX-only backward (L/14's case)."""
+    cfg = get_config(cname)
+    g = np.load(os.path.join(golden_dir, f"f1_{cname}.npz"))
     img = synth.make_images(cfg, 1)
     labels, boxes = synth.make_targets(cfg, 1, max_boxes=6)
     model, crit, lg, grads, pb, ps = _step_hip(cfg, weights.make_weights(cfg), img, labels, boxes, g["scales"])
@@ -170,7 +172,7 @@ def test_train_step_matches_reference_fixture_f1(golden_dir):
     for k in LOSS_KEYS:
         assert lg[k] == pytest.approx(float(g[k]), rel=2e-2, abs=1e-2), k
     ref = {k[5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("grad/")}
-    worst, worst_cos = _grad_report(grads, ref, "tiny vs reference fixture")
+    worst, worst_cos = _grad_report(grads, ref, f"{cname} vs reference fixture")
     assert worst_cos > 0.99
 
 
@@ -201,3 +203,35 @@ def test_train_step_b16_matches_reference_fixture_f2(golden_dir):
         cos = float((gr.reshape(-1)[:64] * head).sum() / (gr.reshape(-1)[:64].norm() * head.norm() + 1e-20))
         assert cos > 0.9, (n, cos)    # 64-element sample of an end-to-end gradient (loss-amplified bf16 noise);
                                       # the strict all-element check is test_backward_chain_...[owlvit-base-patch16-1]
+
+
+def test_l14_train_step_matches_reference_fixture_f4(golden_dir):
+    """BASELINE configs[4] architecture (owlvit-large-patch14, 840x840) at batch 1: patch 14 (im2row fallback),
+    T = 3601, and the literal `layers.11` rule on 24 layers -> backward through 12 frozen layers."""
+    path = os.path.join(golden_dir, "f4_l14.npz")
+    if not os.path.exists(path):
+        pytest.skip("f4 fixture missing")
+    cfg = get_config("owlvit-large-patch14")
+    g = np.load(path)
+    img = synth.make_images(cfg, 1)
+    labels, boxes = synth.make_targets(cfg, 1, max_boxes=16)
+    model, crit, lg, grads, pb, ps = _step_hip(cfg, weights.make_weights(cfg), img, labels, boxes, g["scales"])
+    eb, es = _maxerr(pb, torch.from_numpy(g["pred_boxes"])), _maxerr(ps, torch.from_numpy(g["pred_sims"]))
+    same = float((crit.last["target_classes"][0].cpu() == torch.from_numpy(g["target_classes"])).float().mean())
+    print(f"L/14 vs reference fixture: max|d boxes|={eb:.3e} max|d sims|={es:.3e}; losses", lg,
+          "ref", {k: float(g[k]) for k in LOSS_KEYS}, "target agreement", same)
+    assert eb < 1e-2 and es < 1e-2
+    for k in LOSS_KEYS:
+        assert lg[k] == pytest.approx(float(g[k]), rel=2e-2, abs=1e-2), k
+    # sign(pred - tgt) in the L1 term and the min/max selections in GIoU are discontinuous: a matched coordinate within
+    # bf16-forward noise of its target coordinate legitimately flips them relative to the fp32 reference (here row 610:
+    # x1 = 0.1997 vs 0.1996), and that single row then dominates the box-head gradient norms.
+    pi, ti = g["pred_idx"], g["tgt_idx"]
+    near_tie = bool((np.abs(g["pred_boxes"][0][pi] - boxes[0][ti]) < 3e-3).any())
+    big = max(float(g["gradnorm/" + n]) for n in grads)
+    for n, gr in grads.items():
+        ref_norm = float(g["gradnorm/" + n])
+        if ref_norm < 1e-2 * big or (near_tie and n.startswith("box_head")):
+            continue
+        assert float(gr.double().norm()) == pytest.approx(ref_norm, rel=0.3), n
+    print("near-tie between a matched prediction and its target:", near_tie)
