@@ -402,40 +402,68 @@ extern "C" int owl_box_final_bwd(void* stream, const float* dboxes, const float*
 // ---------------------------------------------------------------------------------------------------
 // transpose bf16 [R,C] -> [C,R] with optional column sums (bias gradient) in the same pass.
 // ---------------------------------------------------------------------------------------------------
+// 64x64 tiles, 16-byte global accesses on both sides: a thread loads 8 consecutive columns of a row (uint4), the tile
+// goes through LDS (row stride 72 halves = 144 B keeps 16-byte alignment and spreads banks), and is written back as 8
+// consecutive rows (= 8 consecutive output columns) per thread.  R must be a multiple of 8 for the vector store path
+// (token counts are; the scalar tail handles the rest), C a multiple of 8.
 __global__ __launch_bounds__(256) void transpose_colsum_kernel(const bf16_t* __restrict__ in, int64_t ld_in, bf16_t* __restrict__ out,
                                                                int64_t ld_out, float* colsum, int64_t R, int64_t C, int row_tiles) {
-    __shared__ bf16_t tile[64][66];
-    __shared__ float cs[4][64];
+    __shared__ __attribute__((aligned(16))) bf16_t tile[64][72];
+    __shared__ float cs[32][65];
     const int64_t c0 = (int64_t)blockIdx.x * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    float acc = 0.f;
+    const int t = threadIdx.x;
+    const int lr = t >> 3, lc = (t & 7) * 8;          // load: rows lr, lr+32 ; columns lc..lc+7
+    const int sc = t >> 3, sr = (t & 7) * 8;          // store: output rows (= input cols) sc, sc+32 ; input rows sr..sr+7
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int rt = 0; rt < row_tiles; rt++) {
         const int64_t r0 = ((int64_t)blockIdx.y * row_tiles + rt) * 64;
         if (r0 >= R) break;
         __syncthreads();
-        for (int i = ty; i < 64; i += 4) {
-            const int64_t r = r0 + i, c = c0 + tx;
-            const bf16_t v = (r < R && c < C) ? in[r * ld_in + c] : (bf16_t)0;
-            tile[i][tx] = v;
-            acc += bf2f(v);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int64_t r = r0 + lr + 32 * h, c = c0 + lc;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (r < R && c + 8 <= C) v = *(const uint4*)(in + r * ld_in + c);
+            else if (r < R) { bf16_t tmp[8] = {0, 0, 0, 0, 0, 0, 0, 0}; for (int e = 0; e < 8; e++) if (c + e < C) tmp[e] = in[r * ld_in + c + e]; v = *(uint4*)tmp; }
+            *(uint4*)&tile[lr + 32 * h][lc] = v;
+            if (colsum) {
+                const bf16_t* pv = (const bf16_t*)&v;
+#pragma unroll
+                for (int e = 0; e < 8; e++) acc[e] += bf2f(pv[e]);
+            }
         }
         __syncthreads();
-        if (out)
-            for (int i = ty; i < 64; i += 4) {
-                const int64_t c = c0 + i, r = r0 + tx;
-                if (c < C && r < R) out[c * ld_out + r] = tile[tx][i];
+        if (out) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int col = sc + 32 * h;                 // input column = output row
+                const int64_t oc = c0 + col, orow0 = r0 + sr;
+                if (oc >= C) continue;
+                bf16_t tmp[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) tmp[e] = tile[sr + e][col];
+                if (orow0 + 8 <= R) *(uint4*)(out + oc * ld_out + orow0) = *(uint4*)tmp;
+                else for (int e = 0; e < 8; e++) if (orow0 + e < R) out[oc * ld_out + orow0 + e] = tmp[e];
             }
+        }
     }
     if (colsum) {
-        cs[ty][tx] = acc;
         __syncthreads();
-        if (ty == 0 && c0 + tx < C) atomicAdd(colsum + c0 + tx, cs[0][tx] + cs[1][tx] + cs[2][tx] + cs[3][tx]);
+#pragma unroll
+        for (int e = 0; e < 8; e++) cs[lr][lc + e] = acc[e];
+        __syncthreads();
+        if (t < 64 && c0 + t < C) {
+            float s = 0.f;
+            for (int k = 0; k < 32; k++) s += cs[k][t];
+            atomicAdd(colsum + c0 + t, s);
+        }
     }
 }
 
 extern "C" int owl_transpose_colsum_bf16(void* stream, const void* in, int64_t ld_in, void* out_t, int64_t ld_out, float* colsum,
                                          int64_t R, int64_t C) {
     OWL_CHECK_ARG(in && (out_t || colsum) && R > 0 && C > 0, "owl_transpose_colsum_bf16: bad args");
+    OWL_CHECK_ARG(ld_in % 8 == 0 && (!out_t || ld_out % 8 == 0), "owl_transpose_colsum_bf16: leading dimensions must be multiples of 8");
     const int row_tiles = 8;
     dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + 64 * row_tiles - 1) / (64 * row_tiles)));
     hipLaunchKernelGGL(transpose_colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, ld_in, (bf16_t*)out_t, ld_out, colsum, R, C, row_tiles);

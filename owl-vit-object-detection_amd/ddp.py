@@ -20,20 +20,22 @@ def init_from_env(backend: str = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("OWL_FORCE_DIST", "0") == "1"      # exercise the RCCL path with a single rank (testing)
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 
 
 def allreduce_flat(flat_grad: torch.Tensor, group=None) -> torch.Tensor:
     """SUM all-reduce of the flat gradient bucket, in place (single collective per step)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or os.environ.get("OWL_FORCE_DIST", "0") == "1"):
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
     return flat_grad
 

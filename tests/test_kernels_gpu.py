@@ -271,3 +271,18 @@ def test_cast_and_transpose():
     t = torch.zeros(136, 200, dtype=torch.bfloat16, device=DEV)
     ops.transpose_bf16(a, t, 200, 136)
     assert torch.equal(t, a.t().contiguous())
+
+
+@pytest.mark.parametrize("R,C", [(304, 136), (2312, 768), (200, 64), (1000, 3072)])
+def test_transpose_colsum(R, C):
+    a = ops.zeros_rows(R, C, torch.bfloat16, DEV); a[:R] = rnd(R, C).bfloat16()
+    Rp = ops.pad_rows(R)
+    t = torch.zeros(C, Rp, dtype=torch.bfloat16, device=DEV)
+    cs = torch.ones(C, device=DEV)
+    ops.transpose_colsum(a, t, cs, R, C)
+    assert torch.equal(t[:, :R], a[:R].t())
+    assert float(t[:, R:].abs().max()) == 0.0 if Rp > R else True
+    report("colsum", cs, 1.0 + a[:R].float().sum(0), 2e-2, 1e-3)
+    cs2 = torch.zeros(C, device=DEV)
+    ops.transpose_colsum(a, None, cs2, R, C)          # column sums only
+    report("colsum only", cs2, a[:R].float().sum(0), 2e-2, 1e-3)
