@@ -24,8 +24,9 @@ def box_convert(boxes: torch.Tensor, in_fmt: str, out_fmt: str) -> torch.Tensor:
 def scale_bounding_box(boxes: torch.Tensor, imwidth, imheight, mode: str) -> torch.Tensor:
     """ref src/util.py:83-93: mode "down" divides x by width and y by height, "up" multiplies."""
     assert mode in ("down", "up")
-    w = torch.as_tensor(imwidth, dtype=boxes.dtype, device=boxes.device).reshape(-1, 1)
-    h = torch.as_tensor(imheight, dtype=boxes.dtype, device=boxes.device).reshape(-1, 1)
+    shape = (-1,) + (1,) * (boxes.dim() - 1)          # per-image scalars broadcast over [n, coord]
+    w = torch.as_tensor(imwidth, dtype=boxes.dtype, device=boxes.device).reshape(shape)
+    h = torch.as_tensor(imheight, dtype=boxes.dtype, device=boxes.device).reshape(shape)
     out = boxes.clone()
     if mode == "down":
         out[..., 0::2] = out[..., 0::2] / w
