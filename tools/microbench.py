@@ -36,18 +36,12 @@ def bench_attn(B, H, T):
     print(f"attn B={B} H={H} T={T}: {t*1e3:.3f} ms  {fl/t/1e12:.1f} TF/s", flush=True)
 
 if __name__ == "__main__":
-    from owl_vit_object_detection_amd import _lib
     B = 32; Tp = 2312; M = B*Tp
-    bench_attn(32, 12, 2305)
-    bench_attn(32, 12, 2305)
-    bench_attn(8, 12, 2305)
-    _lib.call("owl_gemm_set_tile", 0)
-    sys.exit(0)
     bench_gemm(M, 768, 768)
-    bench_gemm(M, 2304, 768)
+    bench_gemm(M, 1536, 768)
     bench_gemm(M, 3072, 768, ops.EPI_QGELU_BF16)
+    bench_gemm(M, 768, 3072)
     bench_gemm(M, 768, 3072, ops.EPI_RESID_F32)
-    bench_gemm(M, 768, 768, ops.EPI_RESID_F32)
     bench_gemm(8192, 8192, 8192)
     bench_attn(32, 12, 2305)
     bench_attn(8, 12, 2305)
