@@ -103,6 +103,16 @@ int owl_spread_labels(void* stream, const float* boxes, int64_t* target_classes,
 int owl_push_pull_loss(void* stream, const float* sims, const float* boxes, const int64_t* target_classes, const float* scales, const float* tgt_boxes, const int64_t* pred_idx, const int64_t* tgt_idx, const int* counts, float* per_image, float* losses, float* dsims, float* dl1, float* dgiou, int64_t B, int64_t P, int64_t C, int64_t Nmax, int64_t bg);
 int owl_push_pull_loss_bwd(void* stream, const float* g4, const int64_t* target_classes, const float* dsims, const float* dl1, const float* dgiou, float* out_sims, float* out_boxes, int64_t B, int64_t P, int64_t C, int64_t bg);
 
+/* ---- inference post-process, fully on device (ref src/models.py:122-146 PostProcess.__call__; top-k prefix = ref
+ * main.py:114-117).  Per image: score = max_c sims, class = first arg-max, keep score > conf_thr, class-aware NMS
+ * (torchvision.ops.batched_nms semantics: same class, IoU > iou_thr, lower score suppressed), results ordered by
+ * descending score (ties: ascending patch index), at most max_out per image.
+ * boxes [B,P,4] f32 xyxy, sims [B,P,C] f32 -> out_boxes [B,max_out,4], out_scores [B,max_out], out_classes [B,max_out] i64,
+ * out_patch [B,max_out] i64 (source patch index), out_count [B] i32; entries beyond the count are left untouched.
+ * workspace: device scratch of owl_postprocess_workspace() bytes (16-byte aligned); `bytes` is a HOST pointer.     */
+int owl_postprocess_workspace(int64_t B, int64_t P, int64_t* bytes);
+int owl_postprocess(void* stream, const float* boxes, const float* sims, void* workspace, int64_t ws_bytes, float* out_boxes, float* out_scores, int64_t* out_classes, int64_t* out_patch, int* out_count, int64_t B, int64_t P, int64_t C, int64_t max_out, float conf_thr, float iou_thr);
+
 /* pairwise out3 = {iou, union, giou} each [N,M] (free functions box_iou / generalized_box_iou, ref src/matcher.py:8-44) */
 int owl_box_pairwise(void* stream, const float* boxes1, const float* boxes2, float* out3, int64_t N, int64_t M);
 

@@ -287,3 +287,61 @@ def adamw_step(p, g, m, v, step, lr=3e-6, wd=0.1, b1=0.9, b2=0.999, eps=1e-8):
     denom = v.sqrt() / math.sqrt(bc2) + eps
     p = p - (lr / bc1) * m / denom
     return p, m, v
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Inference post-process: ref src/models.py:122-146 + the eval loop's top-200
+# (ref main.py:114-117).  The suppression itself is ``torchvision.ops.batched_nms`` -- a third-party dependency that is
+# neither under /root/reference nor installed here (unpinned in the reference's requirements.txt), so its PUBLISHED
+# algorithm is restated: per class, visit boxes by descending score, keep a box iff no kept box of the same class has
+# IoU > thr with it (IoU = inter / (area_a + area_b - inter), plain f32, intersection sides clamped at 0); the result
+# is ordered by descending score.  For >4000 box coordinates torchvision takes its per-class ("vanilla") route, i.e.
+# raw coordinates with no class offset -- that is what is restated (the coordinate-offset route only differs by
+# rounding of the shifted coordinates).  Ties in score: lower patch index first (what a stable sort gives).
+# PARITY NOTE: the max/threshold/index/shape part is pinned by running the reference's PostProcess (fixture F6); the
+# NMS inside that run is this same restatement injected as the torchvision stub => "parity unpinned" for torchvision.
+# ---------------------------------------------------------------------------------------------------------------------
+def nms_class_aware(boxes: np.ndarray, scores: np.ndarray, classes: np.ndarray, iou_threshold: float) -> np.ndarray:
+    """Indices kept, ordered by descending score (ties: ascending index).  f32 arithmetic like torchvision's CPU kernel."""
+    boxes = np.asarray(boxes, np.float32)
+    scores = np.asarray(scores, np.float32)
+    n = boxes.shape[0]
+    order = np.lexsort((np.arange(n), -scores.astype(np.float64)))     # primary: score desc; secondary: index asc
+    x1, y1, x2, y2 = (boxes[:, k] for k in range(4))
+    areas = (x2 - x1) * (y2 - y1)
+    thr = np.float32(iou_threshold)
+    suppressed = np.zeros(n, bool)
+    keep = []
+    for a in range(n):
+        i = order[a]
+        if suppressed[i]:
+            continue
+        keep.append(i)
+        rest = order[a + 1:]
+        if rest.size == 0:
+            break
+        w = np.maximum(np.float32(0), np.minimum(x2[i], x2[rest]) - np.maximum(x1[i], x1[rest]))
+        h = np.maximum(np.float32(0), np.minimum(y2[i], y2[rest]) - np.maximum(y1[i], y1[rest]))
+        inter = w * h
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ovr = inter / (areas[i] + areas[rest] - inter)
+        hit = (ovr > thr) & (classes[rest] == classes[i])
+        suppressed[rest[hit]] = True
+    return np.asarray(keep, np.int64)
+
+
+def post_process(pred_boxes, pred_sims, confidence_threshold=0.75, iou_threshold=0.3, top_k=None):
+    """ref src/models.py:127-146 for ONE image ([P,4], [P,C]) -> (boxes [K,4], classes [K], scores [K], patch_idx [K]).
+
+    ``top_k`` = the eval loop's ``torch.topk(scores, min(200, K))`` (ref main.py:114-117); because the NMS result is
+    already score-descending this is a prefix."""
+    b = np.asarray(pred_boxes, np.float32)
+    s = np.asarray(pred_sims, np.float32)
+    scores = s.max(axis=1)
+    classes = s.argmax(axis=1)                  # first maximal class, like torch.max on CPU
+    sel = np.nonzero(scores > np.float32(confidence_threshold))[0]
+    keep = nms_class_aware(b[sel], scores[sel], classes[sel], iou_threshold)
+    idx = sel[keep]
+    if top_k is not None:
+        idx = idx[:top_k]
+    return b[idx], classes[idx].astype(np.int64), scores[idx], idx.astype(np.int64)

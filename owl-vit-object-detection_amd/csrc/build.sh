@@ -10,7 +10,7 @@ for f in *.hip; do
   o=build/${f%.hip}.o
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ common.h -nt "$o" ]; then
     extra=""
-    case "$f" in loss.hip) extra="-ffp-contract=off";; esac
+    case "$f" in loss.hip|postprocess.hip) extra="-ffp-contract=off";; esac
     hipcc $FLAGS $extra -c "$f" -o "$o" &
   fi
   objs="$objs $o"

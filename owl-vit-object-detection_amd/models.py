@@ -22,6 +22,7 @@ import torch.nn as nn
 
 from . import ops, weights as W
 from .config import OwlConfig, get_config
+from .postprocess import PostProcess  # noqa: F401  (the reference exports it from src/models.py:122)
 
 
 def box_bias_table(grid: int) -> torch.Tensor:

@@ -148,3 +148,27 @@ def colsum_f32(src, colsum, R, C):
 
 def attention_bwd(qkv, qkvT, dO, dOT, O, lse, dvec, dqkv, B, H, T, Tp, scale):
     _lib.call("owl_attention_bwd_bf16", stream(), qkv, qkvT, dO, dOT, O, lse, dvec, dqkv, B, H, T, Tp, float(scale))
+
+
+_pp_ws = {}
+
+
+def postprocess(boxes, sims, max_out, conf_thr, iou_thr):
+    """owl_postprocess: boxes [B,P,4] f32, sims [B,P,C] f32 -> (boxes [B,K,4], classes [B,K] i64 (-1 pad), scores [B,K]
+    (0 pad), patch [B,K] i64 (-1 pad), counts [B] i32) with K = max_out.  ref src/models.py:127-146."""
+    B, P, C = sims.shape
+    dev = sims.device
+    key = (B, P, dev)
+    if key not in _pp_ws:
+        nbytes = torch.zeros(1, dtype=torch.int64)
+        _lib.call("owl_postprocess_workspace", B, P, nbytes)
+        _pp_ws[key] = torch.empty(int(nbytes.item()), dtype=torch.uint8, device=dev)
+    ws = _pp_ws[key]
+    out_boxes = torch.zeros(B, max_out, 4, dtype=torch.float32, device=dev)
+    out_scores = torch.zeros(B, max_out, dtype=torch.float32, device=dev)
+    out_classes = torch.full((B, max_out), -1, dtype=torch.int64, device=dev)
+    out_patch = torch.full((B, max_out), -1, dtype=torch.int64, device=dev)
+    counts = torch.zeros(B, dtype=torch.int32, device=dev)
+    _lib.call("owl_postprocess", stream(), boxes, sims, ws, ws.numel(), out_boxes, out_scores, out_classes, out_patch, counts,
+              B, P, C, max_out, conf_thr, iou_thr)
+    return out_boxes, out_classes, out_scores, out_patch, counts

@@ -32,7 +32,39 @@ tv = types.ModuleType("torchvision")
 tv_ops = types.ModuleType("torchvision.ops")
 tv_ops.box_area = lambda b: (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
 tv_ops.nms = None
-tv_ops.batched_nms = None
+
+
+def _stub_batched_nms(boxes, scores, idxs, iou_threshold):
+    """torchvision.ops.batched_nms is absent here; its published algorithm (per class: greedy NMS by descending
+    score on raw coordinates, suppress IoU > thr; result ordered by descending score) restated in plain torch so
+    that the reference's PostProcess (src/models.py:122-146) can run for fixture F6.  The NMS arithmetic in F6 is
+    therefore NOT torchvision's own ("parity unpinned" for that dependency); what F6 pins is everything the
+    reference itself does around it: the max / threshold / indexing / ordering / output shapes."""
+    n = boxes.shape[0]
+    keep_mask = torch.zeros(n, dtype=torch.bool)
+    area = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
+    for cls in torch.unique(idxs):
+        ids = torch.nonzero(idxs == cls).squeeze(1)
+        order = ids[torch.sort(scores[ids], descending=True, stable=True).indices]
+        alive = torch.ones(len(order), dtype=torch.bool)
+        for a in range(len(order)):
+            if not alive[a]:
+                continue
+            i = order[a]
+            keep_mask[i] = True
+            rest = order[a + 1:]
+            if len(rest) == 0:
+                break
+            w = (torch.minimum(boxes[i, 2], boxes[rest, 2]) - torch.maximum(boxes[i, 0], boxes[rest, 0])).clamp(min=0)
+            h = (torch.minimum(boxes[i, 3], boxes[rest, 3]) - torch.maximum(boxes[i, 1], boxes[rest, 1])).clamp(min=0)
+            inter = w * h
+            ovr = inter / (area[i] + area[rest] - inter)
+            alive[a + 1:] &= ~(ovr > iou_threshold)
+    keep = torch.nonzero(keep_mask).squeeze(1)
+    return keep[torch.sort(scores[keep], descending=True, stable=True).indices]
+
+
+tv_ops.batched_nms = _stub_batched_nms
 tv.ops = tv_ops
 sys.modules["torchvision"] = tv
 sys.modules["torchvision.ops"] = tv_ops
@@ -296,6 +328,47 @@ def f5():
         print("f5", name, {k: float(v) for k, v in losses.items()},
               "spread:", int((res[name + "/target_classes"] != C).sum()), "matched:", len(labels))
     np.savez_compressed(os.path.join(HERE, "f5_loss_cases.npz"), **res)
+
+
+def f6():
+    """Post-process cases through the reference's PostProcess (src/models.py:122-146) at its batch size of 1."""
+    from src.models import PostProcess as RefPostProcess
+    res = {}
+    cases = []
+    rng_ = np.random.default_rng(77)
+
+    def synth_case(P, C, cluster):
+        if cluster:
+            centers = rng_.random((8, 2)).astype(np.float32) * 0.6 + 0.1
+            c = centers[rng_.integers(0, 8, P)] + rng_.normal(0, 0.01, (P, 2)).astype(np.float32)
+            wh = np.float32(0.2) + rng_.normal(0, 0.01, (P, 2)).astype(np.float32)
+        else:
+            c = rng_.random((P, 2)).astype(np.float32) * 0.7
+            wh = rng_.random((P, 2)).astype(np.float32) * 0.3 + np.float32(0.02)
+        boxes = np.concatenate([c, c + wh], 1).astype(np.float32)
+        sims = ((rng_.random((P, C)).astype(np.float32) * 2 - 1) * np.float32(0.6)).astype(np.float32)
+        return boxes, sims
+
+    cases.append(synth_case(576, 10, False) + (0.01, 0.6))       # config.yaml:13-14 thresholds
+    cases.append(synth_case(2304, 10, True) + (0.3, 0.45))
+    cases.append(synth_case(2304, 10, False) + (0.01, 0.6))
+    cases.append(synth_case(144, 4, True) + (0.75, 0.3))         # the class defaults (models.py:123): nothing passes
+    # a real model output (tiny config through the reference model)
+    cfg = get_config("tiny")
+    model, _ = build_reference_model(cfg)
+    model.eval()
+    with torch.no_grad():
+        pb, _, ps, _ = model(torch.from_numpy(synth.make_images(cfg, 1, 3)))
+    cases.append((pb[0].numpy().copy(), ps[0].numpy().copy(), 0.01, 0.6))
+    for k, (boxes, sims, conf, iou) in enumerate(cases):
+        pp = RefPostProcess(confidence_threshold=conf, iou_threshold=iou)
+        ob, oc, os_ = pp(torch.from_numpy(boxes)[None].clone(), torch.from_numpy(sims)[None].clone())
+        res[f"boxes_{k}"] = boxes; res[f"sims_{k}"] = sims
+        res[f"conf_{k}"] = np.float32(conf); res[f"iou_{k}"] = np.float32(iou)
+        res[f"out_boxes_{k}"] = ob.numpy(); res[f"out_classes_{k}"] = oc.numpy(); res[f"out_scores_{k}"] = os_.numpy()
+        print("f6 case", k, "kept", ob.shape[1], "of", boxes.shape[0])
+    res["n_cases"] = np.int64(len(cases))
+    np.savez_compressed(os.path.join(HERE, "f6_postprocess.npz"), **res)
 
 
 def lsap():

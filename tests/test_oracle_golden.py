@@ -165,3 +165,14 @@ def test_trainable_set_matches_freeze_rule():
     w = weights.param_shapes(cfg)
     assert sorted(O.trainable_names(w)) == sorted(n for n in w if weights.is_trainable(n))
     assert len(O.trainable_names(w)) == 29
+
+
+def test_postprocess_oracle_vs_reference_f6(golden_dir):
+    """oracle.post_process vs the reference's PostProcess outputs (ref src/models.py:122-146), fixture F6."""
+    z = np.load(os.path.join(golden_dir, "f6_postprocess.npz"))
+    for k in range(int(z["n_cases"])):
+        eb, ec, es, _ = O.post_process(z[f"boxes_{k}"], z[f"sims_{k}"], float(z[f"conf_{k}"]), float(z[f"iou_{k}"]))
+        assert z[f"out_boxes_{k}"].shape == (1, len(es), 4) and z[f"out_classes_{k}"].shape == (1, len(es))
+        assert np.array_equal(ec, z[f"out_classes_{k}"][0])
+        assert np.array_equal(es, z[f"out_scores_{k}"][0])
+        assert np.array_equal(eb, z[f"out_boxes_{k}"][0])
