@@ -113,6 +113,14 @@ int owl_push_pull_loss_bwd(void* stream, const float* g4, const int64_t* target_
 int owl_postprocess_workspace(int64_t B, int64_t P, int64_t* bytes);
 int owl_postprocess(void* stream, const float* boxes, const float* sims, void* workspace, int64_t ws_bytes, float* out_boxes, float* out_scores, int64_t* out_classes, int64_t* out_patch, int* out_count, int64_t B, int64_t P, int64_t C, int64_t max_out, float conf_thr, float iou_thr);
 
+/* ---- device input pipeline (ref src/dataset.py:69-71: HF OwlViTImageProcessor = PIL bicubic resize -> x(1/255) ->
+ * (x-mean)/std).  owl_bicubic_coeffs is HOST-side (all pointers host): Pillow's Resample.c tap tables for one axis,
+ * bounds[2*out] = {first tap, tap count}, kk[out*ksize] 22-bit fixed point; kk_capacity in ints; ksize returned.
+ * owl_preprocess_u8 (device pointers): src RGB u8 [H,W,3] -> horizontal pass into tmp u8 [H,out_w,3] -> vertical pass
+ * -> lut[3][256] (the reference's rescale+normalize value of each u8 level) -> out [3,out_h,out_w] f32 or bf16.      */
+int owl_bicubic_coeffs(int64_t in_size, int64_t out_size, int* bounds, int* kk, int64_t kk_capacity, int* ksize_out);
+int owl_preprocess_u8(void* stream, const unsigned char* src_hwc, int64_t H, int64_t W, const int* bounds_x, const int* kk_x, int64_t ksize_x, const int* bounds_y, const int* kk_y, int64_t ksize_y, unsigned char* tmp, const float* lut, void* out, int out_bf16, int64_t out_h, int64_t out_w);
+
 /* pairwise out3 = {iou, union, giou} each [N,M] (free functions box_iou / generalized_box_iou, ref src/matcher.py:8-44) */
 int owl_box_pairwise(void* stream, const float* boxes1, const float* boxes2, float* out3, int64_t N, int64_t M);
 

@@ -345,3 +345,107 @@ def post_process(pred_boxes, pred_sims, confidence_threshold=0.75, iou_threshold
     if top_k is not None:
         idx = idx[:top_k]
     return b[idx], classes[idx].astype(np.int64), scores[idx], idx.astype(np.int64)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Input pipeline: ref src/dataset.py:69-71 ``image_processor(images=image,
+# return_tensors="pt")["pixel_values"]`` = HF OwlViTImageProcessor (PIL backend): PIL bicubic resize of the u8 RGB image
+# to SxS (no crop) -> f32(f64(u8) * (1/255)) -> (x - mean) / std in f32 (transformers image_transforms.rescale /
+# normalize).  Pillow (third-party, not under /root/reference; 12.2.0 here) owns the resize arithmetic; its published
+# algorithm (src/libImaging/Resample.c: precompute_coeffs, normalize_coeffs_8bpc, ImagingResampleHorizontal_8bpc /
+# Vertical_8bpc) is restated: f64 filter weights normalised per output pixel, converted to 22-bit fixed point, a
+# horizontal pass rounded/clamped to u8, then a vertical pass.  Pinned against PIL + the HF processor themselves by
+# tests/golden/make_golden.py f7 (run in the build container) and against PIL directly in tests when it is importable.
+# ---------------------------------------------------------------------------------------------------------------------
+_PIL_PRECISION_BITS = 32 - 8 - 2
+
+
+def _pil_bicubic_filter(x: float) -> float:
+    a = -0.5
+    if x < 0.0:
+        x = -x
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+def pil_bicubic_coeffs(in_size: int, out_size: int):
+    """Resample.c precompute_coeffs + normalize_coeffs_8bpc for the full-image box -> (bounds [out,2] i32 = (first tap,
+    tap count), kk [out,ksize] i32 fixed-point weights, ksize)."""
+    scale = filterscale = float(in_size) / out_size
+    if filterscale < 1.0:
+        filterscale = 1.0
+    support = 2.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), np.int32)
+    kk = np.zeros((out_size, ksize), np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)          # C (int) cast truncates toward zero
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        w = [_pil_bicubic_filter((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ww = 0.0
+        for v in w:
+            ww += v
+        for x in range(xmax):
+            v = w[x] / ww if ww != 0.0 else w[x]
+            kk[xx, x] = int(-0.5 + v * (1 << _PIL_PRECISION_BITS)) if v < 0 else int(0.5 + v * (1 << _PIL_PRECISION_BITS))
+        bounds[xx] = (xmin, xmax)
+    return bounds, kk, ksize
+
+
+def _pil_pass(img: np.ndarray, bounds: np.ndarray, kk: np.ndarray, axis: int) -> np.ndarray:
+    """One 8bpc resample pass along `axis` (0 = vertical, 1 = horizontal) of an [H,W,C] u8 image."""
+    n_in = img.shape[axis]
+    ksize = kk.shape[1]
+    idx = np.minimum(bounds[:, :1] + np.arange(ksize)[None, :], n_in - 1)       # [out, ksize]; padded taps have k = 0
+    src = img.astype(np.int64)
+    acc = np.full((img.shape[0] if axis == 1 else len(bounds), len(bounds) if axis == 1 else img.shape[1], img.shape[2]),
+                  1 << (_PIL_PRECISION_BITS - 1), np.int64)
+    for t in range(ksize):
+        if axis == 1:
+            acc += src[:, idx[:, t], :] * kk[None, :, t, None]
+        else:
+            acc += src[idx[:, t], :, :] * kk[:, t, None, None]
+    return np.clip(acc >> _PIL_PRECISION_BITS, 0, 255).astype(np.uint8)
+
+
+def pil_resize_bicubic_u8(img_hwc: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
+    """PIL ``Image.resize((out_w, out_h), BICUBIC)`` on an RGB u8 image: horizontal pass, then vertical pass."""
+    img = np.ascontiguousarray(img_hwc, dtype=np.uint8)
+    H, W = img.shape[:2]
+    if W != out_w:
+        bx, kx, _ = pil_bicubic_coeffs(W, out_w)
+        img = _pil_pass(img, bx, kx, axis=1)
+    if H != out_h:
+        by, ky, _ = pil_bicubic_coeffs(H, out_h)
+        img = _pil_pass(img, by, ky, axis=0)
+    return img
+
+
+CLIP_MEAN_HF = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD_HF = (0.26862954, 0.26130258, 0.27577711)
+
+
+def normalize_lut(mean=CLIP_MEAN_HF, std=CLIP_STD_HF) -> np.ndarray:
+    """[3,256] f32: the value HF's rescale(1/255) + normalize produce for each u8 level (transformers
+    image_transforms.py rescale: f64 multiply then f32 cast; normalize: f32 subtract / divide)."""
+    v = (np.arange(256, dtype=np.uint8).astype(np.float64) * (1 / 255)).astype(np.float32)
+    m = np.array(mean, dtype=np.float32)[:, None]
+    s = np.array(std, dtype=np.float32)[:, None]
+    return ((v[None, :] - m) / s).astype(np.float32)
+
+
+def preprocess_image(img_hwc: np.ndarray, size: int, mean=CLIP_MEAN_HF, std=CLIP_STD_HF) -> np.ndarray:
+    """ref src/dataset.py:69-71 for one RGB u8 image -> pixel_values [3,size,size] f32."""
+    r = pil_resize_bicubic_u8(img_hwc, size, size)
+    lut = normalize_lut(mean, std)
+    return np.stack([lut[c][r[:, :, c]] for c in range(3)], 0)

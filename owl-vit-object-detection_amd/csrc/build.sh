@@ -16,6 +16,6 @@ for f in *.hip; do
   objs="$objs $o"
 done
 wait
-g++ -O2 -fPIC -std=c++17 -c runtime.cpp -o build/runtime.o
+g++ -O2 -fPIC -std=c++17 -ffp-contract=off -c runtime.cpp -o build/runtime.o
 hipcc --offload-arch=${ARCH} -shared -fPIC -o ../libowlhip.so $objs build/runtime.o
 echo "built $(cd .. && pwd)/libowlhip.so"

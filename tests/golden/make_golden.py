@@ -371,6 +371,43 @@ def f6():
     np.savez_compressed(os.path.join(HERE, "f6_postprocess.npz"), **res)
 
 
+def f7():
+    """Input pipeline (ref src/dataset.py:69-71): PIL bicubic + the HF OwlViTImageProcessor on u8 RGB images.
+    Big cases are stored sub-sampled (every `stride`-th row/column) plus a checksum of the full resized image."""
+    from PIL import Image
+    from transformers import OwlViTImageProcessor
+    rng_ = np.random.default_rng(2024)
+    res = {}
+    cases = [(37, 53, 96, 1), (200, 333, 96, 1), (97, 131, 96, 1), (5, 7, 96, 1), (96, 96, 96, 1),
+             (480, 640, 768, 13), (1000, 1500, 768, 13), (427, 640, 840, 17)]
+    for k, (H, W, S, st) in enumerate(cases):
+        # smooth-ish content + noise so that both interpolation and clamping paths are exercised
+        yy, xx = np.mgrid[0:H, 0:W]
+        base = 127 + 120 * np.sin(xx / 9.0 + k)[..., None] * np.cos(yy / 7.0)[..., None] * np.ones(3)
+        img = np.clip(base + rng_.normal(0, 40, (H, W, 3)), 0, 255).astype(np.uint8)
+        if k % 2 == 0:
+            img = rng_.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        seeded = H * W > 50000
+        if seeded:      # big inputs are regenerated from the repo's counter-based RNG instead of being stored
+            from owl_vit_object_detection_amd import rng as crng
+            img = crng.randint(77, f"f7/{k}", H * W * 3, 256).reshape(H, W, 3).astype(np.uint8)
+        pil = Image.fromarray(img)
+        resized = np.asarray(pil.resize((S, S), resample=Image.BICUBIC))
+        ip = OwlViTImageProcessor(size={"height": S, "width": S})
+        pv = ip(images=pil, return_tensors="pt")["pixel_values"][0].numpy()
+        assert pv.shape == (3, S, S)
+        if seeded:
+            res[f"shape_{k}"] = np.array([H, W], np.int64)
+        else:
+            res[f"img_{k}"] = img
+        res[f"size_{k}"] = np.int64(S); res[f"stride_{k}"] = np.int64(st)
+        res[f"resized_{k}"] = resized[::st, ::st].copy(); res[f"resized_sum_{k}"] = np.int64(resized.astype(np.int64).sum())
+        res[f"pixel_values_{k}"] = pv[:, ::st, ::st].copy()
+        print("f7 case", k, (H, W, S), "mean", float(pv.mean()))
+    res["n_cases"] = np.int64(len(cases))
+    np.savez_compressed(os.path.join(HERE, "f7_preprocess.npz"), **res)
+
+
 def lsap():
     """Known-answer vectors from scipy (the reference's solver) for the C restatement."""
     from scipy.optimize import linear_sum_assignment
