@@ -121,6 +121,15 @@ int owl_postprocess(void* stream, const float* boxes, const float* sims, void* w
 int owl_bicubic_coeffs(int64_t in_size, int64_t out_size, int* bounds, int* kk, int64_t kk_capacity, int* ksize_out);
 int owl_preprocess_u8(void* stream, const unsigned char* src_hwc, int64_t H, int64_t W, const int* bounds_x, const int* kk_x, int64_t ksize_x, const int* bounds_y, const int* kk_y, int64_t ksize_y, unsigned char* tmp, const float* lut, void* out, int out_bf16, int64_t out_h, int64_t out_w);
 
+/* ---- query-bank initialisation: the CLIP-style text tower run once by ref src/models.py:155-169 (HF5:603-663, 945-970).
+ * Linear / LayerNorm layers reuse owl_gemm_nt_bf16 / owl_layernorm_fwd; these are the text-only pieces:
+ * x[n*S+t] = tok_emb[ids[n,t]] + pos_emb[t] (f32 [N*S,W]); causal softmax attention for S <= 64, dh = 64 on
+ * qkv bf16 [N*S,3W] -> out bf16 [N*S,W]; final LN of the EOS row (arg-max id) -> text_projection (f32 [Pdim,W], no bias)
+ * -> L2 normalise -> out f32 [N,Pdim].                                                                               */
+int owl_text_embed(void* stream, const int64_t* ids, const float* tok_emb, const float* pos_emb, float* x, int64_t N, int64_t S, int64_t W, int64_t vocab);
+int owl_causal_attention_small(void* stream, const void* qkv_bf16, void* out_bf16, int64_t N, int64_t S, int64_t heads, float scale);
+int owl_text_pool_project(void* stream, const float* x, const int64_t* ids, const float* gamma, const float* beta, const float* wproj, float* out, int64_t N, int64_t S, int64_t W, int64_t Pdim, float eps);
+
 /* pairwise out3 = {iou, union, giou} each [N,M] (free functions box_iou / generalized_box_iou, ref src/matcher.py:8-44) */
 int owl_box_pairwise(void* stream, const float* boxes1, const float* boxes2, float* out3, int64_t N, int64_t M);
 

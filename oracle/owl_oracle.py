@@ -449,3 +449,35 @@ def preprocess_image(img_hwc: np.ndarray, size: int, mean=CLIP_MEAN_HF, std=CLIP
     r = pil_resize_bicubic_u8(img_hwc, size, size)
     lut = normalize_lut(mean, std)
     return np.stack([lut[c][r[:, :, c]] for c in range(3)], 0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Query-bank initialisation: ref src/models.py:155-169 ``_model(**inputs).text_embeds``.
+# HF5:603-663 OwlViTTextTransformer (token + position embedding, pre-LN causal encoder with quick-GELU MLPs, final
+# LayerNorm, EOS pooling = arg-max token id) -> HF5:952 text_projection (no bias) -> HF5:958 L2 normalise.
+# Pinned by fixture F8 (HF itself, run in the build container, incl. the processor-style padding attention_mask).
+# ---------------------------------------------------------------------------------------------------------------------
+def text_forward(tc, w, input_ids) -> torch.Tensor:
+    """tc: TextConfig; w: name -> array (weights.text_param_shapes names); input_ids [N,S] -> text_embeds [N,proj] f32."""
+    ids = torch.as_tensor(np.asarray(input_ids), dtype=torch.int64)
+    N, S = ids.shape
+    g = {k: torch.as_tensor(np.asarray(v), dtype=torch.float32) for k, v in w.items()}
+    x = g["text_model.embeddings.token_embedding.weight"][ids] + g["text_model.embeddings.position_embedding.weight"][:S][None]
+    H, dh = tc.heads, tc.width // tc.heads
+    causal = torch.full((S, S), float("-inf")).triu(1)
+    for i in range(tc.layers):
+        pre = f"text_model.encoder.layers.{i}."
+        h = F.layer_norm(x, (tc.width,), g[pre + "layer_norm1.weight"], g[pre + "layer_norm1.bias"], tc.ln_eps)
+        q = F.linear(h, g[pre + "self_attn.q_proj.weight"], g[pre + "self_attn.q_proj.bias"]).view(N, S, H, dh).transpose(1, 2)
+        k = F.linear(h, g[pre + "self_attn.k_proj.weight"], g[pre + "self_attn.k_proj.bias"]).view(N, S, H, dh).transpose(1, 2)
+        v = F.linear(h, g[pre + "self_attn.v_proj.weight"], g[pre + "self_attn.v_proj.bias"]).view(N, S, H, dh).transpose(1, 2)
+        a = torch.softmax(q @ k.transpose(-1, -2) * dh ** -0.5 + causal, dim=-1) @ v
+        a = a.transpose(1, 2).reshape(N, S, tc.width)
+        x = x + F.linear(a, g[pre + "self_attn.out_proj.weight"], g[pre + "self_attn.out_proj.bias"])
+        h = F.layer_norm(x, (tc.width,), g[pre + "layer_norm2.weight"], g[pre + "layer_norm2.bias"], tc.ln_eps)
+        u = quick_gelu(F.linear(h, g[pre + "mlp.fc1.weight"], g[pre + "mlp.fc1.bias"]))
+        x = x + F.linear(u, g[pre + "mlp.fc2.weight"], g[pre + "mlp.fc2.bias"])
+    x = F.layer_norm(x, (tc.width,), g["text_model.final_layer_norm.weight"], g["text_model.final_layer_norm.bias"], tc.ln_eps)
+    pooled = x[torch.arange(N), ids.argmax(dim=-1)]
+    e = F.linear(pooled, g["text_projection.weight"])
+    return e / torch.linalg.norm(e, ord=2, dim=-1, keepdim=True)

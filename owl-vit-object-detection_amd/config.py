@@ -100,3 +100,32 @@ def get_config(name: str, **overrides) -> OwlConfig:
     name = name.replace("google/", "")
     cfg = CONFIGS[name]
     return cfg.replace(**overrides) if overrides else cfg
+
+
+@dataclass(frozen=True)
+class TextConfig:
+    """CLIP-style text tower used once to initialise the query bank (ref src/models.py:155-169; HF ``OwlViTTextConfig``
+    defaults for the base models, public ``google/owlvit-large-patch14`` values for L/14).  dh = width / heads = 64."""
+    name: str
+    width: int
+    heads: int
+    mlp: int
+    layers: int
+    proj_dim: int            # = OwlConfig.text_dim (query width); HF needs proj_dim == width (class head out_dim, HF5:1009)
+    vocab: int = 49408
+    max_pos: int = 16
+    ln_eps: float = 1e-5
+
+
+TEXT_CONFIGS = {
+    "owlvit-base-patch32": TextConfig("owlvit-base-text", 512, 8, 2048, 12, 512),
+    "owlvit-base-patch16": TextConfig("owlvit-base-text", 512, 8, 2048, 12, 512),
+    "owlvit-large-patch14": TextConfig("owlvit-large-text", 768, 12, 3072, 12, 768),
+    "tiny": TextConfig("tiny-text", 64, 1, 128, 3, 64, vocab=97, max_pos=16),
+    "tiny-l14": TextConfig("tiny-text", 64, 1, 128, 3, 64, vocab=97, max_pos=16),
+    "small": TextConfig("small-text", 128, 2, 256, 3, 128, vocab=97, max_pos=16),
+}
+
+
+def get_text_config(name: str) -> TextConfig:
+    return TEXT_CONFIGS[name.replace("google/", "")]

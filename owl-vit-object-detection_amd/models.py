@@ -321,14 +321,33 @@ class OwlViT(nn.Module):
         return (boxes, None, sims, None)
 
 
-def load_model(labelmap, device="cuda", arch: str = "owlvit-base-patch32", seed: int = 1234, state=None):
+def load_model(labelmap, device="cuda", arch: str = "owlvit-base-patch32", seed: int = 1234, state=None, *,
+               prompt_ids=None, text_state=None):
     """ref src/models.py:149-191.  The reference downloads `google/owlvit-base-patch32` and runs the
     CLIP text tower once to initialise the query bank; neither box has network access, so weights
     come from `state` (name -> array, reference parameter names) or, by default, the deterministic
     random set (weights.make_weights).  The freeze rule is applied by construction (trainable
-    tensors live in the flat bucket with requires_grad=True; everything else is frozen)."""
+    tensors live in the flat bucket with requires_grad=True; everything else is frozen).
+
+    `prompt_ids` ([3C, S] CLIP token ids of `[label, "a photo of "+label, "a "+label+" in an environment"]`
+    per class, class-major, ref models.py:155-159 -- tokenised by the caller's processor) switches on the
+    reference's query-bank initialisation: the text tower (text.TextTower; weights from `text_state`, HF names
+    `text_model.*` / `text_projection.weight`, or the deterministic random set) runs once on the device and its
+    L2-normalised `text_embeds` become `queries` (ref models.py:161-169)."""
     n_classes = len(labelmap)
     cfg = get_config(arch, n_classes=n_classes)
     if state is None:
         state = W.make_weights(cfg, seed)
+    if prompt_ids is not None:
+        from .config import get_text_config
+        from .text import TextTower
+        ids = np.asarray(prompt_ids.cpu() if torch.is_tensor(prompt_ids) else prompt_ids)
+        if ids.ndim == 3:                         # processor(text=[to_encode]) yields [1, 3C, S]
+            ids = ids[0]
+        if ids.shape[0] != cfg.queries:
+            raise ValueError(f"load_model: expected {cfg.queries} prompts (3 per class), got {ids.shape[0]}")
+        tower = TextTower(get_text_config(arch), text_state, device, seed)
+        state = OrderedDict(state)
+        state["queries"] = tower.query_bank(ids).cpu().numpy()
+        del tower
     return OwlViT(cfg, state, device)

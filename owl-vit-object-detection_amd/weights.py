@@ -105,3 +105,55 @@ def make_weights(cfg: OwlConfig, seed: int = 1234) -> "OrderedDict[str, np.ndarr
 
 def count_trainable(cfg: OwlConfig) -> int:
     return sum(int(np.prod(s)) for n, s in param_shapes(cfg).items() if is_trainable(n))
+
+
+# ---- text tower (query-bank initialisation, ref src/models.py:155-169) ------------------------------------------------
+def text_param_shapes(tc) -> "OrderedDict[str, tuple]":
+    """HF names below ``owlvit.`` (``text_model.*``, ``text_projection.weight``)."""
+    W, I = tc.width, tc.mlp
+    s = OrderedDict()
+    s["text_model.embeddings.token_embedding.weight"] = (tc.vocab, W)
+    s["text_model.embeddings.position_embedding.weight"] = (tc.max_pos, W)
+    for i in range(tc.layers):
+        pre = f"text_model.encoder.layers.{i}."
+        for nm in ("k_proj", "v_proj", "q_proj", "out_proj"):
+            s[pre + f"self_attn.{nm}.weight"] = (W, W)
+            s[pre + f"self_attn.{nm}.bias"] = (W,)
+        s[pre + "layer_norm1.weight"] = (W,)
+        s[pre + "layer_norm1.bias"] = (W,)
+        s[pre + "mlp.fc1.weight"] = (I, W)
+        s[pre + "mlp.fc1.bias"] = (I,)
+        s[pre + "mlp.fc2.weight"] = (W, I)
+        s[pre + "mlp.fc2.bias"] = (W,)
+        s[pre + "layer_norm2.weight"] = (W,)
+        s[pre + "layer_norm2.bias"] = (W,)
+    s["text_model.final_layer_norm.weight"] = (W,)
+    s["text_model.final_layer_norm.bias"] = (W,)
+    s["text_projection.weight"] = (tc.proj_dim, W)
+    return s
+
+
+def make_text_weights(tc, seed: int = 1234) -> "OrderedDict[str, np.ndarray]":
+    """Deterministic random text tower (no checkpoints on either box); scales follow the HF init (HF5:529-565)."""
+    out = OrderedDict()
+    W, L = tc.width, tc.layers
+    for name, shape in text_param_shapes(tc).items():
+        z = rng.normal(seed, tc.name + "/" + name, int(np.prod(shape)))
+        if "layer_norm" in name:
+            v = (1.0 + 0.05 * z) if name.endswith("weight") else 0.02 * z
+        elif name.endswith("bias"):
+            v = 0.02 * z
+        elif "token_embedding" in name:
+            v = 0.02 * z
+        elif "position_embedding" in name:
+            v = 0.01 * z
+        elif any(k in name for k in ("q_proj", "k_proj", "v_proj")):
+            v = (W ** -0.5) * z      # larger than the HF init so that attention is not uniform (a mask bug must show)
+        elif "out_proj" in name or "fc2" in name:
+            v = (W ** -0.5) * (2 * L) ** -0.5 * z
+        elif "fc1" in name:
+            v = (2 * W) ** -0.5 * z
+        else:
+            v = (W ** -0.5) * z
+        out[name] = v.reshape(shape).astype(np.float32)
+    return out

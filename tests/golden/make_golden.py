@@ -408,6 +408,61 @@ def f7():
     np.savez_compressed(os.path.join(HERE, "f7_preprocess.npz"), **res)
 
 
+def synth_prompt_ids(tc, n_prompts, seed=5):
+    """CLIP-processor-shaped token ids: BOS, 1..8 word tokens, EOS (= highest id), zero padding to max_pos."""
+    from owl_vit_object_detection_amd import rng as crng
+    S = tc.max_pos
+    ids = np.zeros((n_prompts, S), np.int64)
+    lens = 1 + crng.randint(seed, "prompt/len", n_prompts, min(8, S - 2))
+    words = crng.randint(seed, "prompt/words", n_prompts * S, tc.vocab - 3).reshape(n_prompts, S) + 1
+    for n in range(n_prompts):
+        ids[n, 0] = tc.vocab - 2
+        ids[n, 1:1 + lens[n]] = words[n, :lens[n]]
+        ids[n, 1 + lens[n]] = tc.vocab - 1
+    return ids
+
+
+def f8():
+    """Query-bank init: HF OwlViTForObjectDetection(...).text_embeds exactly as ref src/models.py:161-169 calls it
+    (input_ids + the processor's padding attention_mask + a dummy image), text weights from weights.make_text_weights."""
+    from owl_vit_object_detection_amd.config import get_text_config
+    res = {}
+    for cname, n_prompts in (("tiny", 12), ("owlvit-base-patch16", 30)):
+        tc = get_text_config(cname)
+        vcfg = get_config("tiny")
+        hf_cfg = OwlViTConfig(
+            vision_config=dict(hidden_size=vcfg.hidden, intermediate_size=vcfg.mlp, num_hidden_layers=2,
+                               num_attention_heads=vcfg.heads, image_size=vcfg.image_size, patch_size=vcfg.patch_size),
+            text_config=dict(hidden_size=tc.width, intermediate_size=tc.mlp, num_hidden_layers=tc.layers,
+                             num_attention_heads=tc.heads, vocab_size=tc.vocab, max_position_embeddings=tc.max_pos,
+                             hidden_act="quick_gelu", layer_norm_eps=tc.ln_eps, bos_token_id=tc.vocab - 2,
+                             eos_token_id=tc.vocab - 1, pad_token_id=0),
+            projection_dim=tc.proj_dim,
+        )
+        hf_cfg._attn_implementation = "eager"
+        hf_cfg.text_config._attn_implementation = "eager"
+        hf_cfg.vision_config._attn_implementation = "eager"
+        hf = OwlViTForObjectDetection(hf_cfg).eval()
+        tw = weights.make_text_weights(tc)
+        sd = hf.state_dict()
+        for name, arr in tw.items():
+            key = "owlvit." + name
+            assert key in sd and tuple(sd[key].shape) == arr.shape, (key, arr.shape)
+            sd[key] = torch.from_numpy(arr)
+        hf.load_state_dict(sd)
+        ids = synth_prompt_ids(tc, n_prompts)
+        mask = (np.arange(tc.max_pos)[None, :] <= ids.argmax(1)[:, None]).astype(np.int64)
+        with torch.no_grad():
+            out = hf(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask),
+                     pixel_values=torch.zeros(1, 3, vcfg.image_size, vcfg.image_size))
+        te = out.text_embeds
+        assert te.shape == (1, n_prompts, tc.proj_dim), te.shape
+        res[cname + "/input_ids"] = ids
+        res[cname + "/text_embeds"] = te[0].numpy()
+        print("f8", cname, te.shape, "row norms", float(te[0].norm(dim=-1).mean()), "cos(0,1)", float((te[0, 0] * te[0, 1]).sum()))
+    np.savez_compressed(os.path.join(HERE, "f8_text_embeds.npz"), **res)
+
+
 def lsap():
     """Known-answer vectors from scipy (the reference's solver) for the C restatement."""
     from scipy.optimize import linear_sum_assignment
