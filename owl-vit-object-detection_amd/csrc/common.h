@@ -26,6 +26,22 @@ __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));   // ONE v_cvt_pk_bf16_f32
 }
 
+// LDS reads the compiler must not "protect": after a global_load_lds the compiler makes every later C++ LDS read
+// wait for vmcnt(0) -- and on gfx950 vmcnt also counts STORES, so one bias read between two epilogue stores turns
+// the whole store tail into store -> ack -> store -> ack (measured: ~9 us of a 34 us K=768 tile).  These helpers
+// issue the ds_read from inline asm (invisible to that logic) and wait for their own lgkmcnt only.  The caller is
+// responsible for the data really being in LDS (its own counted vmcnt + barrier).
+__device__ __forceinline__ f32x4 lds_read_f4(const void* p) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(uintptr_t)LPTR(p)) : "memory");
+    return v;
+}
+__device__ __forceinline__ float lds_read_f1(const void* p) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(uintptr_t)LPTR(p)) : "memory");
+    return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

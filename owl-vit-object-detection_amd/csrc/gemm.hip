@@ -278,7 +278,8 @@ static int launch_cfg(hipStream_t s, GemmP p, int splits) {
     }
     p.tiles_m = (int)((p.M + BM - 1) / BM); p.tiles_n = (int)((p.N + BN - 1) / BN);
     p.nsplit = splits;
-    if (g_debug_nostore) p.M = 0;
+    if (g_debug_nostore == 1) p.M = 0;
+    p.dbg = g_debug_nostore & ~1;            // tuning experiments: bit 1 = cache-resident store window, bit 2 = non-temporal bf16 stores
     const int nitems = p.tiles_m * p.tiles_n * splits;
     // persistent launch: one workgroup per CU-slot (blocks per CU limited by LDS), a multiple of 8 XCDs
     const int slots = g_debug_slots ? g_debug_slots : 256 * (lds_bytes > 80 * 1024 ? 1 : 2);

@@ -34,6 +34,7 @@ struct GemmP {
     int ps_log2;
     const float* pos;      // [T, N]
     int64_t slab_stride;   // EPI_SLAB: elements per split slab
+    int dbg;               // tuning experiments only: bit 1 = stores wrapped into a cache-resident window, bit 2 = non-temporal bf16 stores
 };
 
 __device__ __forceinline__ float sigmoid1702_f(float u) {   // 1 / (1 + exp(-1.702 u)) with v_exp / v_rcp
@@ -130,8 +131,8 @@ __device__ __forceinline__ void epi_pass(const GemmP& p, const f32x16& t0, const
     for (int it = 0; it < 8; it++) {
         const int row = it * 4 + (lane >> 4);
         const unsigned char* rrow = (row < 16 ? pieceA : pieceB) + (row & 15) * 256;
-        const float4 f = *(const float4*)(rrow + ((ch ^ (row & 15)) << 4));
-        float v[4] = {f.x, f.y, f.z, f.w};
+        const f32x4 f = lds_read_f4(rrow + ((ch ^ (row & 15)) << 4));
+        float v[4] = {f[0], f[1], f[2], f[3]};
         if constexpr (!TRANS) {
             const int64_t m = row_base + row, n = col_base + ch * 4;
             if (m >= p.M || n >= p.N) continue;
@@ -175,7 +176,7 @@ __device__ __forceinline__ void epi_tile_bf16(const GemmP& p, const f32x16& acc,
     if constexpr (TRANS) {
         const int64_t n = n_tile + (lane & 31);
         float bv = 0.f;
-        if (p.bias) bv = lds_bias[lane & 31];              // this tile's bias slice, staged in LDS
+        if (p.bias) bv = lds_read_f1(lds_bias + (lane & 31));   // this tile's bias slice, staged in LDS
 #pragma unroll
         for (int qd = 0; qd < 4; qd++) {
             w[2 * qd] = pack_bf2(acc[qd * 4 + 0] + bv, acc[qd * 4 + 1] + bv);
@@ -194,8 +195,8 @@ __device__ __forceinline__ void epi_tile_bf16(const GemmP& p, const f32x16& acc,
             const bool n_ok = !GUARD || (n_tile + 8 * qd + 4 * hi) < p.N;
             const bool ok = m_ok && n_ok;
             if (p.bias) {                                  // wave-uniform
-                const float4 b4 = *(const float4*)(bias_p + 8 * qd);
-                v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+                const f32x4 b4 = lds_read_f4(bias_p + 8 * qd);
+                v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
             }
             if constexpr (EPI == EPI_QGELU_BF16 || EPI == EPI_GELU_BF16) {
                 if (p.aux) {                               // wave-uniform; pre-activation save (trainable layer only)
@@ -237,8 +238,13 @@ __device__ __forceinline__ void epi_store_chunk(const GemmP& p, const uint4& ch,
         const int64_t b = m / p.Tp, t = m - b * p.Tp;
         *(uint4*)((bf16_t*)p.out + (b * p.N + n) * p.Tp + t) = ch;
     } else {
-        const int64_t m = m_tile + (lane & 31), n = n_tile + 16 * c + 8 * hi;
+        int64_t m = m_tile + (lane & 31), n = n_tile + 16 * c + 8 * hi;
         if (GUARD && (m >= p.M || n >= p.N)) return;
-        *(uint4*)((bf16_t*)p.out + m * p.ldo + n) = ch;
+        if (p.dbg & 2) { m = (int64_t)(blockIdx.x & 255) * 256 + (m & 255); n &= 255; }
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+        u32x4_t* dst = (u32x4_t*)((bf16_t*)p.out + m * p.ldo + n);
+        const u32x4_t val = {ch.x, ch.y, ch.z, ch.w};
+        if (p.dbg & 4) __builtin_nontemporal_store(val, dst);
+        else *dst = val;
     }
 }
