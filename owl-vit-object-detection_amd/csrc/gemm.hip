@@ -290,8 +290,9 @@ static int launch_cfg(hipStream_t s, GemmP p, int splits) {
     return 0;
 }
 
-static int g_force_tile = 0;   // 0 auto, 128, 256 (tests / tuning)
+static int g_force_tile = 0;   // 0 auto, 128, 256, 8 = ping-pong schedule (gemm_pp.hip) where it applies (tests / tuning)
 extern "C" int owl_gemm_set_tile(int tile) { g_force_tile = tile; return 0; }
+int owl_gemm_pp_launch(hipStream_t s, int epi, const GemmP& p, int slots_override, int persistent_on, int nostore);   // gemm_pp.hip
 
 template <int EPI>
 static int launch(hipStream_t s, const GemmP& p, int splits) {
@@ -323,6 +324,13 @@ extern "C" int owl_gemm_nt_bf16(void* stream, int epi, const void* A, int64_t ld
     hipStream_t s = (hipStream_t)stream;
     const bool split_ok = (epi == EPI_ATOMIC_F32 || epi == EPI_SLAB_F32);
     OWL_CHECK_ARG(splits == 1 || split_ok, "owl_gemm_nt_bf16: split-K needs the atomic or slab epilogue");
+    // bf16-output epilogues on big problems run the ping-pong schedule (gemm_pp.hip): 13-26 % faster, bit-identical
+    const bool pp_auto = (g_force_tile == 0 && M >= 512 && N >= 256);
+    if ((g_force_tile == 8 || pp_auto) && K >= 128 && (epi != EPI_TRANS_BF16 || (Tp > 0 && Tp % 4 == 0 && N % 64 == 0)) &&
+        ((epi != EPI_DQGELU_BF16 && epi != EPI_DGELU_BF16) || aux)) {
+        const int rc = owl_gemm_pp_launch(s, epi, p, g_debug_slots, g_persistent, g_debug_nostore);
+        if (rc <= 0) return rc;      // 1 = epilogue not handled there: fall through
+    }
     switch (epi) {
         case EPI_BIAS_BF16: return launch<EPI_BIAS_BF16>(s, p, 1);
         case EPI_QGELU_BF16: return launch<EPI_QGELU_BF16>(s, p, 1);

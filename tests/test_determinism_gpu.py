@@ -55,6 +55,30 @@ def test_gemm_bitwise_repeatable(N, K, epi):
         assert torch.equal(run(), ref)
 
 
+@pytest.mark.parametrize("N,K,epi", [(3072, 768, ops.EPI_QGELU_BF16), (768, 3072, ops.EPI_BIAS_BF16), (768, 128, ops.EPI_BIAS_BF16)])
+def test_gemm_pingpong_matches_tile256_bitwise(N, K, epi):
+    """The ping-pong schedule (counted vmcnt, half-tile early release, two wave groups one barrier apart) must give
+    the very bits of the single-phase kernel -- on a persistent launch (more tiles than workgroups, cross-tile
+    prefetch + counted waits across epilogue stores), every run."""
+    from owl_vit_object_detection_amd import _lib
+    torch.manual_seed(3)
+    M = 32 * 2312
+    A = torch.randn(ops.pad_rows(M), K, device=DEV).bfloat16()
+    W = (torch.randn(N, K, device=DEV) * 0.05).bfloat16(); bias = torch.randn(N, device=DEV)
+
+    def run(tile):
+        _lib.call("owl_gemm_set_tile", tile)
+        out = torch.zeros(ops.pad_rows(M), N, device=DEV, dtype=torch.bfloat16)
+        ops.gemm(epi, A, W, out, bias=bias, M=M)
+        torch.cuda.synchronize()
+        _lib.call("owl_gemm_set_tile", 0)
+        return out
+
+    ref = run(256)
+    for _ in range(12):
+        assert torch.equal(run(8), ref)
+
+
 def test_attention_bwd_bitwise_repeatable():
     torch.manual_seed(2)
     H, T, B = 4, 577, 3

@@ -34,9 +34,10 @@ def qgelu(x):
     return x * torch.sigmoid(1.702 * x)
 
 
-@pytest.fixture(params=[128, 256], ids=["tile128", "tile256"])
+@pytest.fixture(params=[128, 256, 8], ids=["tile128", "tile256", "pingpong"])
 def gemm_tile(request):
-    """Run the GEMM tests on both block-tile instantiations (128x128 4-wave, 256x256 8-wave)."""
+    """Run the GEMM tests on every kernel: 128x128 4-wave, 256x256 8-wave, and the 256x256 ping-pong schedule
+    (gemm_pp.hip; it takes the bf16-output epilogues with K >= 128 and falls through to tile256 otherwise)."""
     from owl_vit_object_detection_amd import _lib
     _lib.call("owl_gemm_set_tile", request.param)
     yield request.param

@@ -53,13 +53,34 @@ def check_tile(tile):
     _lib.call("owl_gemm_set_tile", 0)
 
 
+def check_tile(tile):
+    from owl_vit_object_detection_amd import _lib
+    torch.manual_seed(0)
+    for (M, N, K, epi) in [(1000, 768, 768, ops.EPI_BIAS_BF16), (4624, 3072, 768, ops.EPI_QGELU_BF16), (777, 520, 128, ops.EPI_BIAS_BF16),
+                           (73984, 1536, 768, ops.EPI_BIAS_BF16), (20000, 384, 192, ops.EPI_QGELU_BF16), (73984, 768, 3072, ops.EPI_BIAS_BF16)]:
+        A = torch.randn(ops.pad_rows(M), K, device=DEV).bfloat16()
+        W = (torch.randn(N, K, device=DEV) * 0.05).bfloat16()
+        bias = torch.randn(N, device=DEV)
+        outs = []
+        for t in (256, tile):
+            _lib.call("owl_gemm_set_tile", t)
+            out = torch.zeros(ops.pad_rows(M), N, device=DEV, dtype=torch.bfloat16)
+            for _ in range(3): ops.gemm(epi, A, W, out, bias=bias, M=M)
+            outs.append(out[:M].float())
+        print("tile", tile, "vs 256 maxdiff", M, N, K, epi, (outs[0] - outs[1]).abs().max().item(), flush=True)
+    _lib.call("owl_gemm_set_tile", 0)
+
+
 if __name__ == "__main__":
+    from owl_vit_object_detection_amd import _lib
     B = 32; Tp = 2312; M = B*Tp
-    bench_gemm(M, 768, 768)
-    bench_gemm(M, 1536, 768)
-    bench_gemm(M, 3072, 768, ops.EPI_QGELU_BF16)
-    bench_gemm(M, 768, 3072)
-    bench_gemm(M, 768, 3072, ops.EPI_RESID_F32)
-    bench_gemm(8192, 8192, 8192)
-    bench_attn(32, 12, 2305)
-    bench_attn(8, 12, 2305)
+    check_tile(8)
+    for tile in (0, 8):
+        _lib.call("owl_gemm_set_tile", tile)
+        print("tile", tile)
+        bench_gemm(M, 768, 768)
+        bench_gemm(M, 1536, 768)
+        bench_gemm(M, 3072, 768, ops.EPI_QGELU_BF16)
+        bench_gemm(M, 768, 3072)
+        bench_gemm(8192, 8192, 8192)
+    _lib.call("owl_gemm_set_tile", 0)
