@@ -57,7 +57,29 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
     // ---- staging sources: wave w stages rows [w*16, w*16+16) of both tiles (2 DMA each) --------
     const bf16_t* kbase = p.k + (int64_t)b * p.Tp * p.ld_qk + h * 64;
     const bf16_t* vbase = p.vt + (int64_t)b * p.vt_img_stride + (int64_t)h * 64 * p.Tp;
-    auto stage = [&](int buf, int kv) {
+    // Per-lane byte offsets of this lane's two DMA rows inside a 64-key tile (K) / inside the head's V^T block; the
+    // tile's own offset is wave-uniform and is added on the scalar unit, so staging costs no VALU work per tile
+    // (the kernel is VALU-bound; the per-tile 64-bit address products were ~10 % of its VALU time).
+    unsigned k_voff[2], v_voff[2];
+#pragma unroll
+    for (int qd = 0; qd < 2; qd++) {
+        const int r = (w * 2 + qd) * 8 + (lane >> 3);
+        const int ch = (lane & 7) ^ ((r >> 1) & 7);
+        k_voff[qd] = (unsigned)((r * p.ld_qk + ch * 8) * 2);
+        v_voff[qd] = (unsigned)((r * p.Tp + ch * 8) * 2);          // V^T row r = d; 8 keys per chunk
+    }
+    auto stage = [&](int buf, int kv) {                            // full tiles: every key row < T
+        unsigned char* base = lds + buf * 16384;
+        const unsigned char* kt = (const unsigned char*)(kbase + (int64_t)kv * 64 * p.ld_qk);
+        const unsigned char* vtile = (const unsigned char*)(vbase + (int64_t)kv * 64);
+#pragma unroll
+        for (int qd = 0; qd < 2; qd++) {
+            const int r0 = (w * 2 + qd) * 8;
+            __builtin_amdgcn_global_load_lds(GPTR(kt + k_voff[qd]), LPTR(base + r0 * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GPTR(vtile + v_voff[qd]), LPTR(base + 8192 + r0 * 128), 16, 0, 0);
+        }
+    };
+    auto stage_clamped = [&](int buf, int kv) {                    // the partial last tile: key rows >= T re-read row T-1
         unsigned char* base = lds + buf * 16384;
 #pragma unroll
         for (int qd = 0; qd < 2; qd++) {
@@ -67,7 +89,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
             int key = kv * 64 + r;
             if (key >= p.T) key = p.T - 1;
             __builtin_amdgcn_global_load_lds(GPTR(kbase + (int64_t)key * p.ld_qk + ch * 8), LPTR(base + r0 * 128), 16, 0, 0);
-            // V^T row r = d; 8 keys per chunk (reads past T are finite junk, masked by P = 0)
+            // reads past T are finite junk, masked by P = 0
             __builtin_amdgcn_global_load_lds(GPTR(vbase + (int64_t)r * p.Tp + kv * 64 + ch * 8), LPTR(base + 8192 + r0 * 128), 16, 0, 0);
         }
     };
@@ -168,7 +190,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
 
     const int nkv = (p.T + 63) / 64;
     const int nfull = p.T / 64;          // tiles with no key >= T
-    stage(0, 0);
+    if (nfull > 0) stage(0, 0); else stage_clamped(0, 0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -188,13 +210,13 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
         stage(1, kv + 1);
         tile(B0{}, kv, std::false_type{});
         sync();
-        if (kv + 2 < nkv) stage(0, kv + 2);
+        if (kv + 2 < nfull) stage(0, kv + 2); else if (kv + 2 < nkv) stage_clamped(0, kv + 2);
         tile(B1{}, kv + 1, std::false_type{});
         sync();
     }
     // remainder: at most one full tile and/or the partial tile, buffers alternate from (kv & 1)
     if (kv < nfull) {                           // kv even here -> buffer 0
-        if (kv + 1 < nkv) stage(1, kv + 1);
+        if (kv + 1 < nkv) stage_clamped(1, kv + 1);          // kv + 1 == nfull: the partial tile
         tile(B0{}, kv, std::false_type{});
         sync();
         kv++;
