@@ -99,11 +99,37 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
     for (int d = 0; d < 2; d++)
 #pragma unroll
         for (int r = 0; r < 16; r++) o[d][r] = 0.f;
-    float m_run = -1e30f;
 
-    // fragment byte offsets inside a stage buffer, all 24 precomputed once (the kernel is VALU-bound: 78 % VALU
-    // busy vs 45 % MFMA busy by PMC -- per-tile address arithmetic was ~15 % of its VALU instructions)
-    int k_addr[2][4], v_addr[2][8];
+    // The SIMD's VALU issue port (~4 cycles per wave64 instruction, shared by its 3 waves; PMC: 78 % busy vs 45 % for
+    // the matrix pipe) bounds this kernel, so the softmax is built to need as few VALU instructions as possible:
+    //  * Q is scaled by scale*log2(e) ONCE (bf16 round-off of the scaled Q ~ 2^-9 per element, random sign);
+    //  * the running maximum is subtracted by the matrix pipe: one extra MFMA per 32x32 score tile whose K-side fragment
+    //    is 1.0 in contraction slot 0 and whose Q-side fragment holds -M there (M is kept bf16-exact, so the product is
+    //    exact) -- S arrives as s*c - M and P = exp2(S) needs no VALU fma (the matrix pipe is 45 % busy, it has room);
+    //  * no per-tile row maximum: the tile keeps the OLD M as long as P cannot overflow -- checked on the tile's row
+    //    sums (sum <= 2^40, also catches inf / NaN); only a tile that fails the check (and the first tile) takes the
+    //    slow path: recompute S with C = 0, explicit maximum, rescale O and l, new splat.
+    // Per 64-key tile: 32 exp + 32 add + 16 cvt_pk + a handful, instead of ~190 VALU instructions.
+#pragma unroll
+    for (int kc = 0; kc < 4; kc++) {
+        unsigned wq[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const unsigned u = ((const unsigned*)&qf[kc])[e];
+            wq[e] = pack_bf2(__uint_as_float(u << 16) * c, __uint_as_float(u & 0xffff0000u) * c);
+        }
+        const uint4 q4 = make_uint4(wq[0], wq[1], wq[2], wq[3]);
+        qf[kc] = __builtin_bit_cast(bf16x8, q4);
+    }
+    float M = -1e30f;                                            // running maximum of the SCALED scores (log2 domain), bf16-exact
+    // contraction slot 0 (= element 0 of the lanes with hi == 0): K side all ones, Q side -M of the lane's query column
+    const uint4 ones4 = make_uint4(hi == 0 ? 0x3F80u : 0u, 0u, 0u, 0u);
+    const bf16x8 kones = __builtin_bit_cast(bf16x8, ones4);
+    uint4 qn4 = make_uint4(0u, 0u, 0u, 0u);
+    bf16x8 qneg = __builtin_bit_cast(bf16x8, qn4);
+
+    // fragment byte offsets inside a stage buffer, all precomputed once
+    int k_addr[2][4], v_addr[2][4];
 #pragma unroll
     for (int t = 0; t < 2; t++) {
         const int rk = t * 32 + swap23(lane & 31);
@@ -111,66 +137,81 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
         for (int kc = 0; kc < 4; kc++) k_addr[t][kc] = rk * 128 + (((kc * 2 + hi) ^ ((rk >> 1) & 7)) << 4);
         const int rv = t * 32 + (lane & 31);
 #pragma unroll
-        for (int c8 = 0; c8 < 4; c8++) {
-            v_addr[t][2 * c8 + 0] = 8192 + rv * 128 + (((c8 * 2 + hi) ^ ((rv >> 1) & 7)) << 4);       // unused slot layout:
-            v_addr[t][2 * c8 + 1] = v_addr[t][2 * c8 + 0];                                              // [d-block t][chunk c8]
-        }
+        for (int c8 = 0; c8 < 4; c8++) v_addr[t][c8] = 8192 + rv * 128 + (((c8 * 2 + hi) ^ ((rv >> 1) & 7)) << 4);   // [d-block t][chunk c8]
     }
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float l_part = 0.f;                                          // this half-wave's running sum of P (unnormalised)
 
-    // one KV tile: S^T = K Q^T, online softmax, O^T += V^T P^T.  BUF is a compile-time buffer index so that the
-    // stage offset folds into the ds_read immediate; MASK only for the (peeled) partial last tile.
-    auto tile = [&](auto buf_tag, int kv, auto mask_tag) {
+    // one KV tile: S^T = K Q^T (+C), online softmax, O^T += V^T P^T.  BUF is a compile-time buffer index so that the
+    // stage offset folds into the ds_read immediate; MASK only for the (peeled) partial last tile; FIRST forces the
+    // explicit-maximum path.
+    auto tile = [&](auto buf_tag, int kv, auto mask_tag, bool first) {
         constexpr int BUF = decltype(buf_tag)::value;
         constexpr bool MASK = decltype(mask_tag)::value;
         const unsigned char* tb = lds + BUF * 16384;
         f32x16 s[2];
+        auto qk = [&](bool sub_max) {
 #pragma unroll
-        for (int t = 0; t < 2; t++) {
+            for (int t = 0; t < 2; t++) {
+                if (sub_max) s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kones, qneg, zero16, 0, 0, 0);    // -M everywhere
 #pragma unroll
-            for (int kc = 0; kc < 4; kc++) {
-                const bf16x8 kf = *(const bf16x8*)(tb + k_addr[t][kc]);
-                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kc], kc == 0 ? zero16 : s[t], 0, 0, 0);   // C = 0: no clears
+                for (int kc = 0; kc < 4; kc++) {
+                    const bf16x8 kf = *(const bf16x8*)(tb + k_addr[t][kc]);
+                    s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kc], (kc == 0 && !sub_max) ? zero16 : s[t], 0, 0, 0);
+                }
             }
-        }
-        if constexpr (MASK) {
-            // lane's key for register r of tile t:  kv*64 + t*32 + 16*(r>>3) + 8*hi + (r&7)
+            if constexpr (MASK) {
+                // lane's key for register r of tile t:  kv*64 + t*32 + 16*(r>>3) + 8*hi + (r&7)
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int key = kv * 64 + t * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
+                        if (key >= p.T) s[t][r] = -INFINITY;
+                    }
+            }
+        };
+        bool slow = first || (p.dbg & 1);
+        float ts = 0.f;
+        if (!slow) {
+            qk(true);                                            // s = score*c - M
 #pragma unroll
             for (int t = 0; t < 2; t++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
-                    const int key = kv * 64 + t * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
-                    if (key >= p.T) s[t][r] = -INFINITY;
+                    s[t][r] = __builtin_amdgcn_exp2f(s[t][r]);
+                    ts += s[t][r];
                 }
+            slow = __any(!(ts <= 1.0995116e12f));                // 2^40: P may have overflowed (or is about to): redo with a new M
         }
-        // ---- online softmax (per query column = per lane pair {l, l^32}) ---------------------------
-        float mx = s[0][0];
+        if (slow) {                                              // wave-uniform
+            qk(false);                                           // s = score*c
+            float mx = s[0][0];
 #pragma unroll
-        for (int t = 0; t < 2; t++)
+            for (int t = 0; t < 2; t++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[t][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        // deferred rescale: keep the old running max while this tile's max exceeds it by < 2^8 in the exp2
-        // domain (P stays <= 256, harmless in f32 / relative-precision bf16); rescale O only when some lane needs it.
-        if ((p.dbg & 1) || !__all((mx - m_run) * c <= 8.0f)) {
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-            m_run = m_new;
+                for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[t][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float M_new = bf2f(f2bf(fmaxf(M, mx)));          // bf16-exact (round to nearest: P may exceed 1 by 2^-8, harmless)
+            const float alpha = __builtin_amdgcn_exp2f(M - M_new);
+            M = M_new;
             l_part *= alpha;
 #pragma unroll
             for (int d = 0; d < 2; d++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) o[d][r] *= alpha;
+            qn4.x = hi == 0 ? (unsigned)f2bf(-M) : 0u;
+            qneg = __builtin_bit_cast(bf16x8, qn4);
+            ts = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    s[t][r] = __builtin_amdgcn_exp2f(s[t][r] - M);
+                    ts += s[t][r];
+                }
         }
-        const float mc = m_run * c;
-#pragma unroll
-        for (int t = 0; t < 2; t++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                s[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], c, -mc));
-                l_part += s[t][r];
-            }
+        l_part += ts;
         // ---- O^T += V^T P^T (4 chunks of 16 keys, 2 d-blocks) ----
 #pragma unroll
         for (int t = 0; t < 2; t++)
@@ -182,7 +223,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
                 const int c8 = t * 2 + cc;
 #pragma unroll
                 for (int d = 0; d < 2; d++) {
-                    const bf16x8 vf = *(const bf16x8*)(tb + v_addr[d][2 * c8]);
+                    const bf16x8 vf = *(const bf16x8*)(tb + v_addr[d][c8]);
                     o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
                 }
             }
@@ -208,21 +249,21 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
     int kv = 0;
     for (; kv + 1 < nfull; kv += 2) {          // two tiles per trip: buffer index is a compile-time constant
         stage(1, kv + 1);
-        tile(B0{}, kv, std::false_type{});
+        tile(B0{}, kv, std::false_type{}, kv == 0);
         sync();
         if (kv + 2 < nfull) stage(0, kv + 2); else if (kv + 2 < nkv) stage_clamped(0, kv + 2);
-        tile(B1{}, kv + 1, std::false_type{});
+        tile(B1{}, kv + 1, std::false_type{}, false);
         sync();
     }
     // remainder: at most one full tile and/or the partial tile, buffers alternate from (kv & 1)
     if (kv < nfull) {                           // kv even here -> buffer 0
         if (kv + 1 < nkv) stage_clamped(1, kv + 1);          // kv + 1 == nfull: the partial tile
-        tile(B0{}, kv, std::false_type{});
+        tile(B0{}, kv, std::false_type{}, kv == 0);
         sync();
         kv++;
     }
     if (kv < nkv) {
-        if (kv & 1) tile(B1{}, kv, std::true_type{}); else tile(B0{}, kv, std::true_type{});
+        if (kv & 1) tile(B1{}, kv, std::true_type{}, false); else tile(B0{}, kv, std::true_type{}, kv == 0);
     }
     const float l_run = l_part;
 
@@ -241,7 +282,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
                 v.y = pack_bf2(o[d][qd * 4 + 2] * inv, o[d][qd * 4 + 3] * inv);
                 *(uint2*)(op + d * 32 + 8 * qd + 4 * hi) = v;
             }
-        if (p.lse && hi == 0) p.lse[((int64_t)b * p.H + h) * p.Tp + qr] = m_run * c + __builtin_amdgcn_logf(l_tot);
+        if (p.lse && hi == 0) p.lse[((int64_t)b * p.H + h) * p.Tp + qr] = M + __builtin_amdgcn_logf(l_tot);
     }
 }
 
