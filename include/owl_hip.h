@@ -130,6 +130,13 @@ int owl_text_embed(void* stream, const int64_t* ids, const float* tok_emb, const
 int owl_causal_attention_small(void* stream, const void* qkv_bf16, void* out_bf16, int64_t N, int64_t S, int64_t heads, float scale);
 int owl_text_pool_project(void* stream, const float* x, const int64_t* ids, const float* gamma, const float* beta, const float* wproj, float* out, int64_t N, int64_t S, int64_t W, int64_t Pdim, float eps);
 
+/* weight gradients without transposed copies:  slab[s][n][k] = sum_{m in split s} dY[m][n] * X[m][k]  (dW = dY^T X; both
+ * operands token-major bf16 as the other kernels leave them; the transposition happens in LDS via ds_read_b64_tr_b16).
+ * zero_row: >= 512 B of device zeros (source of rows m >= M); slabs [splits_used][N][K] f32 are reduced by owl_slab_reduce;
+ * splits_used is a HOST pointer.  owl_colsum_bf16: colsum[c] += sum_r in[r][c] (bias gradients).                       */
+int owl_gemm_tn_slab_bf16(void* stream, const void* dY, int64_t ldy, const void* X, int64_t ldx, const void* zero_row, float* slab, int64_t M, int64_t N, int64_t K, int splits, int* splits_used);
+int owl_colsum_bf16(void* stream, const void* in_bf16, int64_t ld, float* colsum, int64_t R, int64_t C);
+
 /* pairwise out3 = {iou, union, giou} each [N,M] (free functions box_iou / generalized_box_iou, ref src/matcher.py:8-44) */
 int owl_box_pairwise(void* stream, const float* boxes1, const float* boxes2, float* out3, int64_t N, int64_t M);
 

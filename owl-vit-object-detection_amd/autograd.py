@@ -125,6 +125,14 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
         """grad_w[n_out, n_in] (+)= dy[rows, n_out]^T x[rows, n_in];  grad_b += colsum(dy).
         Token-major operand copies (transposes) -> split-K GEMM into f32 slabs -> deterministic slab reduction.
         Pad columns [rows, rows_pad) of the scratch stay zero: never written, buffers start zeroed."""
+        if n_out % 256 == 0 and n_in % 256 == 0:
+            # TN kernel: reads dy / x where they lie (LDS transpose-reads), no token-major copies
+            if grad_b is not None:
+                ops.colsum_bf16(dy, grad_b, rows, n_out)
+            tiles = (n_out // 256) * (n_in // 256)
+            ns = ops.gemm_tn_slab(dy, x, bw["slab"], rows, n_out, n_in, max(1, 256 // tiles))
+            _lib.call("owl_slab_reduce", ops.stream(), bw["slab"], grad_w, n_out * n_in, n_out * n_in, ns, accumulate)
+            return
         tA, tB = (bw["tAh"], bw["tBh"]) if rows == Mh else (bw["tA"], bw["tB"])
         ld = tA.shape[1]
         assert ld == rows_pad

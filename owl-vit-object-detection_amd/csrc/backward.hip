@@ -488,3 +488,39 @@ extern "C" int owl_colsum_f32(void* stream, const float* in, float* colsum, int6
     OWL_LAUNCH_CHECK();
     return 0;
 }
+
+
+// bf16 column sums (bias gradient when the weight gradient reads dY in place: gemm_tn.hip); colsum += sum_r in[r][c].
+// A workgroup owns 512 columns x 256 rows: lane -> 8 columns (16-byte loads, a wave reads 1 KiB of a row), its 4 waves
+// take rows r0+w, r0+w+4, ...; partial sums meet in LDS, one f32 atomicAdd per column and workgroup.  HBM-bound:
+// reads R*C*2 bytes once.
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ in, int64_t ld, float* colsum, int64_t R, int64_t C) {
+    __shared__ float part[4][512];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t c = (int64_t)blockIdx.x * 512 + lane * 8;
+    const int64_t r0 = (int64_t)blockIdx.y * 256, r1 = min(R, r0 + 256);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c < C) {
+        for (int64_t r = r0 + w; r < r1; r += 4) {
+            const uint4 u = *(const uint4*)(in + r * ld + c);
+            const unsigned wds[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) { acc[2 * e] += __uint_as_float(wds[e] << 16); acc[2 * e + 1] += __uint_as_float(wds[e] & 0xffff0000u); }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) part[w][lane * 8 + e] = acc[e];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 512; i += 256) {
+        const int64_t cc = (int64_t)blockIdx.x * 512 + i;
+        if (cc < C) atomicAdd(colsum + cc, (part[0][i] + part[1][i]) + (part[2][i] + part[3][i]));
+    }
+}
+
+extern "C" int owl_colsum_bf16(void* stream, const void* in_bf16, int64_t ld, float* colsum, int64_t R, int64_t C) {
+    OWL_CHECK_ARG(in_bf16 && colsum && R > 0 && C > 0 && C % 8 == 0 && ld % 8 == 0, "owl_colsum_bf16: bad arguments (C, ld %% 8 == 0)");
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3((unsigned)((C + 511) / 512), (unsigned)((R + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)in_bf16, ld, colsum, R, C);
+    OWL_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,193 @@
+// TN split-K GEMM for the weight gradients:  slab[s][n][k] = sum_{m in split s} dY[m][n] * X[m][k]
+// (dW = dY^T X, ref: autograd of every nn.Linear on the trainable path; HF5:437-439,457,472,474,994-997; ref models.py:25).
+//
+// Both operands are read the way the forward/backward kernels leave them in HBM -- token-major [M, features] -- so the
+// contraction index m is the SLOW index of both tiles.  The first version of this repo made token-contiguous copies
+// (16 transpose launches, 3.6 GB of HBM traffic, 1.3 ms per step) and used the NT kernel; here the transposition is done
+// by the LDS hardware instead: `ds_read_b64_tr_b16` gives a lane 4 consecutive m of ONE feature column (probed on the
+// device, tools/probe/tr_probe.hip: inside a 16-lane group lane j supplies the address of row j>>2 / 8-byte column
+// quad j&3 of a [4 m][16 feature] block and receives column j), two of them = the 8-element K-fragment of
+// v_mfma_f32_32x32x16_bf16.
+//
+// LDS image of a K-tile (64 m) per operand: [64 rows][256 features] bf16, 512-byte rows, staged by LDS-DMA (one 1-KiB
+// instruction = 2 rows).  A transpose-read touches rows {k..k+3, k+8..k+11} x 64 B, which at a 512-byte pitch would all
+// sit on the same 16 banks; the 16-byte chunks of row r are therefore XOR-swizzled with ((r&3)<<2) on the DMA source
+// side (and in the read addresses), which spreads the 4 rows of a block over the 4 quarters of the 256-byte bank row:
+// 32 pieces of 16 B on 16 slots = the 2-cycle minimum of a 512-byte access.
+//
+// Tile 256 (n) x 256 (k) x 64 (m), 8 waves (2 x 4, wave tile 128 x 64), 2 x 64 KiB LDS, one barrier per K-tile,
+// persistent (tile, split) items, f32 slabs through the LDS-staged coalesced epilogue of gemm_common.h.
+// Rows m >= M of the last K-tile are fetched from a caller-provided zero row, so any M works.
+#include "gemm_common.h"
+
+static constexpr int TBK = 64;
+static constexpr int T_OP_BYTES = TBK * 256 * 2;          // 32 KiB per operand per stage
+static constexpr int T_STAGE = 2 * T_OP_BYTES;
+static constexpr int T_LDS = 2 * T_STAGE;
+
+struct TnP {
+    const bf16_t* dY; int64_t ldy;     // [M, ldy], features n in [0, N)
+    const bf16_t* X; int64_t ldx;      // [M, ldx], features k in [0, K)
+    const bf16_t* zero_row;            // >= 512 bytes of zeros
+    float* slab; int64_t slab_stride;  // [nsplit][N][K]
+    int64_t M, N, K;
+    int tiles_n, tiles_k, kt_per_split, nsplit, persistent;
+};
+
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+
+// 8-element K-fragment = two transpose-reads (the compiler's builtin: it tracks lgkmcnt itself and builds the 128-bit
+// register tuple without copies -- an asm ds_read's result may be touched before a hand-placed wait)
+__device__ __forceinline__ bf16x8 lds_tr_frag(const unsigned char* tile_lo, const unsigned char* tile_hi) {
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)tile_lo);
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)tile_hi);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ __launch_bounds__(512) void gemm_tn_slab_kernel(TnP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = w >> 2, wc = w & 3;
+    const int nk_all = (int)((p.M + TBK - 1) / TBK);
+    const int nitems = p.tiles_n * p.tiles_k * p.nsplit;
+    int item, item_end, item_step;
+    if (p.persistent) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, chunk = (nitems + 7) >> 3;
+        item = xcd * chunk + idx; item_end = min(nitems, (xcd + 1) * chunk); item_step = gridDim.x >> 3;
+    } else {
+        item = xcd_remap(blockIdx.x, nitems); item_end = item + 1; item_step = 1;
+    }
+    if (item >= item_end) return;
+
+    int64_t n0, k0;
+    int split, kt0, kt1;
+    auto decode = [&](int it) {
+        const int tile = it / p.nsplit;
+        split = it - tile * p.nsplit;
+        const int tn = tile / p.tiles_k, tk = tile - tn * p.tiles_k;
+        n0 = (int64_t)tn * 256; k0 = (int64_t)tk * 256;
+        kt0 = split * p.kt_per_split;
+        kt1 = min(nk_all, kt0 + p.kt_per_split);
+    };
+
+    // ---- staging: wave w fills rows [w*8, w*8+8) of both operand tiles: 4 DMA instructions (2 rows each) per operand ----
+    // lane -> row (lane>>5) of the pair, 16-byte chunk (lane&31); the SOURCE chunk is swizzled with ((row&3)<<2)
+    auto stage = [&](int buf, int kt) {
+        unsigned char* base = lds + buf * T_STAGE;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int r = w * 8 + q * 2 + (lane >> 5);
+            const int c = (lane & 31) ^ ((r & 3) << 2);
+            const int64_t m = (int64_t)kt * TBK + r;
+            const bool ok = m < p.M;
+            int64_t nn = n0 + c * 8; if (nn + 8 > p.N) nn = p.N - 8;
+            int64_t kk = k0 + c * 8; if (kk + 8 > p.K) kk = p.K - 8;
+            const bf16_t* ga = ok ? p.dY + m * p.ldy + nn : p.zero_row + (lane & 31) * 8;
+            const bf16_t* gb = ok ? p.X + m * p.ldx + kk : p.zero_row + (lane & 31) * 8;
+            __builtin_amdgcn_global_load_lds(GPTR(ga), LPTR(base + (w * 8 + q * 2) * 512), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GPTR(gb), LPTR(base + T_OP_BYTES + (w * 8 + q * 2) * 512), 16, 0, 0);
+        }
+    };
+
+    // ---- transpose-read addresses (bytes inside an operand tile, K-chunk kc = 0, first half): the lane supplies
+    //      row 8*(lane>>5) + ((lane&15)>>2) (+16*kc + 4*half as an immediate), feature f = f0 + 16*((lane>>4)&1) + 4*(lane&3)
+    const int rr = 8 * (lane >> 5) + ((lane & 15) >> 2);
+    const int sw = (rr & 3) << 2;                               // = ((lane&15)>>2) << 2: unchanged by +16*kc, +4*half
+    const unsigned lds_base = 0;
+    unsigned a_addr[4], b_addr[2];                             // byte offsets from `lds`
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int f = wr * 128 + i * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+        a_addr[i] = lds_base + rr * 512 + ((((f >> 3) ^ sw)) << 4) + ((f >> 2) & 1) * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int f = wc * 64 + j * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+        b_addr[j] = lds_base + T_OP_BYTES + rr * 512 + ((((f >> 3) ^ sw)) << 4) + ((f >> 2) & 1) * 8;
+    }
+
+    decode(item);
+    stage(0, kt0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int cur = 0;
+    GemmP ep{};                       // what the shared f32 epilogue needs
+    ep.out = p.slab; ep.ldo = p.K; ep.M = p.N; ep.N = p.K; ep.alpha = 1.0f; ep.slab_stride = p.slab_stride;
+    while (true) {
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+        const int64_t cn0 = n0, ck0 = k0;
+        const int csplit = split, ckt0 = kt0, ckt1 = kt1;
+        const int next = item + item_step;
+        const bool has_next = next < item_end;
+        for (int kt = ckt0; kt < ckt1; kt++) {
+            const bool last = (kt + 1 == ckt1);
+            if (!last) stage(cur ^ 1, kt + 1);
+            else if (has_next) { decode(next); stage(cur ^ 1, kt0); }
+            const unsigned char* tb = lds + cur * T_STAGE;
+#pragma unroll
+            for (int kc = 0; kc < 4; kc++) {
+                bf16x8 fa[4], fb[2];
+#pragma unroll
+                for (int j = 0; j < 2; j++) fb[j] = lds_tr_frag(tb + b_addr[j] + kc * 8192, tb + b_addr[j] + kc * 8192 + 2048);
+#pragma unroll
+                for (int i = 0; i < 4; i++) fa[i] = lds_tr_frag(tb + a_addr[i] + kc * 8192, tb + a_addr[i] + kc * 8192 + 2048);
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);   // D rows = k, cols = n
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            cur ^= 1;
+        }
+        {
+            // buffer cur^1 was just consumed; each wave stages its f32 passes through the 2 x 4 KiB of it that only IT will
+            // DMA into next (rows [w*8, w*8+8) of both operand tiles)
+            unsigned char* xb = lds + (cur ^ 1) * T_STAGE;
+            unsigned char* pieceA = xb + (w * 8) * 512;
+            unsigned char* pieceB = xb + T_OP_BYTES + (w * 8) * 512;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                epi_pass<EPI_SLAB_F32>(ep, acc[i][0], acc[i][1], pieceA, pieceB, cn0 + wr * 128 + i * 32, ck0 + wc * 64, lane, csplit);
+        }
+        if (!has_next) break;
+        item = next;
+    }
+}
+
+extern "C" int owl_gemm_tn_slab_bf16(void* stream, const void* dY, int64_t ldy, const void* X, int64_t ldx, const void* zero_row,
+                                     float* slab, int64_t M, int64_t N, int64_t K, int splits, int* splits_used) {
+    OWL_CHECK_ARG(dY && X && zero_row && slab && splits_used, "owl_gemm_tn_slab_bf16: null pointer");
+    OWL_CHECK_ARG(M > 0 && N >= 8 && K >= 8 && N % 8 == 0 && K % 8 == 0, "owl_gemm_tn_slab_bf16: bad M=%lld N=%lld K=%lld (N, K %% 8 == 0)", (long long)M, (long long)N, (long long)K);
+    OWL_CHECK_ARG(ldy % 8 == 0 && ldx % 8 == 0 && splits >= 1, "owl_gemm_tn_slab_bf16: ldy/ldx must be multiples of 8, splits >= 1");
+    TnP p{};
+    p.dY = (const bf16_t*)dY; p.ldy = ldy; p.X = (const bf16_t*)X; p.ldx = ldx; p.zero_row = (const bf16_t*)zero_row;
+    p.slab = slab; p.slab_stride = N * K; p.M = M; p.N = N; p.K = K;
+    p.tiles_n = (int)((N + 255) / 256); p.tiles_k = (int)((K + 255) / 256);
+    const int nk = (int)((M + TBK - 1) / TBK);
+    if (splits > nk) splits = nk;
+    p.kt_per_split = (nk + splits - 1) / splits;
+    p.nsplit = (nk + p.kt_per_split - 1) / p.kt_per_split;
+    *splits_used = p.nsplit;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)gemm_tn_slab_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
+        attr_done = true;
+    }
+    const int nitems = p.tiles_n * p.tiles_k * p.nsplit;
+    p.persistent = nitems > 256 ? 1 : 0;
+    hipLaunchKernelGGL(gemm_tn_slab_kernel, dim3(p.persistent ? 256 : nitems), dim3(512), T_LDS, (hipStream_t)stream, p);
+    OWL_LAUNCH_CHECK();
+    return 0;
+}

@@ -172,3 +172,23 @@ def postprocess(boxes, sims, max_out, conf_thr, iou_thr):
     _lib.call("owl_postprocess", stream(), boxes, sims, ws, ws.numel(), out_boxes, out_scores, out_classes, out_patch, counts,
               B, P, C, max_out, conf_thr, iou_thr)
     return out_boxes, out_classes, out_scores, out_patch, counts
+
+
+_zero_row = {}
+
+
+def gemm_tn_slab(dy, x, slab, rows, n_out, n_in, splits):
+    """slab[s][n][k] = sum_{m in split s} dy[m][n] * x[m][k] (weight gradient, no transposed copies) -> splits used."""
+    _chk(dy, torch.bfloat16, "dy"); _chk(x, torch.bfloat16, "x"); _chk(slab, torch.float32, "slab")
+    dev = dy.device
+    if dev not in _zero_row:
+        _zero_row[dev] = torch.zeros(512, dtype=torch.bfloat16, device=dev)
+    used = torch.zeros(1, dtype=torch.int32)
+    _lib.call("owl_gemm_tn_slab_bf16", stream(), dy, dy.shape[-1], x, x.shape[-1], _zero_row[dev], slab, rows, n_out, n_in,
+              int(splits), used)
+    return int(used.item())
+
+
+def colsum_bf16(src, colsum, rows, cols):
+    _chk(src, torch.bfloat16, "src"); _chk(colsum, torch.float32, "colsum")
+    _lib.call("owl_colsum_bf16", stream(), src, src.shape[-1], colsum, rows, cols)

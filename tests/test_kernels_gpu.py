@@ -287,3 +287,27 @@ def test_transpose_colsum(R, C):
     cs2 = torch.zeros(C, device=DEV)
     ops.transpose_colsum(a, None, cs2, R, C)          # column sums only
     report("colsum only", cs2, a[:R].float().sum(0), 2e-2, 1e-3)
+
+
+@pytest.mark.parametrize("rows,n_out,n_in,splits", [(73984, 768, 768, 28), (2312, 3072, 768, 9), (4624, 768, 3072, 7), (1000, 256, 512, 3),
+                                                      (64, 256, 256, 1), (73728, 512, 768, 42)])
+def test_gemm_tn_slab_weight_gradient(rows, n_out, n_in, splits):
+    """dW = dY^T X straight from the token-major operands (LDS transpose-reads) vs an f64 reference on a row sample and
+    vs the explicit-transpose NT path; any `rows` (the last K-tile is zero-filled); deterministic."""
+    torch.manual_seed(rows + n_out)
+    dy = torch.zeros(ops.pad_rows(rows), n_out, device=DEV, dtype=torch.bfloat16); dy[:rows] = (torch.randn(rows, n_out, device=DEV) * 0.1).bfloat16()
+    x = torch.zeros(ops.pad_rows(rows), n_in, device=DEV, dtype=torch.bfloat16); x[:rows] = torch.randn(rows, n_in, device=DEV).bfloat16()
+    dy[rows:] = 7.0; x[rows:] = 3.0                     # pad rows must NOT leak into the sum
+    slab = torch.zeros(splits * n_out * n_in, device=DEV)
+    ns = ops.gemm_tn_slab(dy, x, slab, rows, n_out, n_in, splits)
+    assert 1 <= ns <= splits
+    got = slab[: ns * n_out * n_in].view(ns, n_out, n_in).sum(0)
+    ref = dy[:rows].float().T @ x[:rows].float()
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= 2e-3 * scale + 1e-3, (err, scale)          # f32 accumulation, different summation order
+    slab2 = torch.zeros_like(slab)
+    assert ops.gemm_tn_slab(dy, x, slab2, rows, n_out, n_in, splits) == ns and torch.equal(slab, slab2)     # bitwise repeatable
+    cs = torch.zeros(n_out, device=DEV)
+    ops.colsum_bf16(dy, cs, rows, n_out)
+    assert (cs - dy[:rows].float().sum(0)).abs().max().item() <= 1e-3 * rows ** 0.5 + 1e-3
