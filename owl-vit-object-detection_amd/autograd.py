@@ -67,6 +67,7 @@ def _bws(model, B):
     bf, f32 = torch.bfloat16, torch.float32
     z = ops.zeros_rows
     wide = max(3 * D, I)
+    tn_all = all(v % 256 == 0 for v in (D, I, Dt))          # every token-row dW goes through the TN kernel (gemm_tn.hip)
     ws = dict(
         de=z(Mh, Dt, bf, dev), dqhat=torch.zeros(32, Dt, device=dev), du1=z(Mh, D, bf, dev), du0=z(Mh, D, bf, dev),
         g32=z(Mh, 32, bf, dev), e_bf=z(Mh, Dt, bf, dev),
@@ -78,8 +79,12 @@ def _bws(model, B):
         dvec=torch.zeros(B, H, Tp, device=dev),
         # transposed-operand scratch for the dW GEMMs; token-row and head-row users get their own buffers so
         # that the zero pad columns [rows, rows_pad) of each are never dirtied by the other row count
-        tA=torch.zeros(wide, Mp, dtype=bf, device=dev), tB=torch.zeros(wide, Mp, dtype=bf, device=dev),
-        tAh=torch.zeros(max(D, Dt), Mhp, dtype=bf, device=dev), tBh=torch.zeros(max(D, Dt), Mhp, dtype=bf, device=dev),
+        # (only the shapes the TN kernel does not take need them: feature counts that are not multiples of 256 -- the
+        # parity-test configs -- and the 32 x Dt prompt-gradient product)
+        tA=None if tn_all else torch.zeros(wide, Mp, dtype=bf, device=dev),
+        tB=None if tn_all else torch.zeros(wide, Mp, dtype=bf, device=dev),
+        tAh=torch.zeros(32 if tn_all else max(D, Dt), Mhp, dtype=bf, device=dev),
+        tBh=torch.zeros(max(D, Dt), Mhp, dtype=bf, device=dev),
         wT=torch.zeros(wide * max(D, I), dtype=bf, device=dev),
     )
     model._ws[key] = ws
