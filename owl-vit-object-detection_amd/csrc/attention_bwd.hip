@@ -31,6 +31,31 @@ __device__ __forceinline__ int swap23b(int m) { return (m & ~12) | ((m & 4) << 1
 __device__ __forceinline__ int tile_off(int row, int ch) { return row * 128 + ((ch ^ ((row >> 1) & 7)) << 4); }
 
 // ---- D vector ------------------------------------------------------------------------------------
+// ---- VALU-lean recomputation (same idea as attention_fwd.hip: these kernels are bound by VALU issue, not by the matrix pipe) ----
+// P = exp2(s*c - lse) and dS = P * (dP - D) need, per score, an fma and a subtract whose second operands are constants of
+// the score's QUERY.  Both are moved into the matrix pipe: the operand that is loaded once per kernel (this lane's K row in
+// the dK/dV kernel, its Q row in the dQ kernel) is pre-scaled by c, and one extra MFMA per accumulator adds the per-query
+// constant: contraction slots 0 and 1 carry (hi, lo) = a two-term bf16 split of -lse (resp. -D) on the query side and
+// (1, 1) on the key side, so the sum hi + lo enters the f32 accumulator with ~2^-17 relative error.
+__device__ __forceinline__ unsigned split_hi_lo_bf16(float x) {          // packed (hi | lo << 16), hi + lo ~= x
+    const float hi = bf2f(f2bf(x));
+    return pack_bf2(hi, x - hi);
+}
+__device__ __forceinline__ bf16x8 frag_slot01(unsigned w0, int hi_half) {  // 8-element K-fragment with slots 0,1 = w0 (first half-wave only)
+    const uint4 u = make_uint4(hi_half == 0 ? w0 : 0u, 0u, 0u, 0u);
+    return __builtin_bit_cast(bf16x8, u);
+}
+__device__ __forceinline__ bf16x8 scale_frag(bf16x8 f, float c) {
+    unsigned wq[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const unsigned u = ((const unsigned*)&f)[e];
+        wq[e] = pack_bf2(__uint_as_float(u << 16) * c, __uint_as_float(u & 0xffff0000u) * c);
+    }
+    const uint4 q4 = make_uint4(wq[0], wq[1], wq[2], wq[3]);
+    return __builtin_bit_cast(bf16x8, q4);
+}
+
 __global__ __launch_bounds__(256) void attn_dvec_kernel(AttnBwdP p) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;       // over B*Tp*H
     const int64_t nrow = (int64_t)p.Tp * p.H;
@@ -76,6 +101,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdP p) {
         vf[kc] = *(const bf16x8*)(krow + D + kc * 16 + hi * 8);
     }
 
+    bf16x8 ks[4];                                                 // c * K: S arrives in the exp2 domain
+#pragma unroll
+    for (int kc = 0; kc < 4; kc++) ks[kc] = scale_frag(kf[kc], c);
+    const bf16x8 ones01 = frag_slot01(0x3F803F80u, hi);            // key side: 1.0 in contraction slots 0, 1
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
     const bf16_t* qbase = p.qkv + (int64_t)b * p.Tp * p.ld_qkv + h * 64;
     const bf16_t* dobase = p.dO + (int64_t)b * p.Tp * p.ld_do + h * 64;
     const bf16_t* qtbase = p.qkvT + ((int64_t)b * 3 * D + h * 64) * p.Tp;
@@ -103,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdP p) {
     auto load_scal = [&](int qt) -> float {
         const int i = threadIdx.x & 63;
         const int q = qt * 64 + i;
-        if (threadIdx.x < 64) return (q < p.T) ? lsebase[q] : INFINITY;
+        if (threadIdx.x < 64) return (q < p.T) ? lsebase[q] : 1e30f;       // finite "infinity": it goes through a bf16 hi/lo split
         if (threadIdx.x < 128) return (q < p.T) ? dvbase[q] : 0.f;
         return 0.f;
     };
@@ -131,32 +162,31 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdP p) {
         const float* dv_t = lse_t + 64;
 #pragma unroll
         for (int sub = 0; sub < 2; sub++) {
-            f32x16 s, dp;
-#pragma unroll
-            for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
             const int qrow = sub * 32 + swap23b(l31);
+            // query-side fragments of the two constant MFMAs: this lane's A row is query `qrow` of the tile
+            const bf16x8 a_lse = frag_slot01(split_hi_lo_bf16(-lse_t[qrow]), hi);
+            const bf16x8 a_dv = frag_slot01(split_hi_lo_bf16(-dv_t[qrow]), hi);
+            f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lse, ones01, zero16, 0, 0, 0);    // -lse[query] in every key column
+            f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_dv, ones01, zero16, 0, 0, 0);    // -D[query]
 #pragma unroll
             for (int kc = 0; kc < 4; kc++) {
                 const bf16x8 qa = *(const bf16x8*)(tb + tile_off(qrow, kc * 2 + hi));
                 const bf16x8 da = *(const bf16x8*)(tb + 8192 + tile_off(qrow, kc * 2 + hi));
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[kc], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, ks[kc], s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[kc], dp, 0, 0, 0);
             }
             // register r <-> query sub*32 + 16*(r>>3) + 8*hi + (r&7)
 #pragma unroll
             for (int cc = 0; cc < 2; cc++) {
-                const int qb = sub * 32 + cc * 16 + 8 * hi;
-                const float4 l0 = *(const float4*)(lse_t + qb), l1 = *(const float4*)(lse_t + qb + 4);
-                const float4 d0 = *(const float4*)(dv_t + qb), d1 = *(const float4*)(dv_t + qb + 4);
-                const float lv[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
-                const float dd[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
-                bf16x8 pf, dsf;
+                float pv[8], dsv[8];
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[cc * 8 + j], c, -lv[j]));
-                    pf[j] = (short)f2bf(pv);
-                    dsf[j] = (short)f2bf(pv * (dp[cc * 8 + j] - dd[j]));
+                    pv[j] = __builtin_amdgcn_exp2f(s[cc * 8 + j]);            // = exp2(score*c - lse)
+                    dsv[j] = pv[j] * dp[cc * 8 + j];                           // P * (dP - D)
                 }
+                const uint4 pw = make_uint4(pack_bf2(pv[0], pv[1]), pack_bf2(pv[2], pv[3]), pack_bf2(pv[4], pv[5]), pack_bf2(pv[6], pv[7]));
+                const uint4 dsw = make_uint4(pack_bf2(dsv[0], dsv[1]), pack_bf2(dsv[2], dsv[3]), pack_bf2(dsv[4], dsv[5]), pack_bf2(dsv[6], dsv[7]));
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, pw), dsf = __builtin_bit_cast(bf16x8, dsw);
                 const int ch = sub * 4 + cc * 2 + hi;
 #pragma unroll
                 for (int d = 0; d < 2; d++) {
@@ -217,6 +247,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdP p) {
     }
     const float lse_q = p.lse[((int64_t)b * p.H + h) * p.Tp + q];
     const float dvec_q = p.dvec[((int64_t)b * p.H + h) * p.Tp + q];
+    bf16x8 qs[4];                                                 // c * Q: S^T arrives in the exp2 domain
+#pragma unroll
+    for (int kc = 0; kc < 4; kc++) qs[kc] = scale_frag(qf[kc], c);
+    const bf16x8 ones01 = frag_slot01(0x3F803F80u, hi);            // key side: 1.0 in contraction slots 0, 1
+    const bf16x8 q_lse = frag_slot01(split_hi_lo_bf16(-lse_q), hi);   // query side: -lse  (hi, lo)
+    const bf16x8 q_dv = frag_slot01(split_hi_lo_bf16(-dvec_q), hi);   //             -D
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     const bf16_t* kbase = p.qkv + (int64_t)b * p.Tp * p.ld_qkv + D + h * 64;
     const bf16_t* ktbase = p.qkvT + ((int64_t)b * 3 * D + D + h * 64) * p.Tp;
@@ -253,29 +290,30 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdP p) {
         const bool tail = kv * 64 + 64 > p.T;
 #pragma unroll
         for (int sub = 0; sub < 2; sub++) {
-            f32x16 s, dp;
-#pragma unroll
-            for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
+            f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones01, q_lse, zero16, 0, 0, 0);    // -lse of the lane's query
+            f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones01, q_dv, zero16, 0, 0, 0);    // -D
             const int krow = sub * 32 + swap23b(l31);
 #pragma unroll
             for (int kc = 0; kc < 4; kc++) {
                 const bf16x8 ka = *(const bf16x8*)(tb + tile_off(krow, kc * 2 + hi));
                 const bf16x8 va = *(const bf16x8*)(tb + 8192 + tile_off(krow, kc * 2 + hi));
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[kc], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qs[kc], s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[kc], dp, 0, 0, 0);
             }
 #pragma unroll
             for (int cc = 0; cc < 2; cc++) {
-                bf16x8 dsf;
+                float dsv[8];
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[cc * 8 + j], c, -lse_q));
+                    float pv = __builtin_amdgcn_exp2f(s[cc * 8 + j]);          // = exp2(score*c - lse)
                     if (tail) {
                         const int key = kv * 64 + sub * 32 + cc * 16 + 8 * hi + j;
                         if (key >= p.T) pv = 0.f;
                     }
-                    dsf[j] = (short)f2bf(pv * (dp[cc * 8 + j] - dvec_q));
+                    dsv[j] = pv * dp[cc * 8 + j];                              // P * (dP - D)
                 }
+                const uint4 dsw = make_uint4(pack_bf2(dsv[0], dsv[1]), pack_bf2(dsv[2], dsv[3]), pack_bf2(dsv[4], dsv[5]), pack_bf2(dsv[6], dsv[7]));
+                const bf16x8 dsf = __builtin_bit_cast(bf16x8, dsw);
                 const int ch = sub * 4 + cc * 2 + hi;
 #pragma unroll
                 for (int d = 0; d < 2; d++) {
