@@ -160,8 +160,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdP p) {
         const unsigned char* tb = lds + cur * BWD1_STAGE;
         const float* lse_t = (const float*)(tb + 32768);
         const float* dv_t = lse_t + 64;
+        // a wave whose 32 keys all lie beyond T (T = 2305: three of the last block's four waves) only stages and syncs
 #pragma unroll
-        for (int sub = 0; sub < 2; sub++) {
+        for (int sub = 0; sub < (k0 < p.T ? 2 : 0); sub++) {
             const int qrow = sub * 32 + swap23b(l31);
             // query-side fragments of the two constant MFMAs: this lane's A row is query `qrow` of the tile
             const bf16x8 a_lse = frag_slot01(split_hi_lo_bf16(-lse_t[qrow]), hi);
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdP p) {
 // ---- dQ ----------------------------------------------------------------------------------------------
 static constexpr int BWD2_STAGE = 3 * 8192;   // K, V, K^T tiles
 
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdP p) {
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnBwdP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -288,8 +289,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdP p) {
         if (kv + 1 < nkv) stage(cur ^ 1, kv + 1);
         const unsigned char* tb = lds + cur * BWD2_STAGE;
         const bool tail = kv * 64 + 64 > p.T;
+        // idle waves (all 32 queries beyond T) only stage and sync; a tail tile whose keys all sit in its first half skips the second
+        const int nsub = (q0 >= p.T) ? 0 : ((tail && p.T - kv * 64 <= 32) ? 1 : 2);
 #pragma unroll
-        for (int sub = 0; sub < 2; sub++) {
+        for (int sub = 0; sub < nsub; sub++) {
             f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones01, q_lse, zero16, 0, 0, 0);    // -lse of the lane's query
             f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones01, q_dv, zero16, 0, 0, 0);    // -D
             const int krow = sub * 32 + swap23b(l31);

@@ -150,9 +150,13 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
         constexpr bool MASK = decltype(mask_tag)::value;
         const unsigned char* tb = lds + BUF * 16384;
         f32x16 s[2];
+        // the partial last tile often holds very few keys (T = 2305 = 36*64 + 1): when they all sit in its first 32-key
+        // half, the second score tile is skipped altogether (its P is 0)
+        const bool half_only = MASK && (p.T - kv * 64 <= 32);
         auto qk = [&](bool sub_max) {
 #pragma unroll
             for (int t = 0; t < 2; t++) {
+                if (t == 1 && half_only) continue;
                 if (sub_max) s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kones, qneg, zero16, 0, 0, 0);    // -M everywhere
 #pragma unroll
                 for (int kc = 0; kc < 4; kc++) {
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
                         const int key = kv * 64 + t * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
-                        if (key >= p.T) s[t][r] = -INFINITY;
+                        if (key >= p.T || (t == 1 && half_only)) s[t][r] = -INFINITY;
                     }
             }
         };
@@ -214,7 +218,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
         l_part += ts;
         // ---- O^T += V^T P^T (4 chunks of 16 keys, 2 d-blocks) ----
 #pragma unroll
-        for (int t = 0; t < 2; t++)
+        for (int t = 0; t < 2; t++) {
+            if (t == 1 && half_only) continue;
 #pragma unroll
             for (int cc = 0; cc < 2; cc++) {
                 const uint4 pw = make_uint4(pack_bf2(s[t][cc * 8 + 0], s[t][cc * 8 + 1]), pack_bf2(s[t][cc * 8 + 2], s[t][cc * 8 + 3]),
@@ -227,6 +232,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
                     o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
                 }
             }
+        }
     };
 
     const int nkv = (p.T + 63) / 64;
@@ -246,23 +252,26 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
     };
     using B0 = std::integral_constant<int, 0>;
     using B1 = std::integral_constant<int, 1>;
+    // a wave whose 32 queries all lie beyond T (the last query block of T = 2305 has ONE valid query: three of its four
+    // waves) only takes part in the staging and the barriers
+    const bool active = q0 < p.T;
     int kv = 0;
     for (; kv + 1 < nfull; kv += 2) {          // two tiles per trip: buffer index is a compile-time constant
         stage(1, kv + 1);
-        tile(B0{}, kv, std::false_type{}, kv == 0);
+        if (active) tile(B0{}, kv, std::false_type{}, kv == 0);
         sync();
         if (kv + 2 < nfull) stage(0, kv + 2); else if (kv + 2 < nkv) stage_clamped(0, kv + 2);
-        tile(B1{}, kv + 1, std::false_type{}, false);
+        if (active) tile(B1{}, kv + 1, std::false_type{}, false);
         sync();
     }
     // remainder: at most one full tile and/or the partial tile, buffers alternate from (kv & 1)
     if (kv < nfull) {                           // kv even here -> buffer 0
         if (kv + 1 < nkv) stage_clamped(1, kv + 1);          // kv + 1 == nfull: the partial tile
-        tile(B0{}, kv, std::false_type{}, kv == 0);
+        if (active) tile(B0{}, kv, std::false_type{}, kv == 0);
         sync();
         kv++;
     }
-    if (kv < nkv) {
+    if (kv < nkv && active) {
         if (kv & 1) tile(B1{}, kv, std::true_type{}, false); else tile(B0{}, kv, std::true_type{}, kv == 0);
     }
     const float l_run = l_part;
