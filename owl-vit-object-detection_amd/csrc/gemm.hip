@@ -149,9 +149,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_nt_kernel(Gem
     }
 
     // bf16-output epilogues on the 256-wide tile use the register path: element-wise math, pack, v_permlane32_swap
-    // pairing -> 16-byte stores (store ISSUE is the scarce resource: ~64 cycles per wave-instruction per CU whatever
-    // its width).  Deferring those stores into the next tile's K-loop was measured and rejected: the 32-64 extra
-    // live registers cost more in the main loop (spills / just-in-time fragment loads) than the hidden issue time.
+    // pairing -> 16-byte stores.  On gfx950 vmcnt counts stores too and is in-order, so the vmcnt(0) of the next K-step
+    // drains this tile's 16 stores per wave before any new LDS-DMA can be consumed -- that drain (not the store issue
+    // itself) is the epilogue cost of this single-phase kernel; gemm_pp.hip removes most of it with counted waits.
+    // Holding the packed outputs in registers to store them during the next tile was measured and rejected (spills).
     constexpr bool WIDE = (BM == 256) && (EPI == EPI_BIAS_BF16 || EPI == EPI_QGELU_BF16 || EPI == EPI_GELU_BF16 ||
                                           EPI == EPI_DQGELU_BF16 || EPI == EPI_DGELU_BF16 || EPI == EPI_TRANS_BF16);
 

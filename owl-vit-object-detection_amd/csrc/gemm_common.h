@@ -157,12 +157,11 @@ __device__ __forceinline__ void epi_pass(const GemmP& p, const f32x16& t0, const
     }
 }
 
-// ---- register-resident bf16 epilogue of ONE 32x32 accumulator tile (deferred wide stores) --------------
-// Store instructions are issue-bound on CDNA4 (~64 cycles per wave-instruction per CU whatever the width), so
-// the bf16 epilogues (a) build 16-byte-per-lane stores: the 32x32 accumulator gives a lane 4 consecutive
-// outputs per register quad and the other half-wave the adjacent 4 -- one v_permlane32_swap per packed word
-// pairs them into 8 consecutive outputs per lane; (b) do NOT store here: the two 16-byte chunks per tile are
-// returned to the caller, which issues them a couple per K-step inside the NEXT tile's main loop.
+// ---- register-resident bf16 epilogue of ONE 32x32 accumulator tile (wide stores) -------------------------
+// The 32x32 accumulator gives a lane 4 consecutive outputs per register quad and the other half-wave the adjacent 4:
+// one v_permlane32_swap per packed word pairs them into 8 consecutive outputs per lane -> 16-byte stores (half the
+// store instructions of the natural 8-byte layout).  The two 16-byte chunks per tile are returned to the caller,
+// which issues them with epi_store_chunk.
 //   non-TRANS (swapped operands): lane owns output row m = m_tile + (lane&31); chunk c covers columns
 //       n_tile + 16*c + 8*hi + {0..7}
 //   TRANS (natural operands): lane owns output column n = n_tile + (lane&31); chunk c covers token rows
@@ -228,7 +227,7 @@ __device__ __forceinline__ void epi_tile_bf16(const GemmP& p, const f32x16& acc,
     chunk1 = make_uint4(x[2], x[3], y[2], y[3]);
 }
 
-// issue one deferred 16-byte chunk (c = 0/1 within the tile)
+// issue one 16-byte chunk (c = 0/1 within the tile)
 template <int EPI, bool GUARD>
 __device__ __forceinline__ void epi_store_chunk(const GemmP& p, const uint4& ch, int64_t m_tile, int64_t n_tile, int c, int lane) {
     const int hi = lane >> 5;
