@@ -1,0 +1,34 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from owl_vit_object_detection_amd import ops, _lib
+DEV = "cuda"
+torch.manual_seed(0)
+M = 32 * 2312
+bad = 0
+for (N, K, epi) in [(3072, 768, ops.EPI_QGELU_BF16), (768, 3072, ops.EPI_BIAS_BF16), (768, 768, ops.EPI_BIAS_BF16), (1536, 768, ops.EPI_BIAS_BF16), (768, 768, ops.EPI_TRANS_BF16)]:
+    A = torch.randn(ops.pad_rows(M), K, device=DEV).bfloat16()
+    W = (torch.randn(N, K, device=DEV) * 0.05).bfloat16(); bias = torch.randn(N, device=DEV)
+    big = torch.empty(256 * 1024 * 1024, device=DEV, dtype=torch.uint8)
+    def run(tile):
+        _lib.call("owl_gemm_set_tile", tile)
+        if epi == ops.EPI_TRANS_BF16:
+            out = torch.zeros(32 * N * 2312 + 256, device=DEV, dtype=torch.bfloat16)
+            ops.gemm(epi, A, W, out, bias=bias, M=M, N=N, K=K, Tp=2312)
+        else:
+            out = torch.zeros(ops.pad_rows(M), N, device=DEV, dtype=torch.bfloat16)
+            ops.gemm(epi, A, W, out, bias=bias, M=M)
+        _lib.call("owl_gemm_set_tile", 0)
+        return out
+    ref = run(256)
+    s2 = torch.cuda.Stream()
+    for it in range(150):
+        with torch.cuda.stream(s2):
+            big.add_(1)                      # concurrent HBM traffic on another stream
+        got = run(8)
+        if not torch.equal(got, ref):
+            bad += 1
+            print("MISMATCH", N, K, epi, it, (got.float() - ref.float()).abs().max().item())
+    torch.cuda.synchronize()
+    print("shape", N, K, epi, "done", flush=True)
+print("mismatches:", bad)
