@@ -83,3 +83,71 @@ extern "C" int owl_preprocess_u8(void* stream, const unsigned char* src_hwc, int
     OWL_LAUNCH_CHECK();
     return 0;
 }
+
+
+// ---- batched form: one launch pair for a ragged batch (the per-image form above is launch-bound: 2 launches per image) ----
+// desc[i] = {src, H, W, bounds_x, kk_x, ksize_x, bounds_y, kk_y, ksize_y, tmp byte offset} as 10 int64 (device memory)
+struct PreDesc { const unsigned char* src; long long H, W; const int* bx; const int* kx; long long ksx; const int* by; const int* ky; long long ksy; long long tmp_off; };
+
+__global__ __launch_bounds__(256) void pp_resize_h_batch_kernel(const PreDesc* __restrict__ desc, unsigned char* __restrict__ tmp_base, int out_w) {
+    const PreDesc d = desc[blockIdx.z];
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= out_w || y >= d.H) return;
+    const int xmin = d.bx[2 * x], n = d.bx[2 * x + 1];
+    const int* k = d.kx + (int64_t)x * d.ksx;
+    const unsigned char* row = d.src + ((int64_t)y * d.W + xmin) * 3;
+    int s0 = 1 << (PIL_PRECISION_BITS - 1), s1 = s0, s2 = s0;
+    for (int t = 0; t < n; t++) {
+        const int w = k[t];
+        s0 += (int)row[3 * t] * w;
+        s1 += (int)row[3 * t + 1] * w;
+        s2 += (int)row[3 * t + 2] * w;
+    }
+    unsigned char* o = tmp_base + d.tmp_off + ((int64_t)y * out_w + x) * 3;
+    o[0] = pil_clip8(s0); o[1] = pil_clip8(s1); o[2] = pil_clip8(s2);
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void pp_resize_v_batch_kernel(const PreDesc* __restrict__ desc, const unsigned char* __restrict__ tmp_base,
+                                                                void* __restrict__ out, const float* __restrict__ lut, int out_h, int out_w) {
+    const PreDesc d = desc[blockIdx.z];
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= out_w) return;
+    const int ymin = d.by[2 * y], n = d.by[2 * y + 1];
+    const int* k = d.ky + (int64_t)y * d.ksy;
+    const unsigned char* col = tmp_base + d.tmp_off + ((int64_t)ymin * out_w + x) * 3;
+    const int64_t stride = (int64_t)out_w * 3;
+    int s0 = 1 << (PIL_PRECISION_BITS - 1), s1 = s0, s2 = s0;
+    for (int t = 0; t < n; t++) {
+        const int w = k[t];
+        s0 += (int)col[t * stride] * w;
+        s1 += (int)col[t * stride + 1] * w;
+        s2 += (int)col[t * stride + 2] * w;
+    }
+    const float v0 = lut[pil_clip8(s0)], v1 = lut[256 + pil_clip8(s1)], v2 = lut[512 + pil_clip8(s2)];
+    const int64_t plane = (int64_t)out_h * out_w, o = (int64_t)blockIdx.z * 3 * plane + (int64_t)y * out_w + x;
+    if (BF16) {
+        bf16_t* p = (bf16_t*)out;
+        p[o] = f2bf(v0); p[plane + o] = f2bf(v1); p[2 * plane + o] = f2bf(v2);
+    } else {
+        float* p = (float*)out;
+        p[o] = v0; p[plane + o] = v1; p[2 * plane + o] = v2;
+    }
+}
+
+extern "C" int owl_preprocess_u8_batch(void* stream, const void* desc, int64_t n_images, int64_t max_h, unsigned char* tmp, const float* lut,
+                                       void* out, int out_bf16, int64_t out_h, int64_t out_w) {
+    OWL_CHECK_ARG(desc && tmp && lut && out, "owl_preprocess_u8_batch: null pointer");
+    OWL_CHECK_ARG(n_images > 0 && n_images < 65536 && max_h > 0 && max_h < 65536 && out_h > 0 && out_h < 65536 && out_w > 0,
+                  "owl_preprocess_u8_batch: bad sizes n=%lld max_h=%lld out=%lldx%lld", (long long)n_images, (long long)max_h, (long long)out_h, (long long)out_w);
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned gx = (unsigned)((out_w + 255) / 256);
+    hipLaunchKernelGGL(pp_resize_h_batch_kernel, dim3(gx, (unsigned)max_h, (unsigned)n_images), dim3(256), 0, s, (const PreDesc*)desc, tmp, (int)out_w);
+    OWL_LAUNCH_CHECK();
+    if (out_bf16)
+        hipLaunchKernelGGL((pp_resize_v_batch_kernel<true>), dim3(gx, (unsigned)out_h, (unsigned)n_images), dim3(256), 0, s, (const PreDesc*)desc, tmp, out, lut, (int)out_h, (int)out_w);
+    else
+        hipLaunchKernelGGL((pp_resize_v_batch_kernel<false>), dim3(gx, (unsigned)out_h, (unsigned)n_images), dim3(256), 0, s, (const PreDesc*)desc, tmp, out, lut, (int)out_h, (int)out_w);
+    OWL_LAUNCH_CHECK();
+    return 0;
+}

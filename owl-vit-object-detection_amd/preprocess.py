@@ -54,27 +54,33 @@ class DeviceImageProcessor:
             self._tables[key] = (bounds.to(self.device), kk.to(self.device), ksize)
         return self._tables[key]
 
-    def _one(self, img, out):
+    def _to_device(self, img):
         if isinstance(img, np.ndarray):
             img = torch.from_numpy(np.ascontiguousarray(img))
         elif not torch.is_tensor(img):                       # PIL.Image without importing PIL here
             img = torch.from_numpy(np.ascontiguousarray(np.asarray(img.convert("RGB") if hasattr(img, "convert") else img)))
         if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != 3:
             raise ValueError(f"DeviceImageProcessor: expected an RGB uint8 [H,W,3] image, got {img.dtype} {tuple(img.shape)}")
-        img = img.to(self.device, non_blocking=True).contiguous()
-        H, W = int(img.shape[0]), int(img.shape[1])
-        bx, kx, ksx = self._axis_tables(W)
-        by, ky, ksy = self._axis_tables(H)
-        need = H * self.size * 3
-        if self._tmp is None or self._tmp.numel() < need:
-            self._tmp = torch.empty(need, dtype=torch.uint8, device=self.device)
-        _lib.call("owl_preprocess_u8", ops.stream(), img, H, W, bx, kx, ksx, by, ky, ksy, self._tmp, self.lut, out,
-                  1 if self.dtype == torch.bfloat16 else 0, self.size, self.size)
+        return img.to(self.device, non_blocking=True).contiguous()
 
     def __call__(self, images, return_tensors="pt", **_):
         single = not isinstance(images, (list, tuple))
-        imgs = [images] if single else list(images)
-        out = torch.empty(len(imgs), 3, self.size, self.size, dtype=self.dtype, device=self.device)
-        for i, im in enumerate(imgs):
-            self._one(im, out[i])
+        imgs = [self._to_device(im) for im in ([images] if single else list(images))]
+        n = len(imgs)
+        out = torch.empty(n, 3, self.size, self.size, dtype=self.dtype, device=self.device)
+        # one launch pair for the whole (ragged) batch: a 10-int64 descriptor per image
+        rows, off, max_h = [], 0, 0
+        for im in imgs:
+            H, W = int(im.shape[0]), int(im.shape[1])
+            bx, kx, ksx = self._axis_tables(W)
+            by, ky, ksy = self._axis_tables(H)
+            rows.append((im.data_ptr(), H, W, bx.data_ptr(), kx.data_ptr(), ksx, by.data_ptr(), ky.data_ptr(), ksy, off))
+            off += (H * self.size * 3 + 255) // 256 * 256
+            max_h = max(max_h, H)
+        if self._tmp is None or self._tmp.numel() < off:
+            self._tmp = torch.empty(off, dtype=torch.uint8, device=self.device)
+        desc_d = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(self.device, non_blocking=True)
+        _lib.call("owl_preprocess_u8_batch", ops.stream(), desc_d, n, max_h, self._tmp, self.lut, out,
+                  1 if self.dtype == torch.bfloat16 else 0, self.size, self.size)
+        self._keep = (imgs, desc_d)          # keep the sources alive until the stream has consumed them
         return {"pixel_values": out}

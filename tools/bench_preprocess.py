@@ -13,12 +13,12 @@ for (S, dtype) in [(768, torch.bfloat16), (768, torch.float32), (840, torch.bflo
     pin = [torch.from_numpy(i).pin_memory() for i in imgs]
     ip = DeviceImageProcessor(size=S, dtype=dtype)
     for src, tag in ((dev, "HBM-resident"), (pin, "pinned host (PCIe incl.)")):
-        for _ in range(2): ip(images=src)
+        for _ in range(5): ip(images=src)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(10): ip(images=src)
+        for _ in range(20): ip(images=src)
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 10
+        dt = (time.perf_counter() - t0) / 20
         alg = 32 * (480 * 640 * 3 + 3 * S * S * (2 if dtype == torch.bfloat16 else 4))
         print(f"S={S} {dtype}: {tag}: {dt*1e3:.2f} ms / 32 images = {32/dt:.0f} img/s; algorithmic {alg/dt/1e9:.1f} GB/s", flush=True)
 t0 = time.perf_counter(); O.preprocess_image(imgs[0], 768); print(f"CPU oracle (numpy): {(time.perf_counter()-t0)*1e3:.0f} ms/img")
