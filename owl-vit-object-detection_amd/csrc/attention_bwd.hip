@@ -57,24 +57,26 @@ __device__ __forceinline__ bf16x8 scale_frag(bf16x8 f, float c) {
 }
 
 __global__ __launch_bounds__(256) void attn_dvec_kernel(AttnBwdP p) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;       // over B*Tp*H
-    const int64_t nrow = (int64_t)p.Tp * p.H;
-    const int64_t b = i / nrow;
-    if (b >= p.B) return;
-    const int64_t rem = i - b * nrow;
-    const int t = (int)(rem / p.H), h = (int)(rem - (int64_t)t * p.H);
+    // D[b,h,t] = sum_d dO[b,t,h,d] * O[b,t,h,d].  One thread per 16-byte chunk (8 elements) of a token row, consecutive
+    // threads on consecutive chunks (fully coalesced; the first version gave a thread a whole 128-byte head segment and
+    // over-fetched 7x by FETCH_SIZE); the 8 chunks of a head are 8 adjacent lanes -> three xor-shuffles.
+    const int cpr = p.D / 8;                                            // chunks per row
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // over B*Tp*cpr (cpr is a multiple of 8)
+    const int64_t row = i / cpr;
+    const int ci = (int)(i - row * cpr);
     float acc = 0.f;
-    if (t < p.T) {
-        const bf16_t* a = p.dO + ((int64_t)b * p.Tp + t) * p.ld_do + h * 64;
-        const bf16_t* o = p.O + ((int64_t)b * p.Tp + t) * p.ld_do + h * 64;
+    const bool ok = row < (int64_t)p.B * p.Tp;
+    const int64_t b = ok ? row / p.Tp : 0;
+    const int t = ok ? (int)(row - b * p.Tp) : 0;
+    if (ok && t < p.T) {
+        const us8 av = *(const us8*)(p.dO + row * p.ld_do + ci * 8), ov = *(const us8*)(p.O + row * p.ld_do + ci * 8);
 #pragma unroll
-        for (int c = 0; c < 8; c++) {
-            const us8 av = *(const us8*)(a + c * 8), ov = *(const us8*)(o + c * 8);
-#pragma unroll
-            for (int e = 0; e < 8; e++) acc += bf2f(av[e]) * bf2f(ov[e]);
-        }
+        for (int e = 0; e < 8; e++) acc += bf2f(av[e]) * bf2f(ov[e]);
     }
-    p.dvec[((int64_t)b * p.H + h) * p.Tp + t] = acc;
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (ok && (ci & 7) == 0) p.dvec[((int64_t)b * p.H + (ci >> 3)) * p.Tp + t] = acc;
 }
 
 // ---- dK, dV ------------------------------------------------------------------------------------------
@@ -85,8 +87,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdP p) {
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int hi = lane >> 5, l31 = lane & 31;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int k0 = blockIdx.x * 128 + w * 32;
+    // XCD-aware 1-D grid (workgroups id, id+8, ... share an XCD / L2): every key block of one (image, head) runs on the
+    // same XCD, so the Q / dO / Q^T / dO^T tiles it streams (1.2 MB per pair at T = 2305) are fetched into ONE L2 instead
+    // of all eight (FETCH_SIZE of the first version: 6x the algorithmic bytes)
+    const int nblk = (p.T + 127) / 128;
+    const int pair = ((int)(blockIdx.x >> 3) / nblk) * 8 + (int)(blockIdx.x & 7);
+    if (pair >= p.B * p.H) return;
+    const int blk = (int)(blockIdx.x >> 3) % nblk;
+    const int h = pair % p.H, b = pair / p.H;
+    const int k0 = blk * 128 + w * 32;
     const float c = p.scale_log2e;
     const int D = p.D;
 
@@ -230,8 +239,12 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnBwdP p) {
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int hi = lane >> 5, l31 = lane & 31;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * 128 + w * 32;
+    const int nblk = (p.T + 127) / 128;                          // XCD-aware 1-D grid, as in the dK/dV kernel
+    const int pair = ((int)(blockIdx.x >> 3) / nblk) * 8 + (int)(blockIdx.x & 7);
+    if (pair >= p.B * p.H) return;
+    const int blk = (int)(blockIdx.x >> 3) % nblk;
+    const int h = pair % p.H, b = pair / p.H;
+    const int q0 = blk * 128 + w * 32;
     const float c = p.scale_log2e;
     const int D = p.D;
 
@@ -363,10 +376,11 @@ extern "C" int owl_attention_bwd_bf16(void* stream, const void* qkv, const void*
         (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BWD2_STAGE);
         attr_done = true;
     }
-    const int64_t nd = B * Tp * H;
+    const int64_t nd = B * Tp * (H * 8);                       // one thread per 16-byte chunk
     hipLaunchKernelGGL(attn_dvec_kernel, dim3((unsigned)((nd + 255) / 256), 1, 1), dim3(256), 0, s, p);
     OWL_LAUNCH_CHECK();
-    dim3 grid((unsigned)((T + 127) / 128), (unsigned)H, (unsigned)B);
+    const int64_t npairs8 = (B * H + 7) / 8;                  // (image, head) pairs per XCD, rounded up
+    dim3 grid((unsigned)(npairs8 * ((T + 127) / 128) * 8));
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(256), 2 * BWD1_STAGE, s, p);
     OWL_LAUNCH_CHECK();
     hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 2 * BWD2_STAGE, s, p);
