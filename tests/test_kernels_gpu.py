@@ -311,3 +311,14 @@ def test_gemm_tn_slab_weight_gradient(rows, n_out, n_in, splits):
     cs = torch.zeros(n_out, device=DEV)
     ops.colsum_bf16(dy, cs, rows, n_out)
     assert (cs - dy[:rows].float().sum(0)).abs().max().item() <= 1e-3 * rows ** 0.5 + 1e-3
+
+
+@pytest.mark.parametrize("R,C", [(73984, 768), (1000, 512), (37, 4), (2312, 1024)])
+def test_colsum_f32(R, C):
+    from owl_vit_object_detection_amd import _lib
+    torch.manual_seed(R)
+    x = torch.randn(R, C, device=DEV)
+    out = torch.full((C,), 0.5, device=DEV)
+    _lib.call("owl_colsum_f32", ops.stream(), x, out, R, C)
+    ref = 0.5 + x.double().sum(0)
+    assert (out.double() - ref).abs().max().item() <= 1e-4 * R ** 0.5 + 1e-4
