@@ -247,8 +247,8 @@ __global__ __launch_bounds__(256) void class_sims_bwd_kernel(const float* __rest
     for (int i = threadIdx.x; i < 32 * (Dt >> 2); i += 256) ((float4*)lq)[i] = ((const float4*)qhat)[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t row0 = ((int64_t)blockIdx.x * 4 + w) * 16;
-    for (int64_t r = row0; r < min(rows, row0 + 16); r++) {
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + w) * 36;     // 144 rows per workgroup: the 64 KiB query table is loaded once per 144 rows
+    for (int64_t r = row0; r < min(rows, row0 + 36); r++) {
         const float inv = inv_norm[r];
         // lanes 0..31 <-> query j
         float gj = 0.f, gs = 0.f;
@@ -300,7 +300,7 @@ extern "C" int owl_class_sims_bwd(void* stream, const float* dsims, const float*
     OWL_CHECK_ARG(shmem <= 150 * 1024, "owl_class_sims_bwd: Dt too large for LDS");
     static bool attr_done = false;
     if (!attr_done) { (void)hipFuncSetAttribute((const void*)class_sims_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_done = true; }
-    hipLaunchKernelGGL(class_sims_bwd_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(256), shmem, (hipStream_t)stream, dsims, sims, argmax,
+    hipLaunchKernelGGL(class_sims_bwd_kernel, dim3((unsigned)((rows + 143) / 144)), dim3(256), shmem, (hipStream_t)stream, dsims, sims, argmax,
                        inv_norm, e, qhat32, (bf16_t*)de_bf16, (bf16_t*)g_bf16, (bf16_t*)e_bf16, rows, (int)Dt, (int)C);
     OWL_LAUNCH_CHECK();
     return 0;
