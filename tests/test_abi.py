@@ -38,3 +38,28 @@ def test_argument_validation_sets_error_without_gpu(built):
     with pytest.raises(_lib.OwlLibError, match="null pointer"):
         _lib.call("owl_gemm_nt_bf16", None, 0, None, 0, 0, None, 0, 0, None, None, 0, None, None, 0, 1, 4, 64, 1.0, 1, 0)
     assert "null pointer" in _lib.last_error()
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No CPU / eager fallback: without libowlhip.so every op raises (the product path never routes through the oracle)."""
+    from owl_vit_object_detection_amd import _lib as L
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "libowlhip.so"))
+    with pytest.raises(L.OwlLibError, match="no CPU fallback|not found"):
+        L.load()
+    with pytest.raises(L.OwlLibError):
+        L.call("owl_abi_version")
+
+
+def test_product_package_never_imports_the_oracle():
+    """Only tests/, selftest.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    import os
+    import re
+    pkg = os.path.dirname(os.path.abspath(__import__("owl_vit_object_detection_amd").__file__))
+    offenders = []
+    for fn in sorted(os.listdir(pkg)):
+        if fn.endswith(".py") and fn != "selftest.py":
+            src = open(os.path.join(pkg, fn)).read()
+            if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
+                offenders.append(fn)
+    assert offenders == []
