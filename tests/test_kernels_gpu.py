@@ -44,7 +44,7 @@ def gemm_tile(request):
     _lib.call("owl_gemm_set_tile", 0)
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 192, 128), (2048, 768, 768), (128, 128, 64), (1000, 3072, 256)])
+@pytest.mark.parametrize("M,N,K", [(300, 192, 128), (2048, 768, 768), (128, 128, 64), (1000, 3072, 256), (1000, 328, 256), (777, 264, 128)])
 def test_gemm_bias_bf16(M, N, K, gemm_tile):
     A = ops.zeros_rows(M, K, torch.bfloat16, DEV)
     A[:M] = rnd(M, K).bfloat16()
