@@ -63,9 +63,13 @@ __global__ __launch_bounds__(512) void gemm_tn_slab_kernel(TnP p) {
 
     int64_t n0, k0;
     int split, kt0, kt1;
+    // items are split-major: consecutive items (= the workgroups of one XCD at any time) are different output tiles of
+    // the SAME token range, so the dY / X rows they stream are shared through that XCD's L2 (tile-major order read every
+    // operand byte ~2x: FETCH_SIZE 1.0 GB per launch at 4.6 TB/s)
+    const int ntiles = p.tiles_n * p.tiles_k;
     auto decode = [&](int it) {
-        const int tile = it / p.nsplit;
-        split = it - tile * p.nsplit;
+        split = it / ntiles;
+        const int tile = it - split * ntiles;
         const int tn = tile / p.tiles_k, tk = tile - tn * p.tiles_k;
         n0 = (int64_t)tn * 256; k0 = (int64_t)tk * 256;
         kt0 = split * p.kt_per_split;
