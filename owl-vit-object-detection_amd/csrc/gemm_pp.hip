@@ -133,6 +133,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
 
     int cur = 0, tile_parity = 0;
     int pending_stores = 0;          // epilogue stores issued after the newest in-flight K-tile's DMA (0 or 16)
+    bool deferred_A = false;         // TRANS: the A pieces of the K-tile after next wait for the epilogue to release its staging area
     while (true) {
         f32x16 acc[4][2];
 #pragma unroll
@@ -187,14 +188,20 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
             pp_wait_lgkm(); pp_bar();
             mma(1, 1);
             pp_bar();
-            // ---- q3: A rows are free; retire K-tile kt+1, leave kt+2 in flight ----
-            if (live) { stage_A(); n_new += 4; }
+            // ---- q3: A rows are free; retire K-tile kt+1, leave kt+2 in flight.  The transposing epilogue borrows this
+            //      buffer's A rows as its staging area, so at a tile's last K-tile it defers the A pieces until after it ----
+            if (live && !(TRANS && kt + 1 == nk)) { stage_A(); n_new += 4; }
+            else if (live) deferred_A = true;
             {
                 const int total = n_new + pending_stores;
                 if (total == 8) pp_wait<8>();
                 else if (total == 9) pp_wait<9>();
                 else if (total == 24) pp_wait<24>();
                 else if (total == 25) pp_wait<25>();
+                else if (total == 4) pp_wait<4>();
+                else if (total == 5) pp_wait<5>();
+                else if (total == 20) pp_wait<20>();
+                else if (total == 21) pp_wait<21>();
                 else pp_wait<0>();
                 pending_stores = 0;
             }
@@ -205,7 +212,50 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
         }
         if (grp == 0) pp_bar();                       // let group 1 finish its last MFMA half: epilogues run together
         const bool inner = (cm0 + PBM <= p.M) && (cn0 + PBN <= p.N);
-        {
+        if constexpr (TRANS) {
+            // Per-head transposed store out_t[b][n][t]: written straight from the accumulators a lane's 16-byte pieces land
+            // in 32 different 64-byte sectors per instruction (WRITE_SIZE 1.45x the output).  Instead each wave stages a
+            // [32 n][64 t] bf16 image (16-byte chunks XOR-swizzled by n&7) in its 4 KiB of the A rows this tile no longer
+            // needs and writes it back as 8 rows x 128 contiguous bytes per instruction.
+            unsigned char* img = lds + s_buf * P_STAGE + w * 4096;
+            const float* lbias = (const float*)(lds + P_BIAS_OFF + tile_parity * 1024) + wc * 64;
+            const int n_l = lane & 31;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                float bv = 0.f;
+                if (p.bias) bv = lds_read_f1(lbias + j * 32 + n_l);
+#pragma unroll
+                for (int ip = 0; ip < 2; ip++) {
+                    // accumulator register r of tile ti: token 8*(r>>2) + 4*hi + (r&3) of its 32, column n_l
+#pragma unroll
+                    for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+                        for (int qd = 0; qd < 4; qd++) {
+                            const f32x16& a = acc[2 * ip + ti][j];
+                            uint2 v;
+                            v.x = pack_bf2(a[qd * 4 + 0] + bv, a[qd * 4 + 1] + bv);
+                            v.y = pack_bf2(a[qd * 4 + 2] + bv, a[qd * 4 + 3] + bv);
+                            *(uint2*)(img + n_l * 128 + (((ti * 4 + qd) ^ (n_l & 7)) << 4) + hi * 8) = v;
+                        }
+                    const int64_t m_base = cm0 + grp * 128 + ip * 64;
+                    const int64_t n_base = cn0 + wc * 64 + j * 32;
+#pragma unroll
+                    for (int it = 0; it < 4; it++) {
+                        const int nr = it * 8 + (lane >> 3), c16 = lane & 7;
+                        const f32x4 raw = lds_read_f4(img + nr * 128 + ((c16 ^ (nr & 7)) << 4));
+                        const int64_t n = n_base + nr, m = m_base + c16 * 8;
+                        if (n < p.N && m < p.M) {
+                            const int64_t bimg = m / p.Tp, t = m - bimg * p.Tp;
+                            *(f32x4*)((bf16_t*)p.out + (bimg * p.N + n) * p.Tp + t) = raw;
+                        }
+                    }
+                }
+            }
+            // the staging slices are wave-private, but the deferred DMA below is partitioned differently: everybody must be done
+            pp_wait_lgkm();
+            pp_bar();
+            if (deferred_A) { stage_A(); deferred_A = false; }
+        } else {
             const float* lbias = (const float*)(lds + P_BIAS_OFF + tile_parity * 1024) + wc * 64;
             auto run = [&](auto guard_tag) {
                 constexpr bool G = decltype(guard_tag)::value;
@@ -226,8 +276,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
         if (item >= item_end) break;
         tile_parity ^= 1;
         // counted wait across the epilogue is only valid when this wave really issued its 16 stores (plain inner tiles)
-        pending_stores = (inner && (EPI == EPI_BIAS_BF16 || EPI == EPI_QGELU_BF16 || EPI == EPI_TRANS_BF16) && !p.aux) ? 16 : 0;
-        if (pending_stores == 0) pp_wait<0>();        // otherwise drain now: later counted waits assume nothing unknown is pending
+        pending_stores = (inner && (EPI == EPI_BIAS_BF16 || EPI == EPI_QGELU_BF16) && !p.aux) ? 16 : 0;    // (TRANS: its stores precede the deferred A pieces)
+        if (pending_stores == 0 && !TRANS) pp_wait<0>();   // otherwise drain now: later counted waits assume nothing unknown is pending
+                                                             // (TRANS: the stores are older than the deferred A pieces every later wait retires)
     }
 }
 
