@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--forward-only", action="store_true", help="BASELINE configs[1]-style forward throughput (diagnostic)")
+    ap.add_argument("--gemm-tile", type=int, default=0, help="owl_gemm_set_tile override (tuning A/B only; 0 = automatic)")
     return ap.parse_args()
 
 
@@ -97,6 +98,9 @@ def main():
     from owl_vit_object_detection_amd.losses import PushPullLoss
     from owl_vit_object_detection_amd.models import OwlViT
     from owl_vit_object_detection_amd.optim import FusedAdamW
+    if args.gemm_tile:
+        from owl_vit_object_detection_amd import _lib
+        _lib.call("owl_gemm_set_tile", args.gemm_tile)
     from owl_vit_object_detection_amd import synth
 
     rank, world, local = ddp.init_from_env("nccl")

@@ -297,7 +297,10 @@ int owl_gemm_pp_launch(hipStream_t s, int epi, const GemmP& p, int slots_overrid
 
 template <int EPI>
 static int launch(hipStream_t s, const GemmP& p, int splits) {
-    const bool big = g_force_tile ? (g_force_tile == 256) : (p.M >= 512 && p.N >= 256);
+    // 256-wide tiles only when they give the chip enough work items (batch-1 out-proj is 10 x 3 of them: the 128x128
+    // kernel's 114 tiles finish sooner)
+    const int64_t t256 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    const bool big = g_force_tile ? (g_force_tile == 256) : (p.M >= 512 && p.N >= 256 && t256 >= 48);
     if (big) return launch_cfg<EPI, 256, 256, 128, 64>(s, p, splits);
     return launch_cfg<EPI, 128, 128, 64, 64>(s, p, splits);
 }
@@ -326,7 +329,7 @@ extern "C" int owl_gemm_nt_bf16(void* stream, int epi, const void* A, int64_t ld
     const bool split_ok = (epi == EPI_ATOMIC_F32 || epi == EPI_SLAB_F32);
     OWL_CHECK_ARG(splits == 1 || split_ok, "owl_gemm_nt_bf16: split-K needs the atomic or slab epilogue");
     // bf16-output epilogues on big problems run the ping-pong schedule (gemm_pp.hip): 13-26 % faster, bit-identical
-    const bool pp_auto = (g_force_tile == 0 && M >= 512 && N >= 256);
+    const bool pp_auto = (g_force_tile == 0 && M >= 512 && N >= 256 && ((M + 255) / 256) * ((N + 255) / 256) >= 48);
     if ((g_force_tile == 8 || pp_auto) && K >= 128 && (epi != EPI_TRANS_BF16 || (Tp > 0 && Tp % 4 == 0 && N % 64 == 0)) &&
         ((epi != EPI_DQGELU_BF16 && epi != EPI_DGELU_BF16) || aux)) {
         const int rc = owl_gemm_pp_launch(s, epi, p, g_debug_slots, g_persistent, g_debug_nostore);
