@@ -242,13 +242,15 @@ extern "C" int owl_merge_ln_bwd(void* stream, const float* dfeats, const float* 
 __global__ __launch_bounds__(256) void class_sims_bwd_kernel(const float* __restrict__ dsims, const float* __restrict__ sims,
                                                              const unsigned char* __restrict__ argmax, const float* __restrict__ inv_norm,
                                                              const float* __restrict__ e, const float* __restrict__ qhat, bf16_t* de,
-                                                             bf16_t* G, bf16_t* e_bf16, int64_t rows, int Dt, int C) {
+                                                             bf16_t* G, bf16_t* e_bf16, int64_t rows, int Dt, int C, int rows_per_wave) {
     extern __shared__ __attribute__((aligned(16))) float lq[];     // qhat [32][Dt]
     for (int i = threadIdx.x; i < 32 * (Dt >> 2); i += 256) ((float4*)lq)[i] = ((const float4*)qhat)[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t row0 = ((int64_t)blockIdx.x * 4 + w) * 36;     // 144 rows per workgroup: the 64 KiB query table is loaded once per 144 rows
-    for (int64_t r = row0; r < min(rows, row0 + 36); r++) {
+    // the 64 KiB query table is loaded once per workgroup: many rows per workgroup at large batch (36 per wave), fewer when
+    // that would leave most CUs idle (batch 1)
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + w) * rows_per_wave;
+    for (int64_t r = row0; r < min(rows, row0 + rows_per_wave); r++) {
         const float inv = inv_norm[r];
         // lanes 0..31 <-> query j
         float gj = 0.f, gs = 0.f;
@@ -300,8 +302,10 @@ extern "C" int owl_class_sims_bwd(void* stream, const float* dsims, const float*
     OWL_CHECK_ARG(shmem <= 150 * 1024, "owl_class_sims_bwd: Dt too large for LDS");
     static bool attr_done = false;
     if (!attr_done) { (void)hipFuncSetAttribute((const void*)class_sims_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_done = true; }
-    hipLaunchKernelGGL(class_sims_bwd_kernel, dim3((unsigned)((rows + 143) / 144)), dim3(256), shmem, (hipStream_t)stream, dsims, sims, argmax,
-                       inv_norm, e, qhat32, (bf16_t*)de_bf16, (bf16_t*)g_bf16, (bf16_t*)e_bf16, rows, (int)Dt, (int)C);
+    int rpw = (int)((rows + 4 * 512 - 1) / (4 * 512));           // aim at >= 512 workgroups ...
+    rpw = rpw < 4 ? 4 : (rpw > 36 ? 36 : rpw);                   // ... with 16..144 rows each
+    hipLaunchKernelGGL(class_sims_bwd_kernel, dim3((unsigned)((rows + 4 * rpw - 1) / (4 * rpw))), dim3(256), shmem, (hipStream_t)stream, dsims, sims, argmax,
+                       inv_norm, e, qhat32, (bf16_t*)de_bf16, (bf16_t*)g_bf16, (bf16_t*)e_bf16, rows, (int)Dt, (int)C, rpw);
     OWL_LAUNCH_CHECK();
     return 0;
 }

@@ -168,25 +168,58 @@ __global__ __launch_bounds__(1024) void spread_kernel(const float* __restrict__ 
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     float4* bx = (float4*)sm;          // [P]
     int* tc = (int*)(bx + P);          // [P]
+    // The reference's loop visits p = 0..P-1 in order and acts only on rows that are (by then) non-background.  Reading
+    // tc[p] one row at a time costs an LDS round trip per row (2304 x ~100 cycles = the whole kernel); instead a bit mask
+    // of the non-background rows is kept in LDS and the NEXT such row >= p is found by one wave (64 mask words per probe).
+    // Rows relabelled behind the cursor are, as in the reference, not revisited; rows relabelled ahead of it are.
+    __shared__ unsigned posmask[256];  // P <= 8192
+    __shared__ int next_s;
     const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+    const int nwords = (P + 31) >> 5;
     int64_t* tcg = target_classes + (int64_t)b * P;
-    for (int r = tid; r < P; r += NT) { bx[r] = *(const float4*)(boxes + ((int64_t)b * P + r) * 4); tc[r] = (int)tcg[r]; }
+    for (int i = tid; i < nwords; i += NT) posmask[i] = 0u;
     __syncthreads();
-    for (int p = 0; p < P; p++) {
-        const int lab = tc[p];
-        if (lab == bg) continue;       // uniform: everyone reads the same word after the last barrier
-        const float4 a = bx[p];
+    for (int r = tid; r < P; r += NT) {
+        bx[r] = *(const float4*)(boxes + ((int64_t)b * P + r) * 4);
+        const int t = (int)tcg[r];
+        tc[r] = t;
+        if (t != bg) atomicOr(&posmask[r >> 5], 1u << (r & 31));
+    }
+    __syncthreads();
+    int p = 0;
+    while (true) {
+        if (tid < 64) {                // wave 0: first set bit at position >= p
+            int found = -1;
+            for (int w0 = p >> 5; w0 < nwords && found < 0; w0 += 64) {
+                const int wi = w0 + tid;
+                unsigned m = wi < nwords ? posmask[wi] : 0u;
+                if (wi == (p >> 5)) m &= ~0u << (p & 31);
+                const unsigned long long any = __ballot(m != 0u);
+                if (any) {
+                    const int l = __ffsll((long long)any) - 1;
+                    const unsigned ml = (unsigned)__shfl((int)m, l, 64);
+                    found = (w0 + l) * 32 + (__ffs((int)ml) - 1);
+                }
+            }
+            if (tid == 0) next_s = found;
+        }
+        __syncthreads();
+        const int cur = next_s;
+        if (cur < 0) break;            // uniform
+        const int lab = tc[cur];
+        const float4 a = bx[cur];
         const float area_a = (a.z - a.x) * (a.w - a.y);
-        __syncthreads();               // all threads have read tc[p] before anyone rewrites it
+        __syncthreads();               // everybody has read next_s / tc[cur] before anyone rewrites them
         for (int r = tid; r < P; r += NT) {
             const float4 q = bx[r];
             const float area_q = (q.z - q.x) * (q.w - q.y);
             const float w = fmaxf(fminf(a.z, q.z) - fmaxf(a.x, q.x), 0.f), h = fmaxf(fminf(a.w, q.w) - fmaxf(a.y, q.y), 0.f);
             const float inter = w * h;
             const float uni = area_a + area_q - inter;
-            if (inter / uni > thr) tc[r] = lab;
+            if (inter / uni > thr) { tc[r] = lab; atomicOr(&posmask[r >> 5], 1u << (r & 31)); }
         }
         __syncthreads();
+        p = cur + 1;
     }
     for (int r = tid; r < P; r += NT) tcg[r] = tc[r];
 }
@@ -383,9 +416,9 @@ extern "C" int owl_hungarian(void* stream, const float* costT, const int64_t* la
 extern "C" int owl_spread_labels(void* stream, const float* boxes, int64_t* target_classes, int64_t B, int64_t P, int64_t bg, float thr) {
     OWL_CHECK_ARG(boxes && target_classes, "owl_spread_labels: null pointer");
     const size_t sh = (size_t)P * 20;
-    OWL_CHECK_ARG(sh <= 160 * 1024 - 256, "owl_spread_labels: P too large");
+    OWL_CHECK_ARG(sh <= 156 * 1024 && P <= 8192, "owl_spread_labels: P too large");
     static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute((const void*)spread_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); attr_done = true; }
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)spread_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024); attr_done = true; }
     hipLaunchKernelGGL(spread_kernel, dim3((unsigned)B), dim3(1024), sh, (hipStream_t)stream, boxes, target_classes, (int)P, (int)bg, thr);
     OWL_LAUNCH_CHECK();
     return 0;
