@@ -388,13 +388,18 @@ __global__ __launch_bounds__(256) void box_final_bwd_kernel(const float* __restr
 
 // partials: f32 workspace [owl_box_final_bwd_blocks(rows)][4*D + 4]; dw2 [4,D] and db2 [4] must be CONTIGUOUS
 // (dw2 followed by db2, as in the flat gradient bucket) -- they are accumulated by one deterministic reduce.
-extern "C" int owl_box_final_bwd_blocks(int64_t rows) { return (int)((rows + 63) / 64); }
+// rows per workgroup: 64 at large batch, down to 8 when that would leave most CUs idle (batch 1: 2304 rows)
+static int box_bwd_rpb(int64_t rows) {
+    int64_t r = (rows + 511) / 512;
+    return (int)(r < 8 ? 8 : (r > 64 ? 64 : r));
+}
+extern "C" int owl_box_final_bwd_blocks(int64_t rows) { const int rpb = box_bwd_rpb(rows); return (int)((rows + rpb - 1) / rpb); }
 
 extern "C" int owl_box_final_bwd(void* stream, const float* dboxes, const float* sig, const void* h1_bf16, const void* u1_bf16,
                                  const float* w2, void* du1_bf16, float* partials, float* dw2_db2, int64_t rows, int64_t D) {
     OWL_CHECK_ARG(dboxes && sig && h1_bf16 && u1_bf16 && w2 && du1_bf16 && partials && dw2_db2, "owl_box_final_bwd: null pointer");
     OWL_CHECK_ARG(D <= 1024 && D % 4 == 0, "owl_box_final_bwd: D <= 1024, D %% 4");
-    const int rpb = 64;
+    const int rpb = box_bwd_rpb(rows);
     const int nblk = (int)((rows + rpb - 1) / rpb);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(box_final_bwd_kernel, dim3((unsigned)nblk), dim3(256), 0, s, dboxes, sig, (const bf16_t*)h1_bf16,
