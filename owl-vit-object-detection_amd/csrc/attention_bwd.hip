@@ -123,7 +123,35 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdP p) {
     const float* lsebase = p.lse + ((int64_t)b * p.H + h) * p.Tp;
     const float* dvbase = p.dvec + ((int64_t)b * p.H + h) * p.Tp;
 
-    auto stage = [&](int buf, int qt) {
+    // Staging.  Full tiles go through `buffer_load_dwordx4 ... offen lds`: the (image, head) bases sit in buffer
+    // descriptors, the tile offset in an SGPR and the lane's row/chunk offsets in VGPRs computed once -- no address VALU
+    // per tile (the global_load_lds form needs a 64-bit VGPR address per piece).  Only the partial last tile clamps rows.
+    unsigned row_voff[2][2], col_voff[2];                          // [qd]: {Q, dO} row-major pieces; Q^T / dO^T pieces
+#pragma unroll
+    for (int qd = 0; qd < 2; qd++) {
+        const int r = (w * 2 + qd) * 8 + (lane >> 3);
+        const int ch = (lane & 7) ^ ((r >> 1) & 7);
+        row_voff[qd][0] = (unsigned)((r * p.ld_qkv + ch * 8) * 2);
+        row_voff[qd][1] = (unsigned)((r * p.ld_do + ch * 8) * 2);
+        col_voff[qd] = (unsigned)((r * p.Tp + ch * 8) * 2);
+    }
+    const __amdgpu_buffer_rsrc_t q_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)qbase, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t do_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dobase, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t qt_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)qtbase, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dot_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dotbase, 0, 0x7fffffff, 0x00020000);
+    const int q_tile_bytes = (int)(64 * p.ld_qkv * 2), do_tile_bytes = (int)(64 * p.ld_do * 2);
+    auto stage_full = [&](int buf, int qt) {
+        unsigned char* base = lds + buf * BWD1_STAGE;
+#pragma unroll
+        for (int qd = 0; qd < 2; qd++) {
+            const int r0 = (w * 2 + qd) * 8;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(q_rsrc, LPTR(base + r0 * 128), 16, (int)row_voff[qd][0], qt * q_tile_bytes, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(do_rsrc, LPTR(base + 8192 + r0 * 128), 16, (int)row_voff[qd][1], qt * do_tile_bytes, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(qt_rsrc, LPTR(base + 16384 + r0 * 128), 16, (int)col_voff[qd], qt * 128, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(dot_rsrc, LPTR(base + 24576 + r0 * 128), 16, (int)col_voff[qd], qt * 128, 0, 0);
+        }
+    };
+    auto stage_clamped = [&](int buf, int qt) {
         unsigned char* base = lds + buf * BWD1_STAGE;
 #pragma unroll
         for (int qd = 0; qd < 2; qd++) {
@@ -137,6 +165,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdP p) {
             __builtin_amdgcn_global_load_lds(GPTR(qtbase + (int64_t)r * p.Tp + qt * 64 + ch * 8), LPTR(base + 16384 + r0 * 128), 16, 0, 0);
             __builtin_amdgcn_global_load_lds(GPTR(dotbase + (int64_t)r * p.Tp + qt * 64 + ch * 8), LPTR(base + 24576 + r0 * 128), 16, 0, 0);
         }
+    };
+    auto stage = [&](int buf, int qt) {                            // wave-uniform choice
+        if (qt * 64 + 64 <= p.T) stage_full(buf, qt); else stage_clamped(buf, qt);
     };
     // lse / D values of a tile travel through a register: loaded when the tile is staged, written to
     // LDS after the compute phase (keeps ordinary loads out of the LDS-DMA window)
@@ -271,7 +302,30 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnBwdP p) {
 
     const bf16_t* kbase = p.qkv + (int64_t)b * p.Tp * p.ld_qkv + D + h * 64;
     const bf16_t* ktbase = p.qkvT + ((int64_t)b * 3 * D + D + h * 64) * p.Tp;
-    auto stage = [&](int buf, int kv) {
+    // staging as in the dK/dV kernel: buffer loads with scalar tile offsets for full tiles, clamped rows for the last one
+    unsigned row_voff[2], col_voff[2];
+#pragma unroll
+    for (int qd = 0; qd < 2; qd++) {
+        const int r = (w * 2 + qd) * 8 + (lane >> 3);
+        const int ch = (lane & 7) ^ ((r >> 1) & 7);
+        row_voff[qd] = (unsigned)((r * p.ld_qkv + ch * 8) * 2);
+        col_voff[qd] = (unsigned)((r * p.Tp + ch * 8) * 2);
+    }
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(kbase + D), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t kt_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ktbase, 0, 0x7fffffff, 0x00020000);
+    const int k_tile_bytes = (int)(64 * p.ld_qkv * 2);
+    auto stage_full = [&](int buf, int kv) {
+        unsigned char* base = lds + buf * BWD2_STAGE;
+#pragma unroll
+        for (int qd = 0; qd < 2; qd++) {
+            const int r0 = (w * 2 + qd) * 8;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, LPTR(base + r0 * 128), 16, (int)row_voff[qd], kv * k_tile_bytes, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, LPTR(base + 8192 + r0 * 128), 16, (int)row_voff[qd], kv * k_tile_bytes, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(kt_rsrc, LPTR(base + 16384 + r0 * 128), 16, (int)col_voff[qd], kv * 128, 0, 0);
+        }
+    };
+    auto stage_clamped = [&](int buf, int kv) {
         unsigned char* base = lds + buf * BWD2_STAGE;
 #pragma unroll
         for (int qd = 0; qd < 2; qd++) {
@@ -284,6 +338,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnBwdP p) {
             __builtin_amdgcn_global_load_lds(GPTR(kbase + D + (int64_t)key * p.ld_qkv + ch * 8), LPTR(base + 8192 + r0 * 128), 16, 0, 0);
             __builtin_amdgcn_global_load_lds(GPTR(ktbase + (int64_t)r * p.Tp + kv * 64 + ch * 8), LPTR(base + 16384 + r0 * 128), 16, 0, 0);
         }
+    };
+    auto stage = [&](int buf, int kv) {
+        if (kv * 64 + 64 <= p.T) stage_full(buf, kv); else stage_clamped(buf, kv);
     };
 
     f32x16 dq[2];

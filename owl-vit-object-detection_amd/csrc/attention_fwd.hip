@@ -68,15 +68,19 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
         k_voff[qd] = (unsigned)((r * p.ld_qk + ch * 8) * 2);
         v_voff[qd] = (unsigned)((r * p.Tp + ch * 8) * 2);          // V^T row r = d; 8 keys per chunk
     }
+    // Full tiles go through `buffer_load_dwordx4 ... offen lds`: the (image, head) base sits in a buffer descriptor, the
+    // tile offset in an SGPR and the lane's row/chunk offset in one VGPR computed once -- no VALU work per tile (the
+    // global_load_lds form needs a 64-bit VGPR address, i.e. a v_lshl_add_u64 per piece).
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, 0x7fffffff, 0x00020000);
+    const int k_tile_bytes = (int)(64 * p.ld_qk * 2);
     auto stage = [&](int buf, int kv) {                            // full tiles: every key row < T
         unsigned char* base = lds + buf * 16384;
-        const unsigned char* kt = (const unsigned char*)(kbase + (int64_t)kv * 64 * p.ld_qk);
-        const unsigned char* vtile = (const unsigned char*)(vbase + (int64_t)kv * 64);
 #pragma unroll
         for (int qd = 0; qd < 2; qd++) {
             const int r0 = (w * 2 + qd) * 8;
-            __builtin_amdgcn_global_load_lds(GPTR(kt + k_voff[qd]), LPTR(base + r0 * 128), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(GPTR(vtile + v_voff[qd]), LPTR(base + 8192 + r0 * 128), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, LPTR(base + r0 * 128), 16, (int)k_voff[qd], kv * k_tile_bytes, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, LPTR(base + 8192 + r0 * 128), 16, (int)v_voff[qd], kv * 128, 0, 0);
         }
     };
     auto stage_clamped = [&](int buf, int kv) {                    // the partial last tile: key rows >= T re-read row T-1
@@ -217,6 +221,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
         }
         l_part += ts;
         // ---- O^T += V^T P^T (4 chunks of 16 keys, 2 d-blocks) ----
+        __builtin_amdgcn_s_setprio(1);                           // favour the wave that feeds the matrix pipe (+1 %)
 #pragma unroll
         for (int t = 0; t < 2; t++) {
             if (t == 1 && half_only) continue;
@@ -233,6 +238,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
                 }
             }
         }
+        __builtin_amdgcn_s_setprio(0);
     };
 
     const int nkv = (p.T + 63) / 64;

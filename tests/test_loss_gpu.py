@@ -45,14 +45,14 @@ def test_f5_reference_loss_cases(golden_dir):
         assert np.array_equal(indices[0][0].cpu().numpy(), g[name + "/pred_idx"]) and idx[0].shape == idx[1].shape
 
 
-def _random_case(B, P, C, seed, nmax=16):
+def _random_case(B, P, C, seed, nmax=16, counts=None):
     sims = (rng.uniform(seed, "s", B * P * C).reshape(B, P, C) * 1.2 - 0.6).astype(np.float32)
     x0 = rng.uniform(seed, "b", B * P, 0) * 0.7; y0 = rng.uniform(seed, "b", B * P, 1) * 0.7
     w = 0.03 + rng.uniform(seed, "b", B * P, 2) * 0.25; h = 0.03 + rng.uniform(seed, "b", B * P, 3) * 0.25
     pb = np.stack([x0, y0, x0 + w, y0 + h], -1).reshape(B, P, 4).astype(np.float32)
     labels, tbs = [], []
     for b in range(B):
-        n = 1 + int(rng.randint(seed, f"n{b}", 1, nmax)[0])
+        n = counts[b] if counts is not None else 1 + int(rng.randint(seed, f"n{b}", 1, nmax)[0])
         tx = rng.uniform(seed, f"t{b}", n, 0) * 0.6; ty = rng.uniform(seed, f"t{b}", n, 1) * 0.6
         tw = 0.02 + rng.uniform(seed, f"t{b}", n, 2) * 0.35; th = 0.02 + rng.uniform(seed, f"t{b}", n, 3) * 0.35
         tbs.append(np.stack([tx, ty, tx + tw, ty + th], -1).astype(np.float32))
@@ -84,6 +84,26 @@ def test_batched_loss_matches_oracle(B, P, C, scaled):
         assert float(lg[k]) == pytest.approx(float(lo[k]), rel=1e-4, abs=1e-6), k
     np.testing.assert_allclose(sg.grad.cpu().numpy(), so.grad.numpy(), rtol=1e-3, atol=1e-7)
     np.testing.assert_allclose(bg.grad.cpu().numpy(), bo.grad.numpy(), rtol=1e-3, atol=1e-7)
+
+
+@pytest.mark.parametrize("P,counts", [(2304, [100, 57, 1]), (3600, [93, 2])])
+def test_crowded_images_match_oracle(P, counts):
+    """COCO-crowd sized target lists (the survey's 2304 x 90 assignment): same assignment, labels and losses."""
+    C = 10
+    B = len(counts)
+    sims, pb, labels, tbs = _random_case(B, P, C, seed=4242 + P, counts=counts)
+    det = []
+    lo = O.push_pull_loss(torch.from_numpy(sims), [torch.from_numpy(l) for l in labels], torch.from_numpy(pb),
+                          [torch.from_numpy(t) for t in tbs], C, None, det)
+    crit = PushPullLoss(C, None)
+    lg = crit(torch.from_numpy(sims).to(DEV), [torch.from_numpy(l).to(DEV) for l in labels], torch.from_numpy(pb).to(DEV),
+              [torch.from_numpy(t).to(DEV) for t in tbs])
+    for b, n in enumerate(counts):
+        assert np.array_equal(crit.last["pred_idx"][b, :n].cpu().numpy(), det[b]["pred_idx"].numpy()), b
+        assert np.array_equal(crit.last["tgt_idx"][b, :n].cpu().numpy(), det[b]["tgt_idx"].numpy()), b
+        assert np.array_equal(crit.last["target_classes"][b].cpu().numpy(), det[b]["target_classes"].numpy()), b
+    for k in KEYS:
+        assert float(lg[k]) == pytest.approx(float(lo[k]), rel=1e-4, abs=1e-6), k
 
 
 def test_hungarian_tie_heavy_matches_scipy_rule():
