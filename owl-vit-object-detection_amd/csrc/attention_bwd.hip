@@ -14,6 +14,7 @@
 // copies (Q^T, K^T, dO^T as [B][heads*64][Tp]) written by the GEMM's transposing epilogue.
 // All tiles go HBM -> LDS by LDS-DMA, double-buffered, XOR-swizzled as in gemm.hip.
 #include "common.h"
+#include <type_traits>
 
 struct AttnBwdP {
     const bf16_t* qkv; int64_t ld_qkv;       // row-major [B*Tp, 3D]: q | k | v
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdP p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(dot_rsrc, LPTR(base + 24576 + r0 * 128), 16, (int)col_voff[qd], qt * 128, 0, 0);
         }
     };
-    auto stage_clamped = [&](int buf, int qt) {
+    auto stage_clamped = [&](int buf, int qt) {                    // partial last tile: rows >= T re-read row T-1 (32-bit offsets only)
         unsigned char* base = lds + buf * BWD1_STAGE;
 #pragma unroll
         for (int qd = 0; qd < 2; qd++) {
@@ -160,10 +161,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdP p) {
             const int ch = (lane & 7) ^ ((r >> 1) & 7);
             int q = qt * 64 + r;
             if (q >= p.T) q = p.T - 1;
-            __builtin_amdgcn_global_load_lds(GPTR(qbase + (int64_t)q * p.ld_qkv + ch * 8), LPTR(base + r0 * 128), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(GPTR(dobase + (int64_t)q * p.ld_do + ch * 8), LPTR(base + 8192 + r0 * 128), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(GPTR(qtbase + (int64_t)r * p.Tp + qt * 64 + ch * 8), LPTR(base + 16384 + r0 * 128), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(GPTR(dotbase + (int64_t)r * p.Tp + qt * 64 + ch * 8), LPTR(base + 24576 + r0 * 128), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(q_rsrc, LPTR(base + r0 * 128), 16, (q * (int)p.ld_qkv + ch * 8) * 2, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(do_rsrc, LPTR(base + 8192 + r0 * 128), 16, (q * (int)p.ld_do + ch * 8) * 2, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(qt_rsrc, LPTR(base + 16384 + r0 * 128), 16, (int)col_voff[qd], qt * 128, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(dot_rsrc, LPTR(base + 24576 + r0 * 128), 16, (int)col_voff[qd], qt * 128, 0, 0);
         }
     };
     auto stage = [&](int buf, int qt) {                            // wave-uniform choice
@@ -179,7 +180,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdP p) {
         return 0.f;
     };
     auto store_scal = [&](int buf, float v) {
-        if (threadIdx.x < 128) ((float*)(lds + buf * BWD1_STAGE + 32768))[threadIdx.x] = v;
+        // stored already negated and split into (hi, lo) bf16: the consumers use the word as contraction slots 0, 1 directly
+        if (threadIdx.x < 128) ((unsigned*)(lds + buf * BWD1_STAGE + 32768))[threadIdx.x] = split_hi_lo_bf16(-v);
     };
 
     f32x16 dv[2], dk[2];
@@ -198,15 +200,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdP p) {
         float pend = 0.f;
         if (qt + 1 < nq) { stage(cur ^ 1, qt + 1); pend = load_scal(qt + 1); }
         const unsigned char* tb = lds + cur * BWD1_STAGE;
-        const float* lse_t = (const float*)(tb + 32768);
-        const float* dv_t = lse_t + 64;
+        const unsigned* lse_t = (const unsigned*)(tb + 32768);   // packed (hi, lo) of -lse / -D per query of the tile
+        const unsigned* dv_t = lse_t + 64;
         // a wave whose 32 keys all lie beyond T (T = 2305: three of the last block's four waves) only stages and syncs
 #pragma unroll
         for (int sub = 0; sub < (k0 < p.T ? 2 : 0); sub++) {
             const int qrow = sub * 32 + swap23b(l31);
             // query-side fragments of the two constant MFMAs: this lane's A row is query `qrow` of the tile
-            const bf16x8 a_lse = frag_slot01(split_hi_lo_bf16(-lse_t[qrow]), hi);
-            const bf16x8 a_dv = frag_slot01(split_hi_lo_bf16(-dv_t[qrow]), hi);
+            const bf16x8 a_lse = frag_slot01(lse_t[qrow], hi);
+            const bf16x8 a_dv = frag_slot01(dv_t[qrow], hi);
             f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lse, ones01, zero16, 0, 0, 0);    // -lse[query] in every key column
             f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_dv, ones01, zero16, 0, 0, 0);    // -D[query]
 #pragma unroll
@@ -334,9 +336,10 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnBwdP p) {
             const int ch = (lane & 7) ^ ((r >> 1) & 7);
             int key = kv * 64 + r;
             if (key >= p.T) key = p.T - 1;
-            __builtin_amdgcn_global_load_lds(GPTR(kbase + (int64_t)key * p.ld_qkv + ch * 8), LPTR(base + r0 * 128), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(GPTR(kbase + D + (int64_t)key * p.ld_qkv + ch * 8), LPTR(base + 8192 + r0 * 128), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(GPTR(ktbase + (int64_t)r * p.Tp + kv * 64 + ch * 8), LPTR(base + 16384 + r0 * 128), 16, 0, 0);
+            const int voff = (key * (int)p.ld_qkv + ch * 8) * 2;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, LPTR(base + r0 * 128), 16, voff, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, LPTR(base + 8192 + r0 * 128), 16, voff, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(kt_rsrc, LPTR(base + 16384 + r0 * 128), 16, (int)col_voff[qd], kv * 128, 0, 0);
         }
     };
     auto stage = [&](int buf, int kv) {
@@ -354,13 +357,13 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnBwdP p) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    int cur = 0;
-    for (int kv = 0; kv < nkv; kv++) {
-        if (kv + 1 < nkv) stage(cur ^ 1, kv + 1);
+    // one 64-key tile.  TAIL (compile time) only for the peeled partial last tile: in the full tiles the per-element
+    // key mask (compare + select per score) is not even compiled in -- it used to cost ~4 VALU per element of every tile.
+    auto tile = [&](int cur, int kv, auto tail_tag) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
         const unsigned char* tb = lds + cur * BWD2_STAGE;
-        const bool tail = kv * 64 + 64 > p.T;
         // idle waves (all 32 queries beyond T) only stage and sync; a tail tile whose keys all sit in its first half skips the second
-        const int nsub = (q0 >= p.T) ? 0 : ((tail && p.T - kv * 64 <= 32) ? 1 : 2);
+        const int nsub = (q0 >= p.T) ? 0 : ((TAIL && p.T - kv * 64 <= 32) ? 1 : 2);
 #pragma unroll
         for (int sub = 0; sub < nsub; sub++) {
             f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones01, q_lse, zero16, 0, 0, 0);    // -lse of the lane's query
@@ -379,7 +382,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnBwdP p) {
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     float pv = __builtin_amdgcn_exp2f(s[cc * 8 + j]);          // = exp2(score*c - lse)
-                    if (tail) {
+                    if constexpr (TAIL) {
                         const int key = kv * 64 + sub * 32 + cc * 16 + 8 * hi + j;
                         if (key >= p.T) pv = 0.f;
                     }
@@ -395,11 +398,21 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnBwdP p) {
                 }
             }
         }
+    };
+    auto sync = [&]() {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+    };
+    const int nfull = p.T / 64;                                   // tiles with no key >= T
+    int cur = 0;
+    for (int kv = 0; kv < nfull; kv++) {
+        if (kv + 1 < nkv) stage(cur ^ 1, kv + 1);
+        tile(cur, kv, std::false_type{});
+        sync();
         cur ^= 1;
     }
+    if (nfull < nkv) tile(cur, nfull, std::true_type{});
     if (q_ok) {
         bf16_t* orow = p.dqkv + ((int64_t)b * p.Tp + q) * p.ld_qkv + h * 64;
 #pragma unroll

@@ -133,16 +133,27 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
     bf16x8 qneg = __builtin_bit_cast(bf16x8, qn4);
 
     // fragment byte offsets inside a stage buffer, all precomputed once
-    int k_addr[2][4], v_addr[2][4];
+    // (absolute 32-bit LDS addresses: the stage-buffer offset then folds into the ds_read immediate instead of costing one
+    // v_add per read)
+    const unsigned lds0 = (unsigned)(uintptr_t)LPTR(lds);
+    unsigned k_addr[2][4], v_addr[2][4];
 #pragma unroll
     for (int t = 0; t < 2; t++) {
         const int rk = t * 32 + swap23(lane & 31);
 #pragma unroll
-        for (int kc = 0; kc < 4; kc++) k_addr[t][kc] = rk * 128 + (((kc * 2 + hi) ^ ((rk >> 1) & 7)) << 4);
+        for (int kc = 0; kc < 4; kc++) k_addr[t][kc] = lds0 + rk * 128 + (((kc * 2 + hi) ^ ((rk >> 1) & 7)) << 4);
         const int rv = t * 32 + (lane & 31);
 #pragma unroll
-        for (int c8 = 0; c8 < 4; c8++) v_addr[t][c8] = 8192 + rv * 128 + (((c8 * 2 + hi) ^ ((rv >> 1) & 7)) << 4);   // [d-block t][chunk c8]
+        for (int c8 = 0; c8 < 4; c8++) v_addr[t][c8] = lds0 + 8192 + rv * 128 + (((c8 * 2 + hi) ^ ((rv >> 1) & 7)) << 4);   // [d-block t][chunk c8]
     }
+    // opaque to the optimiser, which otherwise re-derives each address from its row and chunk parts at every use
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            asm volatile("" : "+v"(k_addr[t][i]));
+            asm volatile("" : "+v"(v_addr[t][i]));
+        }
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float l_part = 0.f;                                          // this half-wave's running sum of P (unnormalised)
 
@@ -152,11 +163,19 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
     auto tile = [&](auto buf_tag, int kv, auto mask_tag, bool first) {
         constexpr int BUF = decltype(buf_tag)::value;
         constexpr bool MASK = decltype(mask_tag)::value;
-        const unsigned char* tb = lds + BUF * 16384;
+        typedef const __attribute__((address_space(3))) bf16x8* frag_ptr;
         f32x16 s[2];
         // the partial last tile often holds very few keys (T = 2305 = 36*64 + 1): when they all sit in its first 32-key
         // half, the second score tile is skipped altogether (its P is 0)
         const bool half_only = MASK && (p.T - kv * 64 <= 32);
+        // the tile's eight K fragments are requested up front: the two score chains then run back to back on counted
+        // lgkmcnt waits instead of read -> wait -> MFMA per fragment (and the slow path reuses the registers)
+        bf16x8 kfr[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int kc = 0; kc < 4; kc++) kfr[t][kc] = *(frag_ptr)(k_addr[t][kc] + BUF * 16384);
+        __builtin_amdgcn_sched_barrier(0);
         auto qk = [&](bool sub_max) {
 #pragma unroll
             for (int t = 0; t < 2; t++) {
@@ -164,8 +183,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
                 if (sub_max) s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kones, qneg, zero16, 0, 0, 0);    // -M everywhere
 #pragma unroll
                 for (int kc = 0; kc < 4; kc++) {
-                    const bf16x8 kf = *(const bf16x8*)(tb + k_addr[t][kc]);
-                    s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kc], (kc == 0 && !sub_max) ? zero16 : s[t], 0, 0, 0);
+                    s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[t][kc], qf[kc], (kc == 0 && !sub_max) ? zero16 : s[t], 0, 0, 0);
                 }
             }
             if constexpr (MASK) {
@@ -233,7 +251,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
                 const int c8 = t * 2 + cc;
 #pragma unroll
                 for (int d = 0; d < 2; d++) {
-                    const bf16x8 vf = *(const bf16x8*)(tb + v_addr[d][c8]);
+                    const bf16x8 vf = *(frag_ptr)(v_addr[d][c8] + BUF * 16384);
                     o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
                 }
             }
