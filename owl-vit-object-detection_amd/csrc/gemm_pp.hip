@@ -40,7 +40,9 @@ __device__ __forceinline__ void pp_bar() {      // sched_barrier: the scheduler 
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int EPI>
+// TRACE (tuning only, tools/pp_trace.py): the first workgroup stamps s_memtime at every half-slot boundary of K-tile 4
+// of its first tile into 4 KiB of LDS behind the regular image and dumps them to p.aux at the end.
+template <int EPI, bool TRACE = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr bool TRANS = (EPI == EPI_TRANS_BF16);
@@ -64,6 +66,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
     int s_item = item, s_k = 0, s_buf = 0, s_parity = 0;
     // per-lane byte offsets relative to the tile's (wave-uniform) base pointers: 8 VGPRs instead of 8 64-bit pointers
     unsigned a_voff[2][2], w_voff[2][2], b_voff = 0;   // [half][q]
+    // (buffer_load ... lds with a scalar K offset, which pays in the attention kernels, measured 2-3 % SLOWER here: the
+    // ~57-cycle issue cost of an LDS-DMA piece does not depend on the address form, tools/pp_trace.py)
     const bf16_t* a_base = nullptr;
     const bf16_t* w_base = nullptr;
     const float* b_base = nullptr;
@@ -132,6 +136,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
     pp_bar();
 
     int cur = 0, tile_parity = 0;
+    const bool tr_wg = TRACE && blockIdx.x == 0;
+    bool tr_first = true;
+    unsigned long long tr_ts[20] = {};
     int pending_stores = 0;          // epilogue stores issued after the newest in-flight K-tile's DMA (0 or 16)
     bool deferred_A = false;         // TRANS: the A pieces of the K-tile after next wait for the epilogue to release its staging area
     while (true) {
@@ -147,6 +154,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
         if (grp == 1) pp_bar();                       // (re-)create the one-barrier offset
         for (int kt = 0; kt < nk; kt++) {
             const unsigned char* tb = lds + cur * P_STAGE;
+            // s_memtime is issued WITHOUT waiting for its result (a waited stamp costs ~140 cycles and distorts everything);
+            // the 20 results of K-tile 4 stay in SGPRs until the K-tile's last barrier
+            auto stamp = [&](int idx) {
+                if constexpr (TRACE) {
+                    if (tr_wg && tr_first && kt == 4) {
+                        // (the last stamps are read back right away: those wait for their result)
+                        if (idx >= 17) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr_ts[idx]));
+                        else asm volatile("s_memtime %0" : "=s"(tr_ts[idx]));
+                    }
+                }
+            };
             bf16x8 fa[2][4], fb[2][4];                // [tile within quadrant][kc], [j][kc]
             auto ld_a = [&](int ih) {
 #pragma unroll
@@ -171,27 +189,32 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
                 __builtin_amdgcn_s_setprio(0);
             };
             // ---- q0 ----
+            stamp(0);
             ld_b(0); ld_a(0);
-            pp_wait_lgkm(); pp_bar();
+            stamp(1); pp_wait_lgkm(); stamp(2); pp_bar(); stamp(3);
             mma(0, 0);
-            pp_bar();
+            stamp(4); pp_bar();
             // ---- q1 ----
+            stamp(5);
             ld_b(1);
-            pp_wait_lgkm(); pp_bar();
+            stamp(6); pp_wait_lgkm(); stamp(7); pp_bar(); stamp(8);
             mma(0, 1);
-            pp_bar();
+            stamp(9); pp_bar();
             // ---- q2: B rows of this buffer are free (both groups finished their q1 LOAD) ----
+            stamp(10);
             ld_a(1);
             int n_new = 0;
             const bool live = stream_live();
             if (live) n_new = stage_B();
-            pp_wait_lgkm(); pp_bar();
+            stamp(11); pp_wait_lgkm(); stamp(12); pp_bar(); stamp(13);
             mma(1, 1);
-            pp_bar();
+            stamp(14); pp_bar();
             // ---- q3: A rows are free; retire K-tile kt+1, leave kt+2 in flight.  The transposing epilogue borrows this
             //      buffer's A rows as its staging area, so at a tile's last K-tile it defers the A pieces until after it ----
+            stamp(15);
             if (live && !(TRANS && kt + 1 == nk)) { stage_A(); n_new += 4; }
             else if (live) deferred_A = true;
+            stamp(16);
             {
                 const int total = n_new + pending_stores;
                 if (total == 8) pp_wait<8>();
@@ -205,9 +228,18 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
                 else pp_wait<0>();
                 pending_stores = 0;
             }
-            pp_bar();
+            stamp(17); pp_bar(); stamp(18);
             mma(1, 0);
-            pp_bar();
+            stamp(19); pp_bar();
+            if constexpr (TRACE) {
+                if (tr_wg && tr_first && kt == 4) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (lane == 0) {
+#pragma unroll
+                        for (int i = 0; i < 20; i++) ((unsigned long long*)(lds + P_LDS))[w * 40 + i] = tr_ts[i];
+                    }
+                }
+            }
             cur ^= 1;
         }
         if (grp == 0) pp_bar();                       // let group 1 finish its last MFMA half: epilogues run together
@@ -272,6 +304,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
             };
             if (inner) run(std::false_type{}); else run(std::true_type{});
         }
+        if constexpr (TRACE) {
+            if (tr_wg && tr_first) {
+                __syncthreads();
+                if (threadIdx.x < 320) ((unsigned long long*)p.aux)[threadIdx.x] = ((unsigned long long*)(lds + P_LDS))[threadIdx.x];
+                tr_first = false;
+            }
+        }
         item += item_step;
         if (item >= item_end) break;
         tile_parity ^= 1;
@@ -304,7 +343,17 @@ static int launch_pp(hipStream_t s, GemmP p, int slots_override, int persistent_
 // called from gemm.hip's dispatcher; returns 1 if this variant does not handle `epi`
 int owl_gemm_pp_launch(hipStream_t s, int epi, const GemmP& p, int slots_override, int persistent_on, int nostore) {
     switch (epi) {
-        case EPI_BIAS_BF16: return launch_pp<EPI_BIAS_BF16>(s, p, slots_override, persistent_on, nostore);
+        case EPI_BIAS_BF16:
+            if (nostore & 8) {                       // trace run (p.aux = 320 x u64 trace buffer)
+                GemmP q = p;
+                (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI_BIAS_BF16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS + 4096);
+                q.tiles_m = (int)((q.M + PBM - 1) / PBM); q.tiles_n = (int)((q.N + PBN - 1) / PBN); q.nsplit = 1; q.dbg = 0;
+                const int nitems = q.tiles_m * q.tiles_n;
+                q.persistent = nitems > 256 ? 1 : 0;
+                hipLaunchKernelGGL((gemm_pp_kernel<EPI_BIAS_BF16, true>), dim3(q.persistent ? 256 : nitems), dim3(512), P_LDS + 4096, s, q);
+                return 0;
+            }
+            return launch_pp<EPI_BIAS_BF16>(s, p, slots_override, persistent_on, nostore);
         case EPI_QGELU_BF16: return launch_pp<EPI_QGELU_BF16>(s, p, slots_override, persistent_on, nostore);
         case EPI_TRANS_BF16: return launch_pp<EPI_TRANS_BF16>(s, p, slots_override, persistent_on, nostore);
         case EPI_DQGELU_BF16: return launch_pp<EPI_DQGELU_BF16>(s, p, slots_override, persistent_on, nostore);
