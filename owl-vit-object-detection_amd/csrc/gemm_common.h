@@ -189,21 +189,38 @@ __device__ __forceinline__ void epi_tile_bf16(const GemmP& p, const f32x16& acc,
 #pragma unroll
         for (int qd = 0; qd < 4; qd++) {
             float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; e++) v[e] = acc[qd * 4 + e] * p.alpha;
             const bool n_ok = !GUARD || (n_tile + 8 * qd + 4 * hi) < p.N;
             const bool ok = m_ok && n_ok;
+            // v = acc * alpha + bias as ONE packed fma per element pair (alpha = 1 in the encoder: acc*1 + b is exactly acc + b)
+            const f32x2_t al = {p.alpha, p.alpha};
+            f32x2_t b01 = {0.f, 0.f}, b23 = {0.f, 0.f};
             if (p.bias) {                                  // wave-uniform
                 const f32x4 b4 = lds_read_f4(bias_p + 8 * qd);
-                v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
+                b01 = (f32x2_t){b4[0], b4[1]}; b23 = (f32x2_t){b4[2], b4[3]};
             }
+            const f32x2_t v01 = __builtin_elementwise_fma((f32x2_t){acc[qd * 4 + 0], acc[qd * 4 + 1]}, al, b01);
+            const f32x2_t v23 = __builtin_elementwise_fma((f32x2_t){acc[qd * 4 + 2], acc[qd * 4 + 3]}, al, b23);
+            v[0] = v01.x; v[1] = v01.y; v[2] = v23.x; v[3] = v23.y;
             if constexpr (EPI == EPI_QGELU_BF16 || EPI == EPI_GELU_BF16) {
                 if (p.aux) {                               // wave-uniform; pre-activation save (trainable layer only)
                     uint2 a; a.x = pack_bf2(v[0], v[1]); a.y = pack_bf2(v[2], v[3]);
                     if (ok) *(uint2*)((bf16_t*)aux_row + 8 * qd) = a;
                 }
+                if constexpr (EPI == EPI_QGELU_BF16) {
+                    // u * 1/(1 + exp2(-2.4555 u)), two elements per VALU instruction where the ISA has a packed form
+                    // (v_pk_mul_f32 / v_pk_add_f32); v_exp / v_rcp stay scalar.  Same operations as qgelu_f, same rounding.
 #pragma unroll
-                for (int e = 0; e < 4; e++) v[e] = (EPI == EPI_QGELU_BF16) ? qgelu_f(v[e]) : gelu_f(v[e]);
+                    for (int e = 0; e < 4; e += 2) {
+                        const f32x2_t u = {v[e], v[e + 1]};
+                        const f32x2_t t = u * -2.4554669595930156f;
+                        const f32x2_t d = (f32x2_t){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + 1.0f;
+                        const f32x2_t o = u * (f32x2_t){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+                        v[e] = o.x; v[e + 1] = o.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = gelu_f(v[e]);
+                }
             } else if constexpr (EPI == EPI_DQGELU_BF16 || EPI == EPI_DGELU_BF16) {
                 uint2 a = make_uint2(0u, 0u);
                 if (ok) a = *(const uint2*)(aux_row + 8 * qd);
