@@ -8,7 +8,9 @@ mkdir -p build
 objs=""
 for f in *.hip; do
   o=build/${f%.hip}.o
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ common.h -nt "$o" ]; then
+  stale=0
+  for h in *.h; do [ "$h" -nt "$o" ] && stale=1; done
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ $stale = 1 ]; then
     extra=""
     case "$f" in loss.hip|postprocess.hip) extra="-ffp-contract=off";; esac
     hipcc $FLAGS $extra -c "$f" -o "$o" &
