@@ -294,6 +294,7 @@ static int launch_cfg(hipStream_t s, GemmP p, int splits) {
 static int g_force_tile = 0;   // 0 auto, 128, 256, 8 = ping-pong schedule (gemm_pp.hip) where it applies (tests / tuning)
 extern "C" int owl_gemm_set_tile(int tile) { g_force_tile = tile; return 0; }
 int owl_gemm_pp_launch(hipStream_t s, int epi, const GemmP& p, int slots_override, int persistent_on, int nostore);   // gemm_pp.hip
+int owl_gemm_w4_launch(hipStream_t s, int epi, const GemmP& p);                                                       // gemm_w4.hip
 
 template <int EPI>
 static int launch(hipStream_t s, const GemmP& p, int splits) {
@@ -329,6 +330,10 @@ extern "C" int owl_gemm_nt_bf16(void* stream, int epi, const void* A, int64_t ld
     const bool split_ok = (epi == EPI_ATOMIC_F32 || epi == EPI_SLAB_F32);
     OWL_CHECK_ARG(splits == 1 || split_ok, "owl_gemm_nt_bf16: split-K needs the atomic or slab epilogue");
     // bf16-output epilogues on big problems run the ping-pong schedule (gemm_pp.hip): 13-26 % faster, bit-identical
+    if (g_force_tile == 4 && K >= 128) {                 // experimental four-wave kernel (tuning A/B only)
+        const int rc = owl_gemm_w4_launch(s, epi, p);
+        if (rc <= 0) return rc;
+    }
     const bool pp_auto = (g_force_tile == 0 && M >= 512 && N >= 256 && ((M + 255) / 256) * ((N + 255) / 256) >= 48);
     if ((g_force_tile == 8 || pp_auto) && K >= 128 && (epi != EPI_TRANS_BF16 || (Tp > 0 && Tp % 4 == 0 && N % 64 == 0)) &&
         ((epi != EPI_DQGELU_BF16 && epi != EPI_DGELU_BF16) || aux)) {

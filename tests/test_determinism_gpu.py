@@ -77,6 +77,10 @@ def test_gemm_pingpong_matches_tile256_bitwise(N, K, epi):
     ref = run(256)
     for _ in range(12):
         assert torch.equal(run(8), ref)
+    # the experimental four-wave kernel (csrc/gemm_w4.hip, owl_gemm_set_tile(4): one 128x128 block per wave, fragments
+    # software-pipelined inside the wave, LDS-DMA pieces spread over three K-steps) shares the epilogue and the K order
+    for _ in range(6):
+        assert torch.equal(run(4), ref)
 
 
 def test_attention_bwd_bitwise_repeatable():
