@@ -6,13 +6,13 @@
 // output block (4 x 4 accumulator tiles = 256 registers of the 512 a lone wave may use), reads 4 + 4 fragments per 16
 // MFMAs, and hides them by software pipelining inside the wave (fragments of K-step kc+1 are requested before the MFMAs
 // of step kc) instead of by a partner wave.  One barrier per K-tile (four MFMAs into step 2: K-tile c+1 visible, buffer c
-// free); the 16 LDS-DMA pieces per wave of K-tile c+2 are spread over steps 2, 3 and the next step 0.
+// free); the 16 LDS-DMA pieces per wave of K-tile c+2 are spread four per K-step over steps 2, 3 and the next steps 0, 1.
 //
 // Measured (tools/w4_bench.py, bit-identical to the ping-pong kernel): with the staging removed the loop runs at 1490 TF/s
 // at 8192^3 (ping-pong 1262, hipBLASLt 1670) -- the read side is fixed; with all 16 pieces in one K-step 890, in two 1047,
-// in three 1197: the L1/TA path moves one 1 KiB piece per ~16 cycles for the whole CU (half the K-tile), and a lone wave
+// in three 1197, in four 1185: the L1/TA path moves one 1 KiB piece per ~16 cycles for the whole CU (half the K-tile), and a lone wave
 // per SIMD stalls its own MFMA stream whenever its piece queues behind another wave's.  At the model's K = 768 shapes the
-// epilogue (one wave per SIMD, no partner to overlap with) loses more than the loop gains: 826 / 880 / 725 / 1045 TF/s vs
+// epilogue (one wave per SIMD, no partner to overlap with) loses more than the loop gains: 830 / 925 / 755 / 1050 TF/s vs
 // 910 / 1000 / 930 / 1096 for out-proj / QK / fc1 / fc2.  NOT the default; kept as the starting point for round 2
 // (stagger the pieces per wave, a leaner epilogue, 3 LDS stages of BK = 32).
 #include "gemm_common.h"
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmP p) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     int cur = 0, tile_parity = 0;
-    bool pend = false;              // pieces 10-15 of the K-tile being staged are still to be issued (next step 0)
+    bool pend = false;              // pieces 8-15 of the K-tile being staged are still to be issued (next steps 0 and 1)
     load_frags(0, 0, 0);
 
     while (true) {
@@ -146,11 +146,11 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmP p) {
                 // top of step 2, so ONE barrier four MFMAs into step 2 both releases it (every wave's reads have returned) and
                 // publishes K-tile c+1 (every wave's pieces have landed: they were issued 3-4 K-steps ago).  Pieces 0-7 (A) go out
                 // between the remaining MFMAs of step 2, pieces 8-15 (B) between those of step 3.
-                // issue plan (m = MFMA index of the step): step 2: pieces 0-3 after m = 6, 9, 12, 15; step 3: pieces 4-9 after
-                // m = 1, 4, 7, 10, 13, 15; next step 0: pieces 10-15 likewise.  The L1/TA path moves 1 KiB per ~16 cycles for the whole
-                // CU, i.e. the 64 pieces of a K-tile occupy it for half the K-tile: bunching them stalls the issuing waves.
+                // issue plan (m = MFMA index of the step): step 2: pieces 0-3 after m = 6, 9, 12, 15; steps 3, 0', 1': four pieces
+                // each after m = 1, 5, 9, 13.  The L1/TA path moves 1 KiB per ~16 cycles for the whole CU, i.e. the 64 pieces of a
+                // K-tile occupy it for half the K-tile: bunching them stalls the issuing waves.
                 const bool dma = (kc >= 2) && stream_live();
-                const bool dma0 = (kc == 0) && pend;
+                const bool dma0 = (kc <= 1) && pend;
                 if (kc == 2 && dma) stage_begin();
 #pragma unroll
                 for (int i = 0; i < 4; i++)
@@ -166,11 +166,12 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmP p) {
                             __builtin_amdgcn_sched_barrier(0);
                         }
                         if (kc == 2 && m >= 6 && (m % 3) == 0) { if (dma) stage_piece((m - 6) / 3); }
-                        if (kc == 3 && ((m % 3) == 1 || m == 15)) { if (dma) stage_piece(4 + (m == 15 ? 5 : m / 3)); }
-                        if (kc == 0 && ((m % 3) == 1 || m == 15)) { if (dma0) stage_piece(10 + (m == 15 ? 5 : m / 3)); }
+                        if (kc == 3 && (m & 3) == 1) { if (dma) stage_piece(4 + (m >> 2)); }
+                        if (kc == 0 && (m & 3) == 1) { if (dma0) stage_piece(8 + (m >> 2)); }
+                        if (kc == 1 && (m & 3) == 1) { if (dma0) stage_piece(12 + (m >> 2)); }
                     }
                 if (kc == 3 && dma) pend = true;
-                if (dma0) { stage_end(); pend = false; }
+                if (kc == 1 && dma0) { stage_end(); pend = false; }
                 __builtin_amdgcn_sched_barrier(0);
             }
             cur ^= 1;
