@@ -270,7 +270,9 @@ class OwlViT(nn.Module):
             if sv:   # row-major q,k,v and per-head transposed q,k,v (attention-backward operands)
                 qkv_l, qkvT_l = Ls["qkv"], Ls["qkvT"]
                 ops.gemm(ops.EPI_BIAS_BF16, h, lw["wqkv"], qkv_l, bias=lw["bqkv"], M=M, N=3 * D, K=D, ldo=3 * D)
-                ops.gemm(ops.EPI_TRANS_BF16, h, lw["wqkv"], qkvT_l, bias=lw["bqkv"], M=M, N=3 * D, K=D, Tp=Tp)
+                # the attention-backward operands Q^T / K^T (and V^T for this layer's own forward): an HBM-bound token transpose of
+                # the row-major result (same bits as a second GEMM with the transposing epilogue, a third of its time)
+                ops.transpose_tokens(qkv_l, qkvT_l, B, Tp, 3 * D)
                 vt, vt_stride = qkvT_l[2 * D * Tp:], 3 * D * Tp
             else:    # row-major q,k ; V only transposed
                 qkv_l = qkv

@@ -119,6 +119,13 @@ def transpose_bf16(src, dst, R, C, ld_in=None, ld_out=None):
     return dst
 
 
+def transpose_tokens(src, dst, B, Tp, ncols, ld_in=None):
+    """dst[b][c][t] = src[b*Tp + t][c], c < ncols: the per-head transposed layout of EPI_TRANS from row-major activations."""
+    _chk(src, torch.bfloat16, "src"); _chk(dst, torch.bfloat16, "dst")
+    _lib.call("owl_transpose_tokens_bf16", stream(), src, ld_in if ld_in is not None else src.shape[-1], dst, B, Tp, ncols)
+    return dst
+
+
 # ---- backward-side wrappers ---------------------------------------------------------------------------
 def layernorm_bwd(dy, x, stats, gamma, dres, dx, dgamma, dbeta, rows, D):
     _lib.call("owl_layernorm_bwd", stream(), dy, 1 if dy.dtype == torch.bfloat16 else 0, x, stats, gamma, dres, dx,

@@ -322,3 +322,16 @@ def test_colsum_f32(R, C):
     _lib.call("owl_colsum_f32", ops.stream(), x, out, R, C)
     ref = 0.5 + x.double().sum(0)
     assert (out.double() - ref).abs().max().item() <= 1e-4 * R ** 0.5 + 1e-4
+
+
+@pytest.mark.parametrize("B,T,ncols,ld", [(3, 577, 192, 192), (2, 2305, 2304, 2304), (1, 37, 64, 192)])
+def test_transpose_tokens_matches_torch(B, T, ncols, ld):
+    """out[b][c][t] = in[b*Tp + t][c] -- the per-head transposed layout of the transposing GEMM epilogue, bit for bit."""
+    Tp = (T + 7) // 8 * 8
+    torch.manual_seed(11)
+    src = torch.randn(ops.pad_rows(B * Tp), ld, device=DEV).bfloat16()
+    dst = torch.zeros(B * ncols * Tp + 64, device=DEV, dtype=torch.bfloat16)
+    ops.transpose_tokens(src, dst, B, Tp, ncols, ld_in=ld)
+    ref = src[: B * Tp].view(B, Tp, ld)[:, :, :ncols].transpose(1, 2).contiguous()
+    assert torch.equal(dst[: B * ncols * Tp].view(B, ncols, Tp), ref)
+    assert float(dst[B * ncols * Tp:].abs().max()) == 0.0          # nothing written past the end
