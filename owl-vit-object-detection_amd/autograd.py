@@ -179,7 +179,7 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
         ops.layernorm_bwd(bw["dh"], Ls["x_mid"], Ls["st2"], P_[pre + "layer_norm2.weight"], bw["dx"], bw["dxm"], None, None, M, D)
         ops.cast_bf16(bw["dxm"], bw["dxb"])
         ops.gemm(ops.EPI_BIAS_BF16, bw["dxb"], fz[f"{i}.woT"], bw["datt"], M=M, N=D, K=D)
-        ops.gemm(ops.EPI_TRANS_BF16, bw["dxb"], fz[f"{i}.woT"], bw["dattT"], M=M, N=D, K=D, Tp=Tp)
+        ops.transpose_tokens(bw["datt"], bw["dattT"], B, Tp, D)          # dO^T: token transpose of dO (same bits as a transposing GEMM)
         ops.attention_bwd(Ls["qkv"], Ls["qkvT"], bw["datt"], bw["dattT"], Ls["att"], Ls["lse"], bw["dvec"], bw["dqkv"], B, H, T, Tp, scale)
         ops.gemm(ops.EPI_BIAS_BF16, bw["dqkv"], fz[f"{i}.wqkvT"], bw["dh"], M=M, N=D, K=3 * D)
         ops.layernorm_bwd(bw["dh"], Ls["x_in"], Ls["st1"], P_[pre + "layer_norm1.weight"], bw["dxm"], bw["dx"], None, None, M, D)
@@ -199,7 +199,7 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
     dW(bw["dxb"], Lt["att"], G(tl + "self_attn.out_proj.weight"), D, D, M, Mp)
     woT = wT(tl + "self_attn.out_proj.weight", D, D)
     ops.gemm(ops.EPI_BIAS_BF16, bw["dxb"], woT, bw["datt"], M=M, N=D, K=D)
-    ops.gemm(ops.EPI_TRANS_BF16, bw["dxb"], woT, bw["dattT"], M=M, N=D, K=D, Tp=Tp)
+    ops.transpose_tokens(bw["datt"], bw["dattT"], B, Tp, D)              # dO^T: token transpose of dO (same bits as a transposing GEMM)
     ops.attention_bwd(Lt["qkv"], Lt["qkvT"], bw["datt"], bw["dattT"], Lt["att"], Lt["lse"], bw["dvec"], bw["dqkv"], B, H, T, Tp,
                       cfg.head_dim ** -0.5)
     o = model.flat_offsets[tl + "self_attn.q_proj.weight"]
