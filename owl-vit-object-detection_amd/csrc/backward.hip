@@ -239,36 +239,47 @@ extern "C" int owl_merge_ln_bwd(void* stream, const float* dfeats, const float* 
 // One wave per row (row-parallel, no serial loop): writes de (bf16) and the routed, scaled upstream
 // G[r, j] = g_c * inv_r * [j == 3c + argmax] (bf16 [rows, 32]); dqhat = G^T e is then an ordinary split-K GEMM.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void class_sims_bwd_kernel(const float* __restrict__ dsims, const float* __restrict__ sims,
+__global__ __launch_bounds__(512) void class_sims_bwd_kernel(const float* __restrict__ dsims, const float* __restrict__ sims,
                                                              const unsigned char* __restrict__ argmax, const float* __restrict__ inv_norm,
                                                              const float* __restrict__ e, const float* __restrict__ qhat, bf16_t* de,
                                                              bf16_t* G, bf16_t* e_bf16, int64_t rows, int Dt, int C, int rows_per_wave) {
     extern __shared__ __attribute__((aligned(16))) float lq[];     // qhat [32][Dt]
-    for (int i = threadIdx.x; i < 32 * (Dt >> 2); i += 256) ((float4*)lq)[i] = ((const float4*)qhat)[i];
+    for (int i = threadIdx.x; i < 32 * (Dt >> 2); i += 512) ((float4*)lq)[i] = ((const float4*)qhat)[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    // the 64 KiB query table is loaded once per workgroup: many rows per workgroup at large batch (36 per wave), fewer when
-    // that would leave most CUs idle (batch 1)
-    const int64_t row0 = ((int64_t)blockIdx.x * 4 + w) * rows_per_wave;
-    for (int64_t r = row0; r < min(rows, row0 + rows_per_wave); r++) {
+    // the 64 KiB query table is loaded once per workgroup of 8 waves (2 workgroups = 16 waves per CU: the per-row chain
+    // load -> reduce -> load -> store is latency-bound, so occupancy matters): many rows per wave at large batch, fewer when
+    // that would leave most CUs idle (batch 1).  A wave handles its rows two at a time (two independent chains).
+    const int64_t row0 = ((int64_t)blockIdx.x * 8 + w) * rows_per_wave;
+    const int64_t row1 = min(rows, row0 + rows_per_wave);
+    auto head = [&](int64_t r, int& jsel, float& gcls, float& coef_e) {
         const float inv = inv_norm[r];
-        // lanes 0..31 <-> query j
-        float gj = 0.f, gs = 0.f;
-        if (lane < 32) {
-            const int c = lane / 3;
-            if (c < C && (int)argmax[r * C + c] == lane - 3 * c) gj = dsims[r * C + c] * inv;
-            if (lane < C) gs = dsims[r * C + lane] * sims[r * C + lane];
+        // lane c < C owns class c of this row: its arg-max prompt and upstream gradient are read ONCE and handed to the
+        // feature loop through v_readlane (wave-uniform there: scalar operands, no shuffles, no byte loads per class)
+        jsel = 0; gcls = 0.f;
+        float gs = 0.f;
+        if (lane < C) {
+            const float ds = dsims[r * C + lane];
+            jsel = 3 * lane + (int)argmax[r * C + lane];
+            gcls = ds * inv;
+            gs = ds * sims[r * C + lane];
         }
         gs = wave_sum(gs);
-        if (lane < 32) G[r * 32 + lane] = f2bf(gj);
+        // routed upstream G[r][j] = g_c * inv * [j == 3c + argmax_c]: lane j looks its class up
+        const int c = lane / 3;
+        const int jc = __shfl(jsel, c < C ? c : 0, 64);
+        const float gc = __shfl(gcls, c < C ? c : 0, 64);
+        if (lane < 32) G[r * 32 + lane] = f2bf((c < C && jc == lane) ? gc : 0.f);
         const float nrm = 1.0f / inv - 1e-6f;
-        const float coef_e = gs * inv / nrm;
+        coef_e = gs * inv / nrm;
+    };
+    auto body = [&](int64_t r, int jsel, float gcls, float coef_e) {
         for (int k4 = lane; k4 < (Dt >> 2); k4 += 64) {
             const float4 ev = ((const float4*)(e + r * Dt))[k4];
             float4 d = make_float4(-coef_e * ev.x, -coef_e * ev.y, -coef_e * ev.z, -coef_e * ev.w);
             for (int c = 0; c < C; c++) {
-                const int j = 3 * c + (int)argmax[r * C + c];
-                const float g = __shfl(gj, j, 64);
+                const int j = __builtin_amdgcn_readlane(jsel, c);
+                const float g = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gcls), c));
                 const float4 q = ((const float4*)(lq + j * Dt))[k4];
                 d.x += g * q.x; d.y += g * q.y; d.z += g * q.z; d.w += g * q.w;
             }
@@ -277,6 +288,19 @@ __global__ __launch_bounds__(256) void class_sims_bwd_kernel(const float* __rest
             uint2 eb; eb.x = pack_bf2(ev.x, ev.y); eb.y = pack_bf2(ev.z, ev.w);
             ((uint2*)(e_bf16 + r * Dt))[k4] = eb;
         }
+    };
+    int64_t r = row0;
+    for (; r + 1 < row1; r += 2) {
+        int ja, jb; float ga, gb, ca, cb;
+        head(r, ja, ga, ca);
+        head(r + 1, jb, gb, cb);
+        body(r, ja, ga, ca);
+        body(r + 1, jb, gb, cb);
+    }
+    if (r < row1) {
+        int ja; float ga, ca;
+        head(r, ja, ga, ca);
+        body(r, ja, ga, ca);
     }
 }
 
@@ -302,9 +326,9 @@ extern "C" int owl_class_sims_bwd(void* stream, const float* dsims, const float*
     OWL_CHECK_ARG(shmem <= 150 * 1024, "owl_class_sims_bwd: Dt too large for LDS");
     static bool attr_done = false;
     if (!attr_done) { (void)hipFuncSetAttribute((const void*)class_sims_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_done = true; }
-    int rpw = (int)((rows + 4 * 512 - 1) / (4 * 512));           // aim at >= 512 workgroups ...
-    rpw = rpw < 4 ? 4 : (rpw > 36 ? 36 : rpw);                   // ... with 16..144 rows each
-    hipLaunchKernelGGL(class_sims_bwd_kernel, dim3((unsigned)((rows + 4 * rpw - 1) / (4 * rpw))), dim3(256), shmem, (hipStream_t)stream, dsims, sims, argmax,
+    int rpw = (int)((rows + 8 * 512 - 1) / (8 * 512));           // aim at >= 512 workgroups ...
+    rpw = rpw < 2 ? 2 : (rpw > 18 ? 18 : rpw);                   // ... with 16..144 rows each
+    hipLaunchKernelGGL(class_sims_bwd_kernel, dim3((unsigned)((rows + 8 * rpw - 1) / (8 * rpw))), dim3(512), shmem, (hipStream_t)stream, dsims, sims, argmax,
                        inv_norm, e, qhat32, (bf16_t*)de_bf16, (bf16_t*)g_bf16, (bf16_t*)e_bf16, rows, (int)Dt, (int)C, rpw);
     OWL_LAUNCH_CHECK();
     return 0;
