@@ -11,6 +11,7 @@ if [ "$1" != "pmc-only" ]; then
   timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_final -o rf -- python $R/bench.py --no-cpu-baseline > $R/gpurun_out/prof_final_bench.log 2>&1
   timeout 600 python $R/bench.py > $R/gpurun_out/bench_final.log 2>&1; tail -1 $R/gpurun_out/bench_final.log > $R/gpurun_out/bench_final.json
 fi
+[ "$1" = "no-pmc" ] && { cd $R; python tools/prof_summary.py $(ls gpurun_out/prof_final/*.db | head -1) 45 > gpurun_out/prof_final_summary.md; exit 0; }
 i=0
 for C in "SQ_WAVES SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU" "SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
