@@ -147,7 +147,7 @@ int owl_box_pairwise(void* stream, const float* boxes1, const float* boxes2, flo
 /* ---- backward of the row-wise pieces (autograd forms of the entries above) --------------------------
  * parameter-gradient outputs (dgamma, dbeta, dw2, db2, dqueries, colsum) ACCUMULATE (atomics) into
  * buffers the caller zeroes once per step -- they are views of the flat gradient bucket.              */
-int owl_layernorm_bwd(void* stream, const void* dy, int dy_bf16, const float* x, const float* stats, const float* gamma, const float* dres, float* dx, float* dgamma, float* dbeta, int64_t rows, int64_t D);
+int owl_layernorm_bwd(void* stream, const void* dy, int dy_bf16, const float* x, const float* stats, const float* gamma, const float* dres, float* dx, float* dgamma, float* dbeta, int64_t rows, int64_t D, void* dx_bf16);
 int owl_merge_ln_bwd(void* stream, const float* dfeats, const float* x, const float* cls_ln, const float* stats1, const float* stats2, const float* g1, const float* b1, const float* g2, float* dx, float* dcls_ws, float* dg1, float* db1, float* dg2, float* db2, int64_t B, int64_t P, int64_t Tp, int64_t D);
 /* class head backward, row-parallel part: de (bf16 [rows,Dt]), routed upstream G (bf16 [rows,32]) and a bf16 copy of e;
  * dqhat[32,Dt] = G^T e is then a split-K owl_gemm_nt_bf16, and owl_query_normalize_bwd maps it onto dqueries            */

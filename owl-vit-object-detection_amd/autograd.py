@@ -169,32 +169,37 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
                      G("backbone.post_layernorm.weight"), G("backbone.post_layernorm.bias"), G("post_post_layernorm.weight"),
                      G("post_post_layernorm.bias"), B, P, Tp, D)
     scale = cfg.head_dim ** -0.5
+    dxb_fresh = False        # bw["dxb"] already holds the bf16 copy of bw["dx"] (written by the last LayerNorm backward)
     # ---- frozen layers ABOVE the trainable one (literal "layers.11" rule on a deeper model): dX only ----------
     for i in range(cfg.layers - 1, cfg.trainable_layer(), -1):
         Ls, fz = model._layer_ws(B, i), model._fz
         pre = f"backbone.encoder.layers.{i}."
-        ops.cast_bf16(bw["dx"], bw["dxb"])
+        if not dxb_fresh:
+            ops.cast_bf16(bw["dx"], bw["dxb"])
         ops.gemm(ops.EPI_DQGELU_BF16, bw["dxb"], fz[f"{i}.w2T"], bw["du"], aux=Ls["u"], M=M, N=I, K=D)
         ops.gemm(ops.EPI_BIAS_BF16, bw["du"], fz[f"{i}.w1T"], bw["dh"], M=M, N=D, K=I)
-        ops.layernorm_bwd(bw["dh"], Ls["x_mid"], Ls["st2"], P_[pre + "layer_norm2.weight"], bw["dx"], bw["dxm"], None, None, M, D)
-        ops.cast_bf16(bw["dxm"], bw["dxb"])
+        # (the LayerNorm backward also writes the bf16 copy of its dx: the operand of the next dX GEMM, no separate cast pass)
+        ops.layernorm_bwd(bw["dh"], Ls["x_mid"], Ls["st2"], P_[pre + "layer_norm2.weight"], bw["dx"], bw["dxm"], None, None, M, D,
+                          dx_bf16=bw["dxb"])
         ops.gemm(ops.EPI_BIAS_BF16, bw["dxb"], fz[f"{i}.woT"], bw["datt"], M=M, N=D, K=D)
         ops.transpose_tokens(bw["datt"], bw["dattT"], B, Tp, D)          # dO^T: token transpose of dO (same bits as a transposing GEMM)
         ops.attention_bwd(Ls["qkv"], Ls["qkvT"], bw["datt"], bw["dattT"], Ls["att"], Ls["lse"], bw["dvec"], bw["dqkv"], B, H, T, Tp, scale)
         ops.gemm(ops.EPI_BIAS_BF16, bw["dqkv"], fz[f"{i}.wqkvT"], bw["dh"], M=M, N=D, K=3 * D)
-        ops.layernorm_bwd(bw["dh"], Ls["x_in"], Ls["st1"], P_[pre + "layer_norm1.weight"], bw["dxm"], bw["dx"], None, None, M, D)
+        ops.layernorm_bwd(bw["dh"], Ls["x_in"], Ls["st1"], P_[pre + "layer_norm1.weight"], bw["dxm"], bw["dx"], None, None, M, D,
+                          dx_bf16=bw["dxb"])
+        dxb_fresh = True
     Lt = model._layer_ws(B, cfg.trainable_layer())
     # ---- trainable encoder layer: MLP ---------------------------------------------------------------------
-    ops.cast_bf16(bw["dx"], bw["dxb"])
+    if not dxb_fresh:
+        ops.cast_bf16(bw["dx"], bw["dxb"])
     ops.colsum_f32(bw["dx"], G(tl + "mlp.fc2.bias"), M, D)
     dW(bw["dxb"], Lt["g"], G(tl + "mlp.fc2.weight"), D, I, M, Mp)
     ops.gemm(ops.EPI_DQGELU_BF16, bw["dxb"], wT(tl + "mlp.fc2.weight", D, I), bw["du"], aux=Lt["u"], M=M, N=I, K=D)
     dW(bw["du"], Lt["h2"], G(tl + "mlp.fc1.weight"), I, D, M, Mp, G(tl + "mlp.fc1.bias"))
     ops.gemm(ops.EPI_BIAS_BF16, bw["du"], wT(tl + "mlp.fc1.weight", I, D), bw["dh"], M=M, N=D, K=I)
     ops.layernorm_bwd(bw["dh"], Lt["x_mid"], Lt["st2"], P_[tl + "layer_norm2.weight"], bw["dx"], bw["dxm"],
-                      G(tl + "layer_norm2.weight"), G(tl + "layer_norm2.bias"), M, D)
+                      G(tl + "layer_norm2.weight"), G(tl + "layer_norm2.bias"), M, D, dx_bf16=bw["dxb"])
     # ---- trainable encoder layer: attention -----------------------------------------------------------------
-    ops.cast_bf16(bw["dxm"], bw["dxb"])
     ops.colsum_f32(bw["dxm"], G(tl + "self_attn.out_proj.bias"), M, D)
     dW(bw["dxb"], Lt["att"], G(tl + "self_attn.out_proj.weight"), D, D, M, Mp)
     woT = wT(tl + "self_attn.out_proj.weight", D, D)

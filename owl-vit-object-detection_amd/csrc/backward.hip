@@ -15,7 +15,7 @@ template <bool DY_BF16>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy_, const float* __restrict__ x,
                                                      const float2* __restrict__ stats, const float* __restrict__ gamma,
                                                      const float* dres, float* dx, float* dgamma, float* dbeta, int64_t rows,
-                                                     int D, int rows_per_block) {
+                                                     int D, int rows_per_block, bf16_t* dx_bf16) {
     __shared__ float red[2][4][LN_MAXV * 256 + 4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nvec = D >> 2;
@@ -62,6 +62,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                         o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
                     }
                     ((float4*)(dx + row * D))[idx] = o;
+                    if (dx_bf16) {                          // the bf16 copy the next dX GEMM reads (saves a separate cast pass)
+                        uint2 ob; ob.x = pack_bf2(o.x, o.y); ob.y = pack_bf2(o.z, o.w);
+                        ((uint2*)(dx_bf16 + row * D))[idx] = ob;
+                    }
                 }
             }
         }
@@ -81,16 +85,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
 }
 
 extern "C" int owl_layernorm_bwd(void* stream, const void* dy, int dy_bf16, const float* x, const float* stats, const float* gamma,
-                                 const float* dres, float* dx, float* dgamma, float* dbeta, int64_t rows, int64_t D) {
+                                 const float* dres, float* dx, float* dgamma, float* dbeta, int64_t rows, int64_t D, void* dx_bf16) {
     OWL_CHECK_ARG(dy && x && stats && gamma, "owl_layernorm_bwd: null pointer");
     OWL_CHECK_ARG(D % 4 == 0 && D <= 256 * LN_MAXV, "owl_layernorm_bwd: D must be a multiple of 4 and <= 1024");
     OWL_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "owl_layernorm_bwd: dgamma/dbeta both or neither");
+    OWL_CHECK_ARG(!dx_bf16 || dx, "owl_layernorm_bwd: dx_bf16 needs dx");
     const int rpb = 64;
     dim3 grid((unsigned)((rows + rpb - 1) / rpb));
     if (dy_bf16)
-        hipLaunchKernelGGL(ln_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dy, x, (const float2*)stats, gamma, dres, dx, dgamma, dbeta, rows, (int)D, rpb);
+        hipLaunchKernelGGL(ln_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dy, x, (const float2*)stats, gamma, dres, dx, dgamma, dbeta, rows, (int)D, rpb, (bf16_t*)dx_bf16);
     else
-        hipLaunchKernelGGL(ln_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dy, x, (const float2*)stats, gamma, dres, dx, dgamma, dbeta, rows, (int)D, rpb);
+        hipLaunchKernelGGL(ln_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dy, x, (const float2*)stats, gamma, dres, dx, dgamma, dbeta, rows, (int)D, rpb, (bf16_t*)dx_bf16);
     OWL_LAUNCH_CHECK();
     return 0;
 }

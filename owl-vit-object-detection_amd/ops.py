@@ -127,9 +127,11 @@ def transpose_tokens(src, dst, B, Tp, ncols, ld_in=None):
 
 
 # ---- backward-side wrappers ---------------------------------------------------------------------------
-def layernorm_bwd(dy, x, stats, gamma, dres, dx, dgamma, dbeta, rows, D):
+def layernorm_bwd(dy, x, stats, gamma, dres, dx, dgamma, dbeta, rows, D, dx_bf16=None):
+    """dx (f32) = LN backward (+ dres); optionally also its bf16 copy `dx_bf16` (the operand of the next dX GEMM)."""
+    _chk(dx_bf16, torch.bfloat16, "dx_bf16")
     _lib.call("owl_layernorm_bwd", stream(), dy, 1 if dy.dtype == torch.bfloat16 else 0, x, stats, gamma, dres, dx,
-              dgamma, dbeta, rows, D)
+              dgamma, dbeta, rows, D, dx_bf16)
 
 
 def merge_ln_bwd(dfeats, x, cls_ln, st1, st2, g1, b1, g2, dx, dcls_ws, dg1, db1, dg2, db2, B, P, Tp, D):
