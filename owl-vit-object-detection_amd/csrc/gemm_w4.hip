@@ -13,7 +13,8 @@
 // in three 1197, in four 1185: the L1/TA path moves one 1 KiB piece per ~16 cycles for the whole CU (half the K-tile), and a lone wave
 // per SIMD stalls its own MFMA stream whenever its piece queues behind another wave's.  At the model's K = 768 shapes the
 // epilogue (one wave per SIMD, no partner to overlap with) loses more than the loop gains: 830 / 925 / 755 / 1050 TF/s vs
-// 910 / 1000 / 930 / 1096 for out-proj / QK / fc1 / fc2.  NOT the default; kept as the starting point for round 2
+// 910 / 1000 / 930 / 1096 for out-proj / QK / fc1 / fc2.  Staggering the pieces per wave (wave w issues after the (w+1)-th
+// MFMA of every group of four, one scalar branch per MFMA) measured WORSE (1088 at 8192^3).  NOT the default; kept as the starting point for round 2
 // (stagger the pieces per wave, a leaner epilogue, 3 LDS stages of BK = 32).
 #include "gemm_common.h"
 #include <type_traits>
