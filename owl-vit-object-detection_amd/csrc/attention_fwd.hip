@@ -304,17 +304,32 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     const int qr = q0 + (lane & 31);
+    // 16-byte stores: a lane holds 4 consecutive d of its query per register quad and its partner lane^32 the adjacent 4; one
+    // v_permlane32_swap per packed word pairs them into 8 consecutive d per lane (half the store instructions -- the store tail
+    // of an attention workgroup is issue-bound).  Even quads end up complete in lanes 0-31, odd quads in lanes 32-63.
+    uint4 st[2][2];
+#pragma unroll
+    for (int d = 0; d < 2; d++)
+#pragma unroll
+        for (int pr = 0; pr < 2; pr++) {
+            unsigned x[2], y[2];                    // x = even quad (2*pr), y = odd quad (2*pr + 1)
+            x[0] = pack_bf2(o[d][(2 * pr) * 4 + 0] * inv, o[d][(2 * pr) * 4 + 1] * inv);
+            x[1] = pack_bf2(o[d][(2 * pr) * 4 + 2] * inv, o[d][(2 * pr) * 4 + 3] * inv);
+            y[0] = pack_bf2(o[d][(2 * pr + 1) * 4 + 0] * inv, o[d][(2 * pr + 1) * 4 + 1] * inv);
+            y[1] = pack_bf2(o[d][(2 * pr + 1) * 4 + 2] * inv, o[d][(2 * pr + 1) * 4 + 3] * inv);
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                auto r = __builtin_amdgcn_permlane32_swap(x[k], y[k], false, false);   // lanes 32-63 of x <-> lanes 0-31 of y
+                x[k] = r[0]; y[k] = r[1];
+            }
+            st[d][pr] = make_uint4(x[0], x[1], y[0], y[1]);
+        }
     if (qr < p.T) {
         bf16_t* op = p.out + ((int64_t)b * p.Tp + qr) * p.ld_out + h * 64;
 #pragma unroll
         for (int d = 0; d < 2; d++)
 #pragma unroll
-            for (int qd = 0; qd < 4; qd++) {
-                uint2 v;
-                v.x = pack_bf2(o[d][qd * 4 + 0] * inv, o[d][qd * 4 + 1] * inv);
-                v.y = pack_bf2(o[d][qd * 4 + 2] * inv, o[d][qd * 4 + 3] * inv);
-                *(uint2*)(op + d * 32 + 8 * qd + 4 * hi) = v;
-            }
+            for (int pr = 0; pr < 2; pr++) *(uint4*)(op + d * 32 + 16 * pr + 8 * hi) = st[d][pr];
         if (p.lse && hi == 0) p.lse[((int64_t)b * p.H + h) * p.Tp + qr] = M + __builtin_amdgcn_logf(l_tot);
     }
 }
@@ -326,7 +341,7 @@ extern "C" int owl_attention_fwd_bf16(void* stream, const void* q, const void* k
                                       int64_t vt_img_stride, void* out, int64_t ld_out, float* lse, int64_t B,
                                       int64_t H, int64_t T, int64_t Tp, float scale) {
     OWL_CHECK_ARG(q && k && vt && out, "owl_attention_fwd_bf16: null pointer");
-    OWL_CHECK_ARG(ld_qk % 8 == 0 && ld_out % 4 == 0 && Tp % 8 == 0 && T > 0 && T <= Tp, "owl_attention_fwd_bf16: bad strides (ld_qk %% 8, ld_out %% 4, Tp %% 8)");
+    OWL_CHECK_ARG(ld_qk % 8 == 0 && ld_out % 8 == 0 && Tp % 8 == 0 && T > 0 && T <= Tp, "owl_attention_fwd_bf16: bad strides (ld_qk %% 8, ld_out %% 8, Tp %% 8)");
     AttnFwdP p{};
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.ld_qk = ld_qk;
     p.vt = (const bf16_t*)vt; p.vt_img_stride = vt_img_stride;
