@@ -246,20 +246,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdP p) {
         __syncthreads();
         cur ^= 1;
     }
+    uint4 stk[2][2], stv[2][2];
+    pack_token_rows(dk, p.scale, stk);              // 16-byte stores (common.h)
+    pack_token_rows(dv, 1.0f, stv);
     if (key_ok) {
         bf16_t* orow = p.dqkv + ((int64_t)b * p.Tp + key) * p.ld_qkv + h * 64;
 #pragma unroll
         for (int d = 0; d < 2; d++)
 #pragma unroll
-            for (int qd = 0; qd < 4; qd++) {
-                const int dd = d * 32 + 8 * qd + 4 * hi;
-                uint2 v;
-                v.x = pack_bf2(dk[d][qd * 4 + 0] * p.scale, dk[d][qd * 4 + 1] * p.scale);
-                v.y = pack_bf2(dk[d][qd * 4 + 2] * p.scale, dk[d][qd * 4 + 3] * p.scale);
-                *(uint2*)(orow + D + dd) = v;
-                v.x = pack_bf2(dv[d][qd * 4 + 0], dv[d][qd * 4 + 1]);
-                v.y = pack_bf2(dv[d][qd * 4 + 2], dv[d][qd * 4 + 3]);
-                *(uint2*)(orow + 2 * D + dd) = v;
+            for (int pr = 0; pr < 2; pr++) {
+                const int dd = d * 32 + 16 * pr + 8 * hi;
+                *(uint4*)(orow + D + dd) = stk[d][pr];
+                *(uint4*)(orow + 2 * D + dd) = stv[d][pr];
             }
     }
 }
@@ -413,17 +411,14 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnBwdP p) {
         cur ^= 1;
     }
     if (nfull < nkv) tile(cur, nfull, std::true_type{});
+    uint4 stq[2][2];
+    pack_token_rows(dq, p.scale, stq);              // 16-byte stores (common.h)
     if (q_ok) {
         bf16_t* orow = p.dqkv + ((int64_t)b * p.Tp + q) * p.ld_qkv + h * 64;
 #pragma unroll
         for (int d = 0; d < 2; d++)
 #pragma unroll
-            for (int qd = 0; qd < 4; qd++) {
-                uint2 v;
-                v.x = pack_bf2(dq[d][qd * 4 + 0] * p.scale, dq[d][qd * 4 + 1] * p.scale);
-                v.y = pack_bf2(dq[d][qd * 4 + 2] * p.scale, dq[d][qd * 4 + 3] * p.scale);
-                *(uint2*)(orow + d * 32 + 8 * qd + 4 * hi) = v;
-            }
+            for (int pr = 0; pr < 2; pr++) *(uint4*)(orow + d * 32 + 16 * pr + 8 * hi) = stq[d][pr];
     }
 }
 

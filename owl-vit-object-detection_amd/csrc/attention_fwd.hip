@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
 #pragma unroll
         for (int t = 0; t < 2; t++)
 #pragma unroll
-            for (int kc = 0; kc < 4; kc++) kfr[t][kc] = *(frag_ptr)(k_addr[t][kc] + BUF * 16384);
+            for (int kc = 0; kc < 4; kc++) kfr[t][kc] = *(frag_ptr)(uintptr_t)(k_addr[t][kc] + BUF * 16384);
         __builtin_amdgcn_sched_barrier(0);
         auto qk = [&](bool sub_max) {
 #pragma unroll
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
                 const int c8 = t * 2 + cc;
 #pragma unroll
                 for (int d = 0; d < 2; d++) {
-                    const bf16x8 vf = *(frag_ptr)(v_addr[d][c8] + BUF * 16384);
+                    const bf16x8 vf = *(frag_ptr)(uintptr_t)(v_addr[d][c8] + BUF * 16384);
                     o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
                 }
             }
@@ -304,26 +304,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     const int qr = q0 + (lane & 31);
-    // 16-byte stores: a lane holds 4 consecutive d of its query per register quad and its partner lane^32 the adjacent 4; one
-    // v_permlane32_swap per packed word pairs them into 8 consecutive d per lane (half the store instructions -- the store tail
-    // of an attention workgroup is issue-bound).  Even quads end up complete in lanes 0-31, odd quads in lanes 32-63.
     uint4 st[2][2];
-#pragma unroll
-    for (int d = 0; d < 2; d++)
-#pragma unroll
-        for (int pr = 0; pr < 2; pr++) {
-            unsigned x[2], y[2];                    // x = even quad (2*pr), y = odd quad (2*pr + 1)
-            x[0] = pack_bf2(o[d][(2 * pr) * 4 + 0] * inv, o[d][(2 * pr) * 4 + 1] * inv);
-            x[1] = pack_bf2(o[d][(2 * pr) * 4 + 2] * inv, o[d][(2 * pr) * 4 + 3] * inv);
-            y[0] = pack_bf2(o[d][(2 * pr + 1) * 4 + 0] * inv, o[d][(2 * pr + 1) * 4 + 1] * inv);
-            y[1] = pack_bf2(o[d][(2 * pr + 1) * 4 + 2] * inv, o[d][(2 * pr + 1) * 4 + 3] * inv);
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                auto r = __builtin_amdgcn_permlane32_swap(x[k], y[k], false, false);   // lanes 32-63 of x <-> lanes 0-31 of y
-                x[k] = r[0]; y[k] = r[1];
-            }
-            st[d][pr] = make_uint4(x[0], x[1], y[0], y[1]);
-        }
+    pack_token_rows(o, inv, st);                    // 16-byte stores (common.h)
     if (qr < p.T) {
         bf16_t* op = p.out + ((int64_t)b * p.Tp + qr) * p.ld_out + h * 64;
 #pragma unroll

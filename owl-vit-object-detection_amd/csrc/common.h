@@ -42,6 +42,29 @@ __device__ __forceinline__ float lds_read_f1(const void* p) {
     return v;
 }
 
+// Two 32x32 MFMA accumulators (rows = 2 x 32 features d, column = the lane's token) -> 4 x 16 bytes of the token's output row.
+// A lane holds 4 consecutive d per register quad and its partner lane^32 the adjacent 4; one v_permlane32_swap per packed word
+// pairs them into 8 consecutive d per lane: st[d][pr] belongs at feature offset d*32 + 16*pr + 8*(lane>>5).  Half the store
+// instructions of the natural 8-byte layout (the store tail of an attention workgroup is issue-bound).  Call with all lanes active.
+__device__ __forceinline__ void pack_token_rows(const f32x16 (&acc)[2], float scale, uint4 (&st)[2][2]) {
+#pragma unroll
+    for (int d = 0; d < 2; d++)
+#pragma unroll
+        for (int pr = 0; pr < 2; pr++) {
+            unsigned x[2], y[2];                    // x = even quad (2*pr), y = odd quad (2*pr + 1)
+            x[0] = pack_bf2(acc[d][(2 * pr) * 4 + 0] * scale, acc[d][(2 * pr) * 4 + 1] * scale);
+            x[1] = pack_bf2(acc[d][(2 * pr) * 4 + 2] * scale, acc[d][(2 * pr) * 4 + 3] * scale);
+            y[0] = pack_bf2(acc[d][(2 * pr + 1) * 4 + 0] * scale, acc[d][(2 * pr + 1) * 4 + 1] * scale);
+            y[1] = pack_bf2(acc[d][(2 * pr + 1) * 4 + 2] * scale, acc[d][(2 * pr + 1) * 4 + 3] * scale);
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                auto r = __builtin_amdgcn_permlane32_swap(x[k], y[k], false, false);   // lanes 32-63 of x <-> lanes 0-31 of y
+                x[k] = r[0]; y[k] = r[1];
+            }
+            st[d][pr] = make_uint4(x[0], x[1], y[0], y[1]);
+        }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -107,9 +107,9 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmP p) {
     bf16x8 fa[2][4], fb[2][4];
     auto load_frags = [&](int slot, int buf, int kc) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) fa[slot][i] = *(frag_ptr)(a_addr[kc] + buf * W4_STAGE + i * 4096);
+        for (int i = 0; i < 4; i++) fa[slot][i] = *(frag_ptr)(uintptr_t)(a_addr[kc] + buf * W4_STAGE + i * 4096);
 #pragma unroll
-        for (int j = 0; j < 4; j++) fb[slot][j] = *(frag_ptr)(b_addr[kc] + buf * W4_STAGE + j * 4096);
+        for (int j = 0; j < 4; j++) fb[slot][j] = *(frag_ptr)(uintptr_t)(b_addr[kc] + buf * W4_STAGE + j * 4096);
     };
 
     // prologue: K-tiles 0 and 1 in flight, K-tile 0 landed, its first fragments requested
