@@ -29,7 +29,7 @@ __device__ __forceinline__ void row_stats(const float4 (&v)[NV], int nvec, int l
 template <bool OUT_BF16>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* x, const bf16_t* __restrict__ delta, float* x_out,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta, void* out,
-                                                     float2* stats, int64_t rows, int D, float eps) {
+                                                     float2* stats, int64_t rows, int D, float eps, const bf16_t* __restrict__ delta2) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -43,7 +43,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* x, const bf16_
             if (delta) {
                 const uint2 u = ((const uint2*)(delta + row * D))[lane + i * 64];
                 v[i].x += bf2f(u.x & 0xffff); v[i].y += bf2f(u.x >> 16); v[i].z += bf2f(u.y & 0xffff); v[i].w += bf2f(u.y >> 16);
-                ((float4*)(x_out + row * D))[lane + i * 64] = v[i];
+                if (delta2) {                       // (x + delta) + delta2: the two branch outputs of a layer whose first add was not stored
+                    const uint2 u2 = ((const uint2*)(delta2 + row * D))[lane + i * 64];
+                    v[i].x += bf2f(u2.x & 0xffff); v[i].y += bf2f(u2.x >> 16); v[i].z += bf2f(u2.y & 0xffff); v[i].w += bf2f(u2.y >> 16);
+                }
+                if (x_out) ((float4*)(x_out + row * D))[lane + i * 64] = v[i];
             }
         }
     float mean, rstd;
@@ -67,15 +71,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* x, const bf16_
 }
 
 static int ln_launch(void* stream, const float* x, const void* delta, float* x_out, const float* gamma, const float* beta, void* out,
-                     int out_bf16, float* stats, int64_t rows, int64_t D, float eps) {
+                     int out_bf16, float* stats, int64_t rows, int64_t D, float eps, const void* delta2 = nullptr) {
     OWL_CHECK_ARG(x && gamma && beta && out, "owl_layernorm_fwd: null pointer");
     OWL_CHECK_ARG(D % 4 == 0 && D <= 256 * LN_MAXV, "owl_layernorm_fwd: D=%lld must be a multiple of 4 and <= 1024", (long long)D);
-    OWL_CHECK_ARG((delta == nullptr) || (x_out != nullptr), "owl_add_layernorm_fwd: x_out required with delta");
+    OWL_CHECK_ARG(delta || !delta2, "owl_add_layernorm_fwd: delta2 without delta");
     dim3 grid((unsigned)((rows + 3) / 4));
     if (out_bf16)
-        hipLaunchKernelGGL(ln_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)delta, x_out, gamma, beta, out, (float2*)stats, rows, (int)D, eps);
+        hipLaunchKernelGGL(ln_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)delta, x_out, gamma, beta, out, (float2*)stats, rows, (int)D, eps, (const bf16_t*)delta2);
     else
-        hipLaunchKernelGGL(ln_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)delta, x_out, gamma, beta, out, (float2*)stats, rows, (int)D, eps);
+        hipLaunchKernelGGL(ln_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)delta, x_out, gamma, beta, out, (float2*)stats, rows, (int)D, eps, (const bf16_t*)delta2);
     OWL_LAUNCH_CHECK();
     return 0;
 }
@@ -85,11 +89,13 @@ extern "C" int owl_layernorm_fwd(void* stream, const float* x, const float* gamm
     return ln_launch(stream, x, nullptr, nullptr, gamma, beta, out, out_bf16, stats, rows, D, eps);
 }
 
-// x_out = x + delta (bf16);  out = LN(x_out)
+// s = x + delta (+ delta2), bf16 branch outputs;  out = LN(s);  x_out = s unless x_out is null (the sum is then re-formed, from the
+// same operands in the same order, by the next call -- saves writing 4 bytes per element where nobody else reads the sum)
 extern "C" int owl_add_layernorm_fwd(void* stream, const float* x, const void* delta_bf16, float* x_out, const float* gamma,
-                                     const float* beta, void* out, int out_bf16, float* stats, int64_t rows, int64_t D, float eps) {
+                                     const float* beta, void* out, int out_bf16, float* stats, int64_t rows, int64_t D, float eps,
+                                     const void* delta2_bf16) {
     OWL_CHECK_ARG(delta_bf16, "owl_add_layernorm_fwd: null delta");
-    return ln_launch(stream, x, delta_bf16, x_out, gamma, beta, out, out_bf16, stats, rows, D, eps);
+    return ln_launch(stream, x, delta_bf16, x_out, gamma, beta, out, out_bf16, stats, rows, D, eps, delta2_bf16);
 }
 
 // Class-token rows: X[b*Tp + 0, :] = class_embedding + pos[0]   (HF5:338-343)

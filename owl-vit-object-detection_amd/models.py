@@ -17,6 +17,7 @@ import math
 from collections import OrderedDict
 
 import numpy as np
+import os
 import torch
 import torch.nn as nn
 
@@ -251,6 +252,7 @@ class OwlViT(nn.Module):
         d1, d2 = ws["d1"], ws["d2"]
         xs = x                  # residual stream BEFORE the pending MLP-branch delta is added
         pending = None          # bf16 output of the previous layer's fc2, not yet added to the residual stream
+        pending1 = None         # ... and of its out-proj, when that layer's second LayerNorm did not store x + delta1 (frozen layers)
         tl = cfg.trainable_layer()
         for i in range(cfg.layers):
             lw = self._layer_weights(i)
@@ -266,7 +268,11 @@ class OwlViT(nn.Module):
                     x_cur.copy_(xs)
                 ops.layernorm(x_cur, lw["g1"], lw["be1"], h, M, D, Ls["st1"] if sv else None, cfg.ln_eps)
             else:
-                ops.layernorm(xs, lw["g1"], lw["be1"], h, M, D, Ls["st1"] if sv else None, cfg.ln_eps, delta=pending, x_out=x_cur)
+                if pending1 is None:
+                    ops.layernorm(xs, lw["g1"], lw["be1"], h, M, D, Ls["st1"] if sv else None, cfg.ln_eps, delta=pending, x_out=x_cur)
+                else:       # (xs + delta1) + delta2, same operands and order as the two separate adds
+                    ops.layernorm(xs, lw["g1"], lw["be1"], h, M, D, Ls["st1"] if sv else None, cfg.ln_eps, delta=pending1, delta2=pending,
+                                  x_out=x_cur)
             if sv:   # row-major q,k,v and per-head transposed q,k,v (attention-backward operands)
                 qkv_l, qkvT_l = Ls["qkv"], Ls["qkvT"]
                 ops.gemm(ops.EPI_BIAS_BF16, h, lw["wqkv"], qkv_l, bias=lw["bqkv"], M=M, N=3 * D, K=D, ldo=3 * D)
@@ -284,11 +290,17 @@ class OwlViT(nn.Module):
             ops.gemm(ops.EPI_BIAS_BF16, att_l, lw["wo"], d1, bias=lw["bo"], M=M, N=D, K=D)
             x_mid = Ls["x_mid"] if sv else x_cur
             h2 = Ls["h2"] if full else ws["h"]
-            ops.layernorm(x_cur, lw["g2"], lw["be2"], h2, M, D, Ls["st2"] if sv else None, cfg.ln_eps, delta=d1, x_out=x_mid)
+            # A frozen layer's x + delta1 is read by nobody but the next LayerNorm: it is not stored (4 bytes per element), that
+            # LayerNorm adds both branch outputs instead (2 more bytes read).  Layers whose activations are kept, and the last one
+            # (the merge kernel takes a single delta), store it.
+            defer = (not sv) and (i + 1 < cfg.layers)
+            ops.layernorm(x_cur, lw["g2"], lw["be2"], h2, M, D, Ls["st2"] if sv else None, cfg.ln_eps, delta=d1, x_out=x_mid,
+                          store_x=not defer)
             g_l = Ls["g"] if full else g
             ops.gemm(ops.EPI_QGELU_BF16, h2, lw["w1"], g_l, bias=lw["b1"], aux=Ls["u"] if sv else None, M=M, N=I, K=D)
             ops.gemm(ops.EPI_BIAS_BF16, g_l, lw["w2"], d2, bias=lw["b2"], M=M, N=D, K=I)
             pending, xs = d2, x_mid
+            pending1 = d1 if defer else None
 
         # ---- final residual add + post_layernorm (all tokens) * class token -> post_post_layernorm
         #      (ref src/models.py:80-86); the final residual stream is materialised in `x` for the backward
