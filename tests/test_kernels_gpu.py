@@ -335,3 +335,28 @@ def test_transpose_tokens_matches_torch(B, T, ncols, ld):
     ref = src[: B * Tp].view(B, Tp, ld)[:, :, :ncols].transpose(1, 2).contiguous()
     assert torch.equal(dst[: B * ncols * Tp].view(B, ncols, Tp), ref)
     assert float(dst[B * ncols * Tp:].abs().max()) == 0.0          # nothing written past the end
+
+
+def test_add2_layernorm_matches_two_separate_adds():
+    """(x + d1) + d2 formed inside the LayerNorm equals storing x + d1 first and adding d2 in the next call, bit for bit;
+    store_x=False leaves x untouched."""
+    torch.manual_seed(5)
+    rows, D = 1000, 768
+    x = torch.randn(ops.pad_rows(rows), D, device=DEV)
+    d1 = (torch.randn(ops.pad_rows(rows), D, device=DEV) * 0.3).bfloat16()
+    d2 = (torch.randn(ops.pad_rows(rows), D, device=DEV) * 0.3).bfloat16()
+    g = torch.randn(D, device=DEV); b = torch.randn(D, device=DEV)
+    # reference: two stored adds
+    xa = x.clone(); ha = torch.zeros_like(d1); hb = torch.zeros_like(d1)
+    ops.layernorm(xa, g, b, ha, rows, D, delta=d1)                       # xa = x + d1
+    ops.layernorm(xa, g, b, hb, rows, D, delta=d2)                       # xa = (x + d1) + d2, hb = LN(xa)
+    # deferred: first LN without the store, second one adds both
+    xb = x.clone(); h1 = torch.zeros_like(d1); h2 = torch.zeros_like(d1); xo = torch.zeros_like(x)
+    ops.layernorm(xb, g, b, h1, rows, D, delta=d1, store_x=False)
+    assert torch.equal(xb, x)                                            # not stored
+    assert torch.equal(h1, ha)
+    ops.layernorm(xb, g, b, h2, rows, D, delta=d1, delta2=d2, x_out=xo)
+    assert torch.equal(h2, hb) and torch.equal(xo[:rows], xa[:rows])
+    # torch reference of the sum
+    ref = (x[:rows] + d1[:rows].float()) + d2[:rows].float()
+    assert torch.equal(xo[:rows], ref)
