@@ -111,8 +111,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
     //    is 1.0 in contraction slot 0 and whose Q-side fragment holds -M there (M is kept bf16-exact, so the product is
     //    exact) -- S arrives as s*c - M and P = exp2(S) needs no VALU fma (the matrix pipe is 45 % busy, it has room);
     //  * no per-tile row maximum: the tile keeps the OLD M as long as P cannot overflow -- checked on the tile's row
-    //    sums (sum <= 2^40, also catches inf / NaN); only a tile that fails the check (and the first tile) takes the
-    //    slow path: recompute S with C = 0, explicit maximum, rescale O and l, new splat.
+    //    sums (sum <= 2^40, also catches inf / NaN); only a tile that fails the check takes the
+    //    slow path: recompute S with C = 0, explicit maximum, rescale O and l, new splat;
+    //  * the offset starts at ZERO (no offset MFMA at all: 16 instead of 18 MFMAs per tile) and is only set by the first tile
+    //    that fails the check (overflow, or -- first tile -- a row about to underflow): scores of ordinary size never need one.
     // Per 64-key tile: 32 exp + 32 add + 16 cvt_pk + a handful, instead of ~190 VALU instructions.
 #pragma unroll
     for (int kc = 0; kc < 4; kc++) {
@@ -125,7 +127,12 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
         const uint4 q4 = make_uint4(wq[0], wq[1], wq[2], wq[3]);
         qf[kc] = __builtin_bit_cast(bf16x8, q4);
     }
-    float M = -1e30f;                                            // running maximum of the SCALED scores (log2 domain), bf16-exact
+    // Offset subtracted from the SCALED scores (log2 domain), bf16-exact.  It starts at 0 -- no offset, and no offset MFMA -- and
+    // stays there as long as the row sums neither overflow nor (first tile) underflow: for scores of ordinary size the whole row is
+    // exponentiated as it is (f32 / bf16 exponent range), and a tile costs 16 MFMAs instead of 18.  The first tile that fails the
+    // check sets it to the row maximum (slow path below); from then on the offset rides in on the extra MFMA as before.
+    float M = 0.f;
+    bool have_m = false;                                         // wave-uniform: an offset has been set
     // contraction slot 0 (= element 0 of the lanes with hi == 0): K side all ones, Q side -M of the lane's query column
     const uint4 ones4 = make_uint4(hi == 0 ? 0x3F80u : 0u, 0u, 0u, 0u);
     const bf16x8 kones = __builtin_bit_cast(bf16x8, ones4);
@@ -176,7 +183,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
 #pragma unroll
             for (int kc = 0; kc < 4; kc++) kfr[t][kc] = *(frag_ptr)(uintptr_t)(k_addr[t][kc] + BUF * 16384);
         __builtin_amdgcn_sched_barrier(0);
-        auto qk = [&](bool sub_max) {
+        auto qk = [&](auto sub_tag) {
+            constexpr bool sub_max = decltype(sub_tag)::value;
 #pragma unroll
             for (int t = 0; t < 2; t++) {
                 if (t == 1 && half_only) continue;
@@ -197,10 +205,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
                     }
             }
         };
-        bool slow = first || (p.dbg & 1);
+        bool slow = (p.dbg & 1) || (first && (p.dbg & 4));    // (bit 2: old behaviour, the first tile always sets the offset)
         float ts = 0.f;
         if (!slow) {
-            qk(true);                                            // s = score*c - M
+            if (have_m) qk(std::true_type{}); else qk(std::false_type{});      // s = score*c - M   (M = 0: no offset MFMA)
 #pragma unroll
             for (int t = 0; t < 2; t++)
 #pragma unroll
@@ -208,19 +216,22 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
                     s[t][r] = __builtin_amdgcn_exp2f(s[t][r]);
                     ts += s[t][r];
                 }
-            slow = __any(!(ts <= 1.0995116e12f));                // 2^40: P may have overflowed (or is about to): redo with a new M
+            // 2^40: P may have overflowed (or is about to); first tile only: 2^-60, the whole row may be about to underflow
+            slow = __any(!(ts <= 1.0995116e12f) || (first && ts < 8.6736174e-19f));
         }
         if (slow) {                                              // wave-uniform
-            qk(false);                                           // s = score*c
+            qk(std::false_type{});                               // s = score*c
             float mx = s[0][0];
 #pragma unroll
             for (int t = 0; t < 2; t++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[t][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float M_new = bf2f(f2bf(fmaxf(M, mx)));          // bf16-exact (round to nearest: P may exceed 1 by 2^-8, harmless)
-            const float alpha = __builtin_amdgcn_exp2f(M - M_new);
+            // bf16-exact (round to nearest: P may exceed 1 by 2^-8, harmless); on the first tile nothing has been accumulated yet
+            const float M_new = bf2f(f2bf(first ? mx : fmaxf(M, mx)));
+            const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(M - M_new);
             M = M_new;
+            have_m = true;
             l_part *= alpha;
 #pragma unroll
             for (int d = 0; d < 2; d++)
