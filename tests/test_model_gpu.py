@@ -67,6 +67,25 @@ def test_forward_b16_matches_reference_fixture_f2(golden_dir):
     assert _maxerr(pb8[0], pb[0]) < 1e-6 and _maxerr(ps8[0], ps[0]) < 1e-6
 
 
+def test_forward_b32_default_arch_matches_oracle():
+    """What the reference actually loads (src/models.py:152: google/owlvit-base-patch32, 24 x 24 patches of 32 px, T = 577):
+    `load_model`'s default arch, through the reference call surface, against the CPU oracle on the same weights."""
+    from owl_vit_object_detection_amd.models import load_model
+    labelmap = {str(i): i for i in range(10)}
+    model = load_model(labelmap, DEV).eval()
+    cfg = model.cfg
+    assert cfg.name == "owlvit-base-patch32" and cfg.patches == 576 and cfg.tokens == 577
+    img = synth.make_images(cfg, 2)
+    with torch.no_grad():
+        pb, n1, ps, n2 = model(torch.from_numpy(img).to(DEV))
+    assert n1 is None and n2 is None and pb.shape == (2, 576, 4) and ps.shape == (2, 576, 10)
+    w = {k: torch.from_numpy(v) for k, v in weights.make_weights(cfg).items()}
+    rb, rs = O.model_forward(cfg, w, torch.from_numpy(img))
+    eb, es = _maxerr(pb, rb), _maxerr(ps, rs)
+    print(f"B/32: max|d boxes|={eb:.3e} max|d sims|={es:.3e}")
+    assert eb < 1e-2 and es < 1e-2
+
+
 # ---------------------------------------------------------------------------------------------------
 # full train step: forward + matcher/loss + backward through the reference call surface
 # ---------------------------------------------------------------------------------------------------
