@@ -120,20 +120,23 @@ def main():
 
     # ---- dominant-kernel timing: HIP events around every fused-attention-forward launch --------------
     attn_events = []
-    orig_attn = ops.attention_fwd
     record = {"on": False}
 
-    def timed_attn(*a, **k):
-        if not record["on"]:
-            return orig_attn(*a, **k)
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        r = orig_attn(*a, **k)
-        e1.record()
-        attn_events.append((e0, e1))
-        return r
+    def timed(orig):
+        def f(*a, **k):
+            if not record["on"]:
+                return orig(*a, **k)
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig(*a, **k)
+            e1.record()
+            attn_events.append((e0, e1))
+            return r
+        return f
 
-    ops.attention_fwd = timed_attn
+    # the model calls the V-row-major entry (one QKV GEMM, no V^T copy); the V^T entry is hooked too for completeness
+    ops.attention_fwd_vrow = timed(ops.attention_fwd_vrow)
+    ops.attention_fwd = timed(ops.attention_fwd)
 
     def step(i):
         img, tg, _ = batches[i % len(batches)]
@@ -186,7 +189,7 @@ def main():
                        "global_batch": B * world, "tokens": cfg.tokens, "parallelism": f"dp{world}",
                        "gflop_per_image": round(flops_img / 1e9, 1),
                        "step_mfma_frac": round(flops_img * value / world / 1e12 / PEAK_BF16_TFLOPS, 4)},
-            "roofline": {"bound": "mfma", "kernel": "attn_fwd_kernel", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": "attn_fwd_kernel<VROW>", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                          # HBM bytes per launch from PMC (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_attn_fwd.md): measured for
                          # the default workload only (algorithmic = 4*M*D*2 B = 454 MB; r01_pmc_final.md)

@@ -70,6 +70,10 @@ int owl_add_layernorm_fwd(void* stream, const float* x, const void* delta_bf16, 
  * q, k row-major [B*Tp, ld_qk] (head h at column h*64); vt = V^T per head [B][..][64][Tp] as written
  * by epilogue 6; out row-major [B*Tp, ld_out]; lse optional [B,H,Tp] (log2 domain).               */
 int owl_attention_fwd_bf16(void* stream, const void* q, const void* k, int64_t ld_qk, const void* vt, int64_t vt_img_stride, void* out, int64_t ld_out, float* lse, int64_t B, int64_t H, int64_t T, int64_t Tp, float scale);
+/* Same fused attention forward with V read where the QKV GEMM leaves it: `v` = row-major [B*Tp, ld_qkv] (same row stride as q and k),
+ * head h at column h*64 of `v`; the [64 key][64 d] tile is transposed by the LDS hardware (ds_read_b64_tr_b16), so the frozen layers
+ * need no V^T copy and run ONE N = 3D QKV GEMM (HF5:437-439).  Bit-identical to owl_attention_fwd_bf16 on the same data. */
+int owl_attention_fwd_vrow_bf16(void* stream, const void* q, const void* k, const void* v, int64_t ld_qkv, void* out, int64_t ld_out, float* lse, int64_t B, int64_t H, int64_t T, int64_t Tp, float scale);
 
 /* tuning / race-hunting switches (bit 0: always rescale, bit 1: plain block mapping, bit 2: lgkmcnt(0) before barriers) */
 int owl_attention_debug(int flags);
@@ -169,8 +173,9 @@ int owl_cast_f32_bf16(void* stream, const float* in, void* out, int64_t n);
 int owl_transpose_bf16(void* stream, const void* in, int64_t ld_in, void* out, int64_t ld_out, int64_t R, int64_t C);
 /* out[b][c][t] = in[b*Tp + t][c], c < ncols (per-image token transpose of row-major activations into the per-head
  * transposed layout of epilogue 6; replaces the second, transposing QKV GEMM of the layers whose attention runs backward:
- * HF5:428-459 saved-for-backward operands).  Tp % 8 == 0, ncols % 64 == 0, ld_in % 8 == 0. */
-int owl_transpose_tokens_bf16(void* stream, const void* in, int64_t ld_in, void* out, int64_t B, int64_t Tp, int64_t ncols);
+ * HF5:428-459 saved-for-backward operands).  Tp % 8 == 0, ncols % 64 == 0, ld_in % 8 == 0; `out` holds out_cols (>= ncols,
+ * 0 = ncols) rows per image, of which the first ncols are written. */
+int owl_transpose_tokens_bf16(void* stream, const void* in, int64_t ld_in, void* out, int64_t B, int64_t Tp, int64_t ncols, int64_t out_cols);
 
 #ifdef __cplusplus
 }

@@ -27,6 +27,16 @@ struct AttnFwdP {
 
 __device__ __forceinline__ int swap23(int m) { return (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1); }
 
+// 16-byte-chunk swizzle of the ROW-MAJOR V tile (VROW): the transpose-reads of one half-wave touch rows r0..r0+3 x 64 B, rows r0 and
+// r0+2 on the same half of the bank row -- bit 2 of the chunk index must differ between them
+__device__ __forceinline__ int swz_vrow(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+
+// VROW = false: V arrives per head TRANSPOSED (V^T [B][heads*64][Tp], written by a transposing GEMM epilogue or a token transpose).
+// VROW = true : V is read where the QKV GEMM leaves it (row-major, column 2D + h*64 of the qkv rows); the [64 key][64 d] tile is
+//               staged exactly like the K tile and transposed by the LDS hardware (`ds_read_b64_tr_b16`, two per fragment).
+template <bool VROW>
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
     // dynamic LDS (one object): with a static array hipcc drains the just-issued LDS-DMA (vmcnt(0)) before the
     // first ds_read of every tile
@@ -56,7 +66,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
 
     // ---- staging sources: wave w stages rows [w*16, w*16+16) of both tiles (2 DMA each) --------
     const bf16_t* kbase = p.k + (int64_t)b * p.Tp * p.ld_qk + h * 64;
-    const bf16_t* vbase = p.vt + (int64_t)b * p.vt_img_stride + (int64_t)h * 64 * p.Tp;
+    const bf16_t* vbase = VROW ? p.vt + (int64_t)b * p.Tp * p.ld_qk + h * 64
+                               : p.vt + (int64_t)b * p.vt_img_stride + (int64_t)h * 64 * p.Tp;
     // Per-lane byte offsets of this lane's two DMA rows inside a 64-key tile (K) / inside the head's V^T block; the
     // tile's own offset is wave-uniform and is added on the scalar unit, so staging costs no VALU work per tile
     // (the kernel is VALU-bound; the per-tile 64-bit address products were ~10 % of its VALU time).
@@ -66,7 +77,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
         const int r = (w * 2 + qd) * 8 + (lane >> 3);
         const int ch = (lane & 7) ^ ((r >> 1) & 7);
         k_voff[qd] = (unsigned)((r * p.ld_qk + ch * 8) * 2);
-        v_voff[qd] = (unsigned)((r * p.Tp + ch * 8) * 2);          // V^T row r = d; 8 keys per chunk
+        if constexpr (VROW) v_voff[qd] = (unsigned)((r * p.ld_qk + ((lane & 7) ^ swz_vrow(r)) * 8) * 2);    // V row r = key
+        else v_voff[qd] = (unsigned)((r * p.Tp + ch * 8) * 2);     // V^T row r = d; 8 keys per chunk
     }
     // Full tiles go through `buffer_load_dwordx4 ... offen lds`: the (image, head) base sits in a buffer descriptor, the
     // tile offset in an SGPR and the lane's row/chunk offset in one VGPR computed once -- no VALU work per tile (the
@@ -80,7 +92,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
         for (int qd = 0; qd < 2; qd++) {
             const int r0 = (w * 2 + qd) * 8;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, LPTR(base + r0 * 128), 16, (int)k_voff[qd], kv * k_tile_bytes, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, LPTR(base + 8192 + r0 * 128), 16, (int)v_voff[qd], kv * 128, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, LPTR(base + 8192 + r0 * 128), 16, (int)v_voff[qd], VROW ? kv * k_tile_bytes : kv * 128, 0, 0);
         }
     };
     auto stage_clamped = [&](int buf, int kv) {                    // the partial last tile: key rows >= T re-read row T-1
@@ -93,8 +105,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
             int key = kv * 64 + r;
             if (key >= p.T) key = p.T - 1;
             __builtin_amdgcn_global_load_lds(GPTR(kbase + (int64_t)key * p.ld_qk + ch * 8), LPTR(base + r0 * 128), 16, 0, 0);
-            // reads past T are finite junk, masked by P = 0
-            __builtin_amdgcn_global_load_lds(GPTR(vbase + (int64_t)r * p.Tp + kv * 64 + ch * 8), LPTR(base + 8192 + r0 * 128), 16, 0, 0);
+            if constexpr (VROW)          // same clamp as K: a row past T would be multiplied by P = 0, but must be finite
+                __builtin_amdgcn_global_load_lds(GPTR(vbase + (int64_t)key * p.ld_qk + ((lane & 7) ^ swz_vrow(r)) * 8), LPTR(base + 8192 + r0 * 128), 16, 0, 0);
+            else                         // reads past T are finite junk, masked by P = 0
+                __builtin_amdgcn_global_load_lds(GPTR(vbase + (int64_t)r * p.Tp + kv * 64 + ch * 8), LPTR(base + 8192 + r0 * 128), 16, 0, 0);
         }
     };
 
@@ -152,6 +166,19 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
         const int rv = t * 32 + (lane & 31);
 #pragma unroll
         for (int c8 = 0; c8 < 4; c8++) v_addr[t][c8] = lds0 + 8192 + rv * 128 + (((c8 * 2 + hi) ^ ((rv >> 1) & 7)) << 4);   // [d-block t][chunk c8]
+        if constexpr (VROW) {
+            // transpose-read addresses, [d-block t][half h2 of the lane's 8 keys]: inside its 16-lane group (g = lane>>4) lane j
+            // supplies key row (g>>1)*8 + h2*4 + (j>>2), feature quad (j&3) of the group's 16 features t*32 + (g&1)*16 + ..., and
+            // receives feature t*32 + (lane&31) for that row's four keys; the 16-key step c8 is an immediate (2 KiB: the swizzle
+            // does not depend on it)
+            const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; h2++) {
+                const int row = (g >> 1) * 8 + h2 * 4 + (j >> 2);
+                const int chunk = t * 4 + (g & 1) * 2 + ((j & 3) >> 1);
+                v_addr[t][h2] = lds0 + 8192 + row * 128 + ((chunk ^ swz_vrow(row)) << 4) + (j & 1) * 8;
+            }
+        }
     }
     // opaque to the optimiser, which otherwise re-derives each address from its row and chunk parts at every use
 #pragma unroll
@@ -262,7 +289,14 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
                 const int c8 = t * 2 + cc;
 #pragma unroll
                 for (int d = 0; d < 2; d++) {
-                    const bf16x8 vf = *(frag_ptr)(uintptr_t)(v_addr[d][c8] + BUF * 16384);
+                    bf16x8 vf;
+                    if constexpr (VROW) {
+                        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(uintptr_t)(v_addr[d][0] + c8 * 2048 + BUF * 16384));
+                        const s16x4_t hh = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(uintptr_t)(v_addr[d][1] + c8 * 2048 + BUF * 16384));
+                        vf = __builtin_shufflevector(lo, hh, 0, 1, 2, 3, 4, 5, 6, 7);
+                    } else {
+                        vf = *(frag_ptr)(uintptr_t)(v_addr[d][c8] + BUF * 16384);
+                    }
                     o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
                 }
             }
@@ -330,21 +364,34 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
 static int g_attn_dbg = 0;
 extern "C" int owl_attention_debug(int flags) { g_attn_dbg = flags; return 0; }
 
-extern "C" int owl_attention_fwd_bf16(void* stream, const void* q, const void* k, int64_t ld_qk, const void* vt,
-                                      int64_t vt_img_stride, void* out, int64_t ld_out, float* lse, int64_t B,
-                                      int64_t H, int64_t T, int64_t Tp, float scale) {
-    OWL_CHECK_ARG(q && k && vt && out, "owl_attention_fwd_bf16: null pointer");
+static int attn_fwd_launch(void* stream, const void* q, const void* k, int64_t ld_qk, const void* v, int v_row_major,
+                           int64_t vt_img_stride, void* out, int64_t ld_out, float* lse, int64_t B, int64_t H, int64_t T,
+                           int64_t Tp, float scale) {
+    OWL_CHECK_ARG(q && k && v && out, "owl_attention_fwd_bf16: null pointer");
     OWL_CHECK_ARG(ld_qk % 8 == 0 && ld_out % 8 == 0 && Tp % 8 == 0 && T > 0 && T <= Tp, "owl_attention_fwd_bf16: bad strides (ld_qk %% 8, ld_out %% 8, Tp %% 8)");
     AttnFwdP p{};
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.ld_qk = ld_qk;
-    p.vt = (const bf16_t*)vt; p.vt_img_stride = vt_img_stride;
+    p.vt = (const bf16_t*)v; p.vt_img_stride = vt_img_stride;
     p.out = (bf16_t*)out; p.ld_out = ld_out; p.lse = lse;
     p.T = (int)T; p.Tp = (int)Tp; p.H = (int)H;
     p.scale_log2e = scale * 1.4426950408889634f;
     p.B = (int)B; p.nqb = (int)((T + 127) / 128); p.dbg = g_attn_dbg;
     const int64_t npairs8 = (B * H + 7) / 8;                  // pairs per XCD (rounded up)
     dim3 grid((unsigned)(npairs8 * p.nqb * 8));
-    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 2 * 16384, (hipStream_t)stream, p);
+    if (v_row_major) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 2 * 16384, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 2 * 16384, (hipStream_t)stream, p);
     OWL_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int owl_attention_fwd_bf16(void* stream, const void* q, const void* k, int64_t ld_qk, const void* vt,
+                                      int64_t vt_img_stride, void* out, int64_t ld_out, float* lse, int64_t B,
+                                      int64_t H, int64_t T, int64_t Tp, float scale) {
+    return attn_fwd_launch(stream, q, k, ld_qk, vt, 0, vt_img_stride, out, ld_out, lse, B, H, T, Tp, scale);
+}
+
+// same, with V read where the QKV GEMM leaves it: row-major [B*Tp, ld_qkv], head h at column h*64 of `v` (no V^T copy at all)
+extern "C" int owl_attention_fwd_vrow_bf16(void* stream, const void* q, const void* k, const void* v, int64_t ld_qkv, void* out,
+                                           int64_t ld_out, float* lse, int64_t B, int64_t H, int64_t T, int64_t Tp, float scale) {
+    return attn_fwd_launch(stream, q, k, ld_qkv, v, 1, 0, out, ld_out, lse, B, H, T, Tp, scale);
 }

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
 // as 16 bytes = 8 tokens of one column, 8 lanes per 128-byte output row segment.
 template <int TT, int TC>      // tile: TT tokens x TC columns
 __global__ __launch_bounds__(256) void transpose_tokens_kernel(const bf16_t* __restrict__ in, int64_t ld_in, bf16_t* __restrict__ out,
-                                                               int Tp, int ncols) {
+                                                               int Tp, int ncols) {   // ncols here = rows per image of `out`
     __shared__ bf16_t tile[TC][TT + 2];
     const int b = blockIdx.z, t0 = blockIdx.y * TT, c0 = blockIdx.x * TC;
     const int i = threadIdx.x;
@@ -79,15 +79,18 @@ __global__ __launch_bounds__(256) void transpose_tokens_kernel(const bf16_t* __r
     }
 }
 
-extern "C" int owl_transpose_tokens_bf16(void* stream, const void* in, int64_t ld_in, void* out, int64_t B, int64_t Tp, int64_t ncols) {
+extern "C" int owl_transpose_tokens_bf16(void* stream, const void* in, int64_t ld_in, void* out, int64_t B, int64_t Tp, int64_t ncols,
+                                         int64_t out_cols) {
     OWL_CHECK_ARG(in && out && B > 0 && Tp > 0 && ncols > 0, "owl_transpose_tokens_bf16: bad args");
     OWL_CHECK_ARG(Tp % 8 == 0 && ncols % 64 == 0 && ld_in % 8 == 0, "owl_transpose_tokens_bf16: Tp %% 8, ncols %% 64, ld_in %% 8");
+    if (out_cols <= 0) out_cols = ncols;
+    OWL_CHECK_ARG(out_cols >= ncols, "owl_transpose_tokens_bf16: out_cols < ncols");
     if (ncols % 128 == 0 && Tp >= 512) {             // 256-byte segments on both sides
         dim3 grid((unsigned)(ncols / 128), (unsigned)((Tp + 127) / 128), (unsigned)B);
-        hipLaunchKernelGGL((transpose_tokens_kernel<128, 128>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, ld_in, (bf16_t*)out, (int)Tp, (int)ncols);
+        hipLaunchKernelGGL((transpose_tokens_kernel<128, 128>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, ld_in, (bf16_t*)out, (int)Tp, (int)out_cols);
     } else {
         dim3 grid((unsigned)(ncols / 64), (unsigned)((Tp + 63) / 64), (unsigned)B);
-        hipLaunchKernelGGL((transpose_tokens_kernel<64, 64>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, ld_in, (bf16_t*)out, (int)Tp, (int)ncols);
+        hipLaunchKernelGGL((transpose_tokens_kernel<64, 64>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, ld_in, (bf16_t*)out, (int)Tp, (int)out_cols);
     }
     OWL_LAUNCH_CHECK();
     return 0;

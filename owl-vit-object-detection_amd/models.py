@@ -185,7 +185,6 @@ class OwlViT(nn.Module):
         z = ops.zeros_rows
         ws = dict(
             x=z(M, D, f32, dev), h=z(M, D, bf, dev), qkv=z(M, 3 * D, bf, dev),
-            qkvT=torch.zeros(B * 3 * D * Tp + 256, dtype=bf, device=dev),   # [B][3D][Tp] (+ slack for tile over-read)
             att=z(M, D, bf, dev), g=z(M, I, bf, dev), d1=z(M, D, bf, dev), d2=z(M, D, bf, dev),
             im2row=None if self._patch_fused else z(Mh, self._patch_kpad, bf, dev),
             # heads
@@ -248,7 +247,7 @@ class OwlViT(nn.Module):
         ops.layernorm(x, P_["backbone.pre_layernorm.weight"], P_["backbone.pre_layernorm.bias"], x, M, D, eps=cfg.ln_eps)
 
         scale = cfg.head_dim ** -0.5
-        qkv, qkvT, att, g = ws["qkv"], ws["qkvT"], ws["att"], ws["g"]
+        qkv, att, g = ws["qkv"], ws["att"], ws["g"]
         d1, d2 = ws["d1"], ws["d2"]
         xs = x                  # residual stream BEFORE the pending MLP-branch delta is added
         pending = None          # bf16 output of the previous layer's fc2, not yet added to the residual stream
@@ -273,20 +272,15 @@ class OwlViT(nn.Module):
                 else:       # (xs + delta1) + delta2, same operands and order as the two separate adds
                     ops.layernorm(xs, lw["g1"], lw["be1"], h, M, D, Ls["st1"] if sv else None, cfg.ln_eps, delta=pending1, delta2=pending,
                                   x_out=x_cur)
-            if sv:   # row-major q,k,v and per-head transposed q,k,v (attention-backward operands)
-                qkv_l, qkvT_l = Ls["qkv"], Ls["qkvT"]
-                ops.gemm(ops.EPI_BIAS_BF16, h, lw["wqkv"], qkv_l, bias=lw["bqkv"], M=M, N=3 * D, K=D, ldo=3 * D)
-                # the attention-backward operands Q^T / K^T (and V^T for this layer's own forward): an HBM-bound token transpose of
-                # the row-major result (same bits as a second GEMM with the transposing epilogue, a third of its time)
-                ops.transpose_tokens(qkv_l, qkvT_l, B, Tp, 3 * D)
-                vt, vt_stride = qkvT_l[2 * D * Tp:], 3 * D * Tp
-            else:    # row-major q,k ; V only transposed
-                qkv_l = qkv
-                ops.gemm(ops.EPI_BIAS_BF16, h, lw["wqkv"], qkv, bias=lw["bqkv"], M=M, N=2 * D, K=D, ldo=3 * D, w_rows=2 * D)
-                ops.gemm(ops.EPI_TRANS_BF16, h, lw["wqkv"][2 * D:], qkvT, bias=lw["bqkv"][2 * D:], M=M, N=D, K=D, Tp=Tp, w_rows=D)
-                vt, vt_stride = qkvT, D * Tp
+            # ONE row-major QKV GEMM per layer; the fused attention reads V where that GEMM leaves it (LDS transpose-reads), so no
+            # layer needs a V^T copy.  Layers whose attention runs backward also keep per-head Q^T / K^T (an HBM-bound token
+            # transpose of the row-major result: same bits as a second GEMM with the transposing epilogue, a third of its time).
+            qkv_l = Ls["qkv"] if sv else qkv
+            ops.gemm(ops.EPI_BIAS_BF16, h, lw["wqkv"], qkv_l, bias=lw["bqkv"], M=M, N=3 * D, K=D, ldo=3 * D)
+            if sv:
+                ops.transpose_tokens(qkv_l, Ls["qkvT"], B, Tp, 2 * D, out_cols=3 * D)
             att_l = Ls["att"] if sv else att
-            ops.attention_fwd(qkv_l, qkv_l[:, D:], 3 * D, vt, vt_stride, att_l, D, Ls["lse"] if sv else None, B, H, T, Tp, scale)
+            ops.attention_fwd_vrow(qkv_l, qkv_l[:, D:], qkv_l[:, 2 * D:], 3 * D, att_l, D, Ls["lse"] if sv else None, B, H, T, Tp, scale)
             ops.gemm(ops.EPI_BIAS_BF16, att_l, lw["wo"], d1, bias=lw["bo"], M=M, N=D, K=D)
             x_mid = Ls["x_mid"] if sv else x_cur
             h2 = Ls["h2"] if full else ws["h"]

@@ -86,6 +86,12 @@ def attention_fwd(q, k, ld_qk, vt, vt_img_stride, out, ld_out, lse, B, H, T, Tp,
     return out
 
 
+def attention_fwd_vrow(q, k, v, ld_qkv, out, ld_out, lse, B, H, T, Tp, scale):
+    """attention_fwd with V row-major (a column slice of the qkv rows): no V^T copy."""
+    _lib.call("owl_attention_fwd_vrow_bf16", stream(), q, k, v, ld_qkv, out, ld_out, lse, B, H, T, Tp, float(scale))
+    return out
+
+
 def merge_ln(x, g1, b1, g2, b2, cls_ln, feats, stats1, stats2, B, P, Tp, D, eps=1e-5, delta=None, x_out=None):
     _lib.call("owl_merge_ln_fwd", stream(), x, delta, (x_out if x_out is not None else x) if delta is not None else None,
               g1, b1, g2, b2, cls_ln, feats, stats1, stats2, B, P, Tp, D, float(eps))
@@ -120,10 +126,11 @@ def transpose_bf16(src, dst, R, C, ld_in=None, ld_out=None):
     return dst
 
 
-def transpose_tokens(src, dst, B, Tp, ncols, ld_in=None):
-    """dst[b][c][t] = src[b*Tp + t][c], c < ncols: the per-head transposed layout of EPI_TRANS from row-major activations."""
+def transpose_tokens(src, dst, B, Tp, ncols, ld_in=None, out_cols=0):
+    """dst[b][c][t] = src[b*Tp + t][c], c < ncols: the per-head transposed layout of EPI_TRANS from row-major activations
+    (`out_cols` >= ncols rows per image in dst, default ncols)."""
     _chk(src, torch.bfloat16, "src"); _chk(dst, torch.bfloat16, "dst")
-    _lib.call("owl_transpose_tokens_bf16", stream(), src, ld_in if ld_in is not None else src.shape[-1], dst, B, Tp, ncols)
+    _lib.call("owl_transpose_tokens_bf16", stream(), src, ld_in if ld_in is not None else src.shape[-1], dst, B, Tp, ncols, out_cols)
     return dst
 
 

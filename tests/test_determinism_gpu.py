@@ -108,3 +108,22 @@ def test_attention_bwd_bitwise_repeatable():
     ref = run()
     for _ in range(10):
         assert torch.equal(run(), ref)
+
+
+def test_attention_fwd_vrow_bitwise_repeatable():
+    """The V-row-major variant (the one the model runs): 30 launches, identical bits (LDS transpose-reads behind LDS-DMA)."""
+    torch.manual_seed(9)
+    B, H, T = 8, 12, 2305
+    Tp = (T + 7) // 8 * 8; D = H * 64; M = B * Tp
+    qkv = torch.zeros(ops.pad_rows(M), 3 * D, device=DEV, dtype=torch.bfloat16)
+    qkv[:M] = torch.randn(M, 3 * D, device=DEV).bfloat16()
+
+    def run():
+        out = torch.zeros(ops.pad_rows(M), D, device=DEV, dtype=torch.bfloat16); lse = torch.zeros(B, H, Tp, device=DEV)
+        ops.attention_fwd_vrow(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, out, D, lse, B, H, T, Tp, 0.125)
+        return out, lse
+
+    ref = run()
+    for _ in range(30):
+        got = run()
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])

@@ -360,3 +360,20 @@ def test_add2_layernorm_matches_two_separate_adds():
     # torch reference of the sum
     ref = (x[:rows] + d1[:rows].float()) + d2[:rows].float()
     assert torch.equal(xo[:rows], ref)
+
+
+@pytest.mark.parametrize("B,H,T", [(2, 3, 333), (1, 2, 37), (2, 12, 2305), (1, 16, 3601), (3, 12, 577)])
+def test_attention_fwd_vrow_matches_vt_variant_bitwise(B, H, T):
+    """V read row-major through the LDS transpose-reads gives the very bits of the V^T variant (same MFMAs, same order)."""
+    torch.manual_seed(B * 100 + T)
+    Tp = (T + 7) // 8 * 8; D = H * 64; M = B * Tp
+    qkv = torch.zeros(ops.pad_rows(M), 3 * D, device=DEV, dtype=torch.bfloat16)
+    qkv[:M] = torch.randn(M, 3 * D, device=DEV).bfloat16()
+    vt = torch.zeros(B * D * Tp + 256, device=DEV, dtype=torch.bfloat16)
+    vt[: B * D * Tp].view(B, D, Tp)[:] = qkv[:M, 2 * D:].reshape(B, Tp, D).transpose(1, 2)
+    o1 = torch.zeros(ops.pad_rows(M), D, device=DEV, dtype=torch.bfloat16); l1 = torch.zeros(B, H, Tp, device=DEV)
+    o2 = torch.zeros_like(o1); l2 = torch.zeros_like(l1)
+    ops.attention_fwd(qkv, qkv[:, D:], 3 * D, vt, D * Tp, o1, D, l1, B, H, T, Tp, 0.125)
+    ops.attention_fwd_vrow(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, o2, D, l2, B, H, T, Tp, 0.125)
+    assert torch.equal(o1, o2) and torch.equal(l1, l2)
+    assert bool(torch.isfinite(o2.float()).all())

@@ -13,6 +13,6 @@ A = torch.randn(ops.pad_rows(M), 768, device=DEV).bfloat16()
 W = (torch.randn(3072, 768, device=DEV) * 0.05).bfloat16(); bias = torch.randn(3072, device=DEV)
 u = torch.zeros(ops.pad_rows(M), 3072, device=DEV, dtype=torch.bfloat16)
 for _ in range(5):
-    ops.attention_fwd(qkv, qkv[:, D:], 3 * D, vt, H * 64 * Tp, out, D, None, B, H, T, Tp, 0.125)
+    ops.attention_fwd_vrow(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, out, D, None, B, H, T, Tp, 0.125)     # the variant the model runs
     ops.gemm(ops.EPI_QGELU_BF16, A, W, u, bias=bias, M=M)
 torch.cuda.synchronize()
