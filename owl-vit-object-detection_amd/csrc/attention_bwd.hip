@@ -30,6 +30,7 @@ struct AttnBwdP {
 
 __device__ __forceinline__ int swap23b(int m) { return (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1); }
 __device__ __forceinline__ int tile_off(int row, int ch) { return row * 128 + ((ch ^ ((row >> 1) & 7)) << 4); }
+__device__ __forceinline__ int tile_off_v(int row, int ch) { return row * 128 + ((ch ^ swz_vrow(row)) << 4); }   // transpose-friendly image
 
 // ---- D vector ------------------------------------------------------------------------------------
 // ---- VALU-lean recomputation (same idea as attention_fwd.hip: these kernels are bound by VALU issue, not by the matrix pipe) ----
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdP p) {
 }
 
 // ---- dQ ----------------------------------------------------------------------------------------------
-static constexpr int BWD2_STAGE = 3 * 8192;   // K, V, K^T tiles
+static constexpr int BWD2_STAGE = 2 * 8192;   // K, V tiles (row-major; K^T fragments come out of the K tile by LDS transpose-reads)
 
 __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnBwdP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -301,19 +302,18 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnBwdP p) {
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     const bf16_t* kbase = p.qkv + (int64_t)b * p.Tp * p.ld_qkv + D + h * 64;
-    const bf16_t* ktbase = p.qkvT + ((int64_t)b * 3 * D + D + h * 64) * p.Tp;
-    // staging as in the dK/dV kernel: buffer loads with scalar tile offsets for full tiles, clamped rows for the last one
-    unsigned row_voff[2], col_voff[2];
+    // staging: buffer loads with scalar tile offsets for full tiles, clamped rows for the last one.  Both tiles are row-major
+    // [64 key][64 d] with the transpose-friendly chunk swizzle (common.h): the dQ MFMA's K^T operand is read out of the K tile by
+    // ds_read_b64_tr_b16 -- no K^T copy in HBM, a third less LDS-DMA per tile.
+    unsigned row_voff[2];
 #pragma unroll
     for (int qd = 0; qd < 2; qd++) {
         const int r = (w * 2 + qd) * 8 + (lane >> 3);
-        const int ch = (lane & 7) ^ ((r >> 1) & 7);
+        const int ch = (lane & 7) ^ swz_vrow(r);
         row_voff[qd] = (unsigned)((r * p.ld_qkv + ch * 8) * 2);
-        col_voff[qd] = (unsigned)((r * p.Tp + ch * 8) * 2);
     }
     const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(kbase + D), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t kt_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ktbase, 0, 0x7fffffff, 0x00020000);
     const int k_tile_bytes = (int)(64 * p.ld_qkv * 2);
     auto stage_full = [&](int buf, int kv) {
         unsigned char* base = lds + buf * BWD2_STAGE;
@@ -322,7 +322,6 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnBwdP p) {
             const int r0 = (w * 2 + qd) * 8;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, LPTR(base + r0 * 128), 16, (int)row_voff[qd], kv * k_tile_bytes, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, LPTR(base + 8192 + r0 * 128), 16, (int)row_voff[qd], kv * k_tile_bytes, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(kt_rsrc, LPTR(base + 16384 + r0 * 128), 16, (int)col_voff[qd], kv * 128, 0, 0);
         }
     };
     auto stage_clamped = [&](int buf, int kv) {
@@ -331,19 +330,24 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnBwdP p) {
         for (int qd = 0; qd < 2; qd++) {
             const int r0 = (w * 2 + qd) * 8;
             const int r = r0 + (lane >> 3);
-            const int ch = (lane & 7) ^ ((r >> 1) & 7);
+            const int ch = (lane & 7) ^ swz_vrow(r);
             int key = kv * 64 + r;
             if (key >= p.T) key = p.T - 1;
             const int voff = (key * (int)p.ld_qkv + ch * 8) * 2;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, LPTR(base + r0 * 128), 16, voff, 0, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, LPTR(base + 8192 + r0 * 128), 16, voff, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(kt_rsrc, LPTR(base + 16384 + r0 * 128), 16, (int)col_voff[qd], kv * 128, 0, 0);
         }
     };
     auto stage = [&](int buf, int kv) {
         if (kv * 64 + 64 <= p.T) stage_full(buf, kv); else stage_clamped(buf, kv);
     };
 
+    const unsigned lds0 = (unsigned)(uintptr_t)LPTR(lds);
+    unsigned tr_off[2][2];                                        // [d-block][half of the lane's 8 keys]
+#pragma unroll
+    for (int d = 0; d < 2; d++)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; h2++) tr_off[d][h2] = tr_lane_off(lane, d, h2);
     f32x16 dq[2];
 #pragma unroll
     for (int d = 0; d < 2; d++)
@@ -369,8 +373,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnBwdP p) {
             const int krow = sub * 32 + swap23b(l31);
 #pragma unroll
             for (int kc = 0; kc < 4; kc++) {
-                const bf16x8 ka = *(const bf16x8*)(tb + tile_off(krow, kc * 2 + hi));
-                const bf16x8 va = *(const bf16x8*)(tb + 8192 + tile_off(krow, kc * 2 + hi));
+                const bf16x8 ka = *(const bf16x8*)(tb + tile_off_v(krow, kc * 2 + hi));
+                const bf16x8 va = *(const bf16x8*)(tb + 8192 + tile_off_v(krow, kc * 2 + hi));
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qs[kc], s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[kc], dp, 0, 0, 0);
             }
@@ -388,10 +392,10 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnBwdP p) {
                 }
                 const uint4 dsw = make_uint4(pack_bf2(dsv[0], dsv[1]), pack_bf2(dsv[2], dsv[3]), pack_bf2(dsv[4], dsv[5]), pack_bf2(dsv[6], dsv[7]));
                 const bf16x8 dsf = __builtin_bit_cast(bf16x8, dsw);
-                const int ch = sub * 4 + cc * 2 + hi;
+                const unsigned tk = lds0 + cur * BWD2_STAGE + (sub * 2 + cc) * 2048;     // 16 keys further = 2 KiB
 #pragma unroll
                 for (int d = 0; d < 2; d++) {
-                    const bf16x8 kt = *(const bf16x8*)(tb + 16384 + tile_off(d * 32 + l31, ch));
+                    const bf16x8 kt = lds_tr8(tk + tr_off[d][0], tk + tr_off[d][1]);       // K^T[d*32 + lane&31][8 keys]
                     dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt, dsf, dq[d], 0, 0, 0);
                 }
             }

@@ -27,12 +27,6 @@ struct AttnFwdP {
 
 __device__ __forceinline__ int swap23(int m) { return (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1); }
 
-// 16-byte-chunk swizzle of the ROW-MAJOR V tile (VROW): the transpose-reads of one half-wave touch rows r0..r0+3 x 64 B, rows r0 and
-// r0+2 on the same half of the bank row -- bit 2 of the chunk index must differ between them
-__device__ __forceinline__ int swz_vrow(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
-typedef __attribute__((ext_vector_type(4))) short s16x4_t;
-typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
-
 // VROW = false: V arrives per head TRANSPOSED (V^T [B][heads*64][Tp], written by a transposing GEMM epilogue or a token transpose).
 // VROW = true : V is read where the QKV GEMM leaves it (row-major, column 2D + h*64 of the qkv rows); the [64 key][64 d] tile is
 //               staged exactly like the K tile and transposed by the LDS hardware (`ds_read_b64_tr_b16`, two per fragment).
@@ -171,13 +165,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
             // supplies key row (g>>1)*8 + h2*4 + (j>>2), feature quad (j&3) of the group's 16 features t*32 + (g&1)*16 + ..., and
             // receives feature t*32 + (lane&31) for that row's four keys; the 16-key step c8 is an immediate (2 KiB: the swizzle
             // does not depend on it)
-            const int j = lane & 15, g = lane >> 4;
 #pragma unroll
-            for (int h2 = 0; h2 < 2; h2++) {
-                const int row = (g >> 1) * 8 + h2 * 4 + (j >> 2);
-                const int chunk = t * 4 + (g & 1) * 2 + ((j & 3) >> 1);
-                v_addr[t][h2] = lds0 + 8192 + row * 128 + ((chunk ^ swz_vrow(row)) << 4) + (j & 1) * 8;
-            }
+            for (int h2 = 0; h2 < 2; h2++) v_addr[t][h2] = lds0 + 8192 + tr_lane_off(lane, t, h2);
         }
     }
     // opaque to the optimiser, which otherwise re-derives each address from its row and chunk parts at every use
@@ -291,9 +280,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
                 for (int d = 0; d < 2; d++) {
                     bf16x8 vf;
                     if constexpr (VROW) {
-                        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(uintptr_t)(v_addr[d][0] + c8 * 2048 + BUF * 16384));
-                        const s16x4_t hh = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(uintptr_t)(v_addr[d][1] + c8 * 2048 + BUF * 16384));
-                        vf = __builtin_shufflevector(lo, hh, 0, 1, 2, 3, 4, 5, 6, 7);
+                        vf = lds_tr8(v_addr[d][0] + c8 * 2048 + BUF * 16384, v_addr[d][1] + c8 * 2048 + BUF * 16384);
                     } else {
                         vf = *(frag_ptr)(uintptr_t)(v_addr[d][c8] + BUF * 16384);
                     }

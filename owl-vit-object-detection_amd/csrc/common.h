@@ -42,6 +42,30 @@ __device__ __forceinline__ float lds_read_f1(const void* p) {
     return v;
 }
 
+// ---- LDS hardware transpose (ds_read_b64_tr_b16) of a ROW-MAJOR [64 token][64 feature] bf16 tile with 128-byte rows -----------------
+// 16-byte-chunk swizzle: the transpose-reads of one half-wave touch rows r0..r0+3 x 64 B, rows r0 and r0+2 on the same half of the
+// bank row, so bit 2 of the chunk index must differ between them; the plain ds_read_b128 fragment reads (lane = row) stay conflict-free
+// under the same permutation, so ONE image serves both access kinds.
+__device__ __forceinline__ int swz_vrow(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+// Per-lane byte offset (inside the tile) of the transpose-read that yields, for feature block `fb` (32 features) and half h2 of the
+// lane's 8 tokens, feature fb*32 + (lane&31) of tokens tok16*16 + (lane>>5)*8 + h2*4 + 0..3 -- WITHOUT the tok16*2048 term, which is an
+// immediate for the caller (the swizzle does not depend on it).  Inside its 16-lane group (g = lane>>4) lane j supplies token row
+// (g>>1)*8 + h2*4 + (j>>2) and feature quad (j&3) of the group's 16 features.
+__device__ __forceinline__ unsigned tr_lane_off(int lane, int fb, int h2) {
+    const int j = lane & 15, g = lane >> 4;
+    const int row = (g >> 1) * 8 + h2 * 4 + (j >> 2);
+    const int chunk = fb * 4 + (g & 1) * 2 + ((j & 3) >> 1);
+    return (unsigned)(row * 128 + ((chunk ^ swz_vrow(row)) << 4) + (j & 1) * 8);
+}
+// the 8-element MFMA fragment = two transpose-reads (absolute 32-bit LDS addresses)
+__device__ __forceinline__ bf16x8 lds_tr8(unsigned addr_lo, unsigned addr_hi) {
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(uintptr_t)addr_lo);
+    const s16x4_t hh = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(uintptr_t)addr_hi);
+    return __builtin_shufflevector(lo, hh, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
 // Two 32x32 MFMA accumulators (rows = 2 x 32 features d, column = the lane's token) -> 4 x 16 bytes of the token's output row.
 // A lane holds 4 consecutive d per register quad and its partner lane^32 the adjacent 4; one v_permlane32_swap per packed word
 // pairs them into 8 consecutive d per lane: st[d][pr] belongs at feature offset d*32 + 16*pr + 8*(lane>>5).  Half the store
