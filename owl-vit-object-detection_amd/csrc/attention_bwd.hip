@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void attn_dvec_kernel(AttnBwdP p) {
 }
 
 // ---- dK, dV ------------------------------------------------------------------------------------------
-static constexpr int BWD1_STAGE = 4 * 8192 + 512;   // Q, dO, Q^T, dO^T tiles + lse[64] + dvec[64]
+static constexpr int BWD1_STAGE = 2 * 8192 + 512;   // Q, dO tiles (row-major; the Q^T / dO^T fragments come out of them by LDS transpose-reads) + lse[64] + dvec[64]
 
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -120,27 +120,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdP p) {
 
     const bf16_t* qbase = p.qkv + (int64_t)b * p.Tp * p.ld_qkv + h * 64;
     const bf16_t* dobase = p.dO + (int64_t)b * p.Tp * p.ld_do + h * 64;
-    const bf16_t* qtbase = p.qkvT + ((int64_t)b * 3 * D + h * 64) * p.Tp;
-    const bf16_t* dotbase = p.dOT + ((int64_t)b * D + h * 64) * p.Tp;
     const float* lsebase = p.lse + ((int64_t)b * p.H + h) * p.Tp;
     const float* dvbase = p.dvec + ((int64_t)b * p.H + h) * p.Tp;
 
     // Staging.  Full tiles go through `buffer_load_dwordx4 ... offen lds`: the (image, head) bases sit in buffer
     // descriptors, the tile offset in an SGPR and the lane's row/chunk offsets in VGPRs computed once -- no address VALU
     // per tile (the global_load_lds form needs a 64-bit VGPR address per piece).  Only the partial last tile clamps rows.
-    unsigned row_voff[2][2], col_voff[2];                          // [qd]: {Q, dO} row-major pieces; Q^T / dO^T pieces
+    // Both tiles are row-major [64 query][64 d] in the transpose-friendly image (common.h): the dV / dK MFMAs' dO^T / Q^T operands
+    // are read out of them by ds_read_b64_tr_b16 -- no transposed copies in HBM, half the LDS-DMA pieces per tile.
+    unsigned row_voff[2][2];                                       // [qd]: {Q, dO} row-major pieces
 #pragma unroll
     for (int qd = 0; qd < 2; qd++) {
         const int r = (w * 2 + qd) * 8 + (lane >> 3);
-        const int ch = (lane & 7) ^ ((r >> 1) & 7);
+        const int ch = (lane & 7) ^ swz_vrow(r);
         row_voff[qd][0] = (unsigned)((r * p.ld_qkv + ch * 8) * 2);
         row_voff[qd][1] = (unsigned)((r * p.ld_do + ch * 8) * 2);
-        col_voff[qd] = (unsigned)((r * p.Tp + ch * 8) * 2);
     }
     const __amdgpu_buffer_rsrc_t q_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)qbase, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t do_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dobase, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t qt_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)qtbase, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t dot_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dotbase, 0, 0x7fffffff, 0x00020000);
     const int q_tile_bytes = (int)(64 * p.ld_qkv * 2), do_tile_bytes = (int)(64 * p.ld_do * 2);
     auto stage_full = [&](int buf, int qt) {
         unsigned char* base = lds + buf * BWD1_STAGE;
@@ -149,8 +146,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdP p) {
             const int r0 = (w * 2 + qd) * 8;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(q_rsrc, LPTR(base + r0 * 128), 16, (int)row_voff[qd][0], qt * q_tile_bytes, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(do_rsrc, LPTR(base + 8192 + r0 * 128), 16, (int)row_voff[qd][1], qt * do_tile_bytes, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(qt_rsrc, LPTR(base + 16384 + r0 * 128), 16, (int)col_voff[qd], qt * 128, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(dot_rsrc, LPTR(base + 24576 + r0 * 128), 16, (int)col_voff[qd], qt * 128, 0, 0);
         }
     };
     auto stage_clamped = [&](int buf, int qt) {                    // partial last tile: rows >= T re-read row T-1 (32-bit offsets only)
@@ -159,13 +154,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdP p) {
         for (int qd = 0; qd < 2; qd++) {
             const int r0 = (w * 2 + qd) * 8;
             const int r = r0 + (lane >> 3);
-            const int ch = (lane & 7) ^ ((r >> 1) & 7);
+            const int ch = (lane & 7) ^ swz_vrow(r);
             int q = qt * 64 + r;
             if (q >= p.T) q = p.T - 1;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(q_rsrc, LPTR(base + r0 * 128), 16, (q * (int)p.ld_qkv + ch * 8) * 2, 0, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(do_rsrc, LPTR(base + 8192 + r0 * 128), 16, (q * (int)p.ld_do + ch * 8) * 2, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(qt_rsrc, LPTR(base + 16384 + r0 * 128), 16, (int)col_voff[qd], qt * 128, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(dot_rsrc, LPTR(base + 24576 + r0 * 128), 16, (int)col_voff[qd], qt * 128, 0, 0);
         }
     };
     auto stage = [&](int buf, int qt) {                            // wave-uniform choice
@@ -182,9 +175,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdP p) {
     };
     auto store_scal = [&](int buf, float v) {
         // stored already negated and split into (hi, lo) bf16: the consumers use the word as contraction slots 0, 1 directly
-        if (threadIdx.x < 128) ((unsigned*)(lds + buf * BWD1_STAGE + 32768))[threadIdx.x] = split_hi_lo_bf16(-v);
+        if (threadIdx.x < 128) ((unsigned*)(lds + buf * BWD1_STAGE + 16384))[threadIdx.x] = split_hi_lo_bf16(-v);
     };
 
+    const unsigned lds0 = (unsigned)(uintptr_t)LPTR(lds);
+    unsigned tr_off[2][2];                                        // [d-block][half of the lane's 8 queries]
+#pragma unroll
+    for (int d = 0; d < 2; d++)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; h2++) tr_off[d][h2] = tr_lane_off(lane, d, h2);
     f32x16 dv[2], dk[2];
 #pragma unroll
     for (int d = 0; d < 2; d++)
@@ -201,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdP p) {
         float pend = 0.f;
         if (qt + 1 < nq) { stage(cur ^ 1, qt + 1); pend = load_scal(qt + 1); }
         const unsigned char* tb = lds + cur * BWD1_STAGE;
-        const unsigned* lse_t = (const unsigned*)(tb + 32768);   // packed (hi, lo) of -lse / -D per query of the tile
+        const unsigned* lse_t = (const unsigned*)(tb + 16384);   // packed (hi, lo) of -lse / -D per query of the tile
         const unsigned* dv_t = lse_t + 64;
         // a wave whose 32 keys all lie beyond T (T = 2305: three of the last block's four waves) only stages and syncs
 #pragma unroll
@@ -214,8 +213,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdP p) {
             f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_dv, ones01, zero16, 0, 0, 0);    // -D[query]
 #pragma unroll
             for (int kc = 0; kc < 4; kc++) {
-                const bf16x8 qa = *(const bf16x8*)(tb + tile_off(qrow, kc * 2 + hi));
-                const bf16x8 da = *(const bf16x8*)(tb + 8192 + tile_off(qrow, kc * 2 + hi));
+                const bf16x8 qa = *(const bf16x8*)(tb + tile_off_v(qrow, kc * 2 + hi));
+                const bf16x8 da = *(const bf16x8*)(tb + 8192 + tile_off_v(qrow, kc * 2 + hi));
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, ks[kc], s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[kc], dp, 0, 0, 0);
             }
@@ -231,12 +230,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdP p) {
                 const uint4 pw = make_uint4(pack_bf2(pv[0], pv[1]), pack_bf2(pv[2], pv[3]), pack_bf2(pv[4], pv[5]), pack_bf2(pv[6], pv[7]));
                 const uint4 dsw = make_uint4(pack_bf2(dsv[0], dsv[1]), pack_bf2(dsv[2], dsv[3]), pack_bf2(dsv[4], dsv[5]), pack_bf2(dsv[6], dsv[7]));
                 const bf16x8 pf = __builtin_bit_cast(bf16x8, pw), dsf = __builtin_bit_cast(bf16x8, dsw);
-                const int ch = sub * 4 + cc * 2 + hi;
+                const unsigned tq = lds0 + cur * BWD1_STAGE + (sub * 2 + cc) * 2048;      // 16 queries further = 2 KiB
 #pragma unroll
                 for (int d = 0; d < 2; d++) {
-                    const int drow = d * 32 + l31;
-                    const bf16x8 dot = *(const bf16x8*)(tb + 24576 + tile_off(drow, ch));
-                    const bf16x8 qt_ = *(const bf16x8*)(tb + 16384 + tile_off(drow, ch));
+                    const bf16x8 dot = lds_tr8(tq + 8192 + tr_off[d][0], tq + 8192 + tr_off[d][1]);   // dO^T[d*32 + lane&31][8 queries]
+                    const bf16x8 qt_ = lds_tr8(tq + tr_off[d][0], tq + tr_off[d][1]);                 // Q^T
                     dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot, pf, dv[d], 0, 0, 0);
                     dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt_, dsf, dk[d], 0, 0, 0);
                 }
