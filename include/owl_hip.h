@@ -77,9 +77,10 @@ int owl_attention_fwd_vrow_bf16(void* stream, const void* q, const void* k, cons
 
 /* tuning / race-hunting switches (bit 0: always rescale, bit 1: plain block mapping, bit 2: lgkmcnt(0) before barriers) */
 int owl_attention_debug(int flags);
-/* backward of the above for the trainable layer: qkv row-major [B*Tp,3D] (q|k|v), qkvT / dOT per-head
- * transposed copies ([B][3D][Tp] / [B][D][Tp], epilogue 6), O and dO row-major [B*Tp,D]; writes dqkv [B*Tp,3D]. */
-int owl_attention_bwd_bf16(void* stream, const void* qkv, const void* qkvT, const void* dO, const void* dOT, const void* O, const float* lse, float* dvec_ws, void* dqkv, int64_t B, int64_t H, int64_t T, int64_t Tp, float scale);
+/* backward of the fused attention (layers whose attention runs backward): qkv row-major [B*Tp,3D] (q|k|v), dO / O row-major
+ * [B*Tp,D], lse from the forward; writes dqkv [B*Tp,3D] (dq|dk|dv, bf16).  Every transposed operand of the dK/dV/dQ MFMAs is read
+ * out of the row-major tiles by the LDS hardware (ds_read_b64_tr_b16): no Q^T / K^T / dO^T copies exist.  dvec_ws: f32 [B,H,Tp]. */
+int owl_attention_bwd_bf16(void* stream, const void* qkv, const void* dO, const void* O, const float* lse, float* dvec_ws, void* dqkv, int64_t B, int64_t H, int64_t T, int64_t Tp, float scale);
 
 /* ---- post_layernorm on all tokens + class-token merge + post_post_layernorm (ref src/models.py:80-86);
  * optional fused final residual add (delta_bf16 -> x_out = x + delta, may alias x)                      */

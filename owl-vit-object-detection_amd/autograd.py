@@ -75,7 +75,7 @@ def _bws(model, B):
         slab=torch.zeros(_slab_elems(cfg), device=dev),
         dfeats=z(Mh, D, f32, dev), dcls=torch.zeros(B, D, device=dev),
         dx=z(M, D, f32, dev), dxb=z(M, D, bf, dev), du=z(M, I, bf, dev), dh=z(M, D, bf, dev), dxm=z(M, D, f32, dev),
-        datt=z(M, D, bf, dev), dattT=torch.zeros(B * D * Tp + 256, dtype=bf, device=dev), dqkv=z(M, 3 * D, bf, dev),
+        datt=z(M, D, bf, dev), dqkv=z(M, 3 * D, bf, dev),
         dvec=torch.zeros(B, H, Tp, device=dev),
         # transposed-operand scratch for the dW GEMMs; token-row and head-row users get their own buffers so
         # that the zero pad columns [rows, rows_pad) of each are never dirtied by the other row count
@@ -182,8 +182,7 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
         ops.layernorm_bwd(bw["dh"], Ls["x_mid"], Ls["st2"], P_[pre + "layer_norm2.weight"], bw["dx"], bw["dxm"], None, None, M, D,
                           dx_bf16=bw["dxb"])
         ops.gemm(ops.EPI_BIAS_BF16, bw["dxb"], fz[f"{i}.woT"], bw["datt"], M=M, N=D, K=D)
-        ops.transpose_tokens(bw["datt"], bw["dattT"], B, Tp, D)          # dO^T: token transpose of dO (same bits as a transposing GEMM)
-        ops.attention_bwd(Ls["qkv"], Ls["qkvT"], bw["datt"], bw["dattT"], Ls["att"], Ls["lse"], bw["dvec"], bw["dqkv"], B, H, T, Tp, scale)
+        ops.attention_bwd(Ls["qkv"], bw["datt"], Ls["att"], Ls["lse"], bw["dvec"], bw["dqkv"], B, H, T, Tp, scale)
         ops.gemm(ops.EPI_BIAS_BF16, bw["dqkv"], fz[f"{i}.wqkvT"], bw["dh"], M=M, N=D, K=3 * D)
         ops.layernorm_bwd(bw["dh"], Ls["x_in"], Ls["st1"], P_[pre + "layer_norm1.weight"], bw["dxm"], bw["dx"], None, None, M, D,
                           dx_bf16=bw["dxb"])
@@ -204,8 +203,7 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
     dW(bw["dxb"], Lt["att"], G(tl + "self_attn.out_proj.weight"), D, D, M, Mp)
     woT = wT(tl + "self_attn.out_proj.weight", D, D)
     ops.gemm(ops.EPI_BIAS_BF16, bw["dxb"], woT, bw["datt"], M=M, N=D, K=D)
-    ops.transpose_tokens(bw["datt"], bw["dattT"], B, Tp, D)              # dO^T: token transpose of dO (same bits as a transposing GEMM)
-    ops.attention_bwd(Lt["qkv"], Lt["qkvT"], bw["datt"], bw["dattT"], Lt["att"], Lt["lse"], bw["dvec"], bw["dqkv"], B, H, T, Tp,
+    ops.attention_bwd(Lt["qkv"], bw["datt"], Lt["att"], Lt["lse"], bw["dvec"], bw["dqkv"], B, H, T, Tp,
                       cfg.head_dim ** -0.5)
     o = model.flat_offsets[tl + "self_attn.q_proj.weight"]
     g_wqkv = model.flat_grad[o: o + 3 * D * D].view(3 * D, D)

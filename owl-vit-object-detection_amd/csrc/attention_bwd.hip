@@ -18,9 +18,7 @@
 
 struct AttnBwdP {
     const bf16_t* qkv; int64_t ld_qkv;       // row-major [B*Tp, 3D]: q | k | v
-    const bf16_t* qkvT;                      // [B][3D][Tp]
     const bf16_t* dO; int64_t ld_do;         // row-major [B*Tp, D]
-    const bf16_t* dOT;                       // [B][D][Tp]
     const bf16_t* O;                         // row-major [B*Tp, D]
     const float* lse; float* dvec;           // [B][H][Tp]
     bf16_t* dqkv;                            // row-major [B*Tp, 3D]
@@ -84,7 +82,7 @@ __global__ __launch_bounds__(256) void attn_dvec_kernel(AttnBwdP p) {
 // ---- dK, dV ------------------------------------------------------------------------------------------
 static constexpr int BWD1_STAGE = 2 * 8192 + 512;   // Q, dO tiles (row-major; the Q^T / dO^T fragments come out of them by LDS transpose-reads) + lse[64] + dvec[64]
 
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdP p) {
+__global__ __launch_bounds__(256, 3) void attn_bwd_dkdv_kernel(AttnBwdP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -424,15 +422,15 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnBwdP p) {
     }
 }
 
-extern "C" int owl_attention_bwd_bf16(void* stream, const void* qkv, const void* qkvT, const void* dO, const void* dOT, const void* O,
+extern "C" int owl_attention_bwd_bf16(void* stream, const void* qkv, const void* dO, const void* O,
                                       const float* lse, float* dvec_ws, void* dqkv, int64_t B, int64_t H, int64_t T, int64_t Tp,
                                       float scale) {
-    OWL_CHECK_ARG(qkv && qkvT && dO && dOT && O && lse && dvec_ws && dqkv, "owl_attention_bwd_bf16: null pointer");
+    OWL_CHECK_ARG(qkv && dO && O && lse && dvec_ws && dqkv, "owl_attention_bwd_bf16: null pointer");
     OWL_CHECK_ARG(Tp % 8 == 0 && T > 0 && T <= Tp, "owl_attention_bwd_bf16: Tp %% 8, T <= Tp");
     AttnBwdP p{};
     p.D = (int)(H * 64);
-    p.qkv = (const bf16_t*)qkv; p.ld_qkv = 3 * (int64_t)p.D; p.qkvT = (const bf16_t*)qkvT;
-    p.dO = (const bf16_t*)dO; p.ld_do = p.D; p.dOT = (const bf16_t*)dOT; p.O = (const bf16_t*)O;
+    p.qkv = (const bf16_t*)qkv; p.ld_qkv = 3 * (int64_t)p.D;
+    p.dO = (const bf16_t*)dO; p.ld_do = p.D; p.O = (const bf16_t*)O;
     p.lse = lse; p.dvec = dvec_ws; p.dqkv = (bf16_t*)dqkv;
     p.B = (int)B; p.T = (int)T; p.Tp = (int)Tp; p.H = (int)H;
     p.scale = scale; p.scale_log2e = scale * 1.4426950408889634f;

@@ -209,7 +209,7 @@ class OwlViT(nn.Module):
         bf, f32 = torch.bfloat16, torch.float32
         z = ops.zeros_rows
         L = dict(x_in=z(M, D, f32, dev), x_mid=z(M, D, f32, dev), st1=torch.zeros(M, 2, device=dev), st2=torch.zeros(M, 2, device=dev),
-                 qkv=z(M, 3 * D, bf, dev), qkvT=torch.zeros(B * 3 * D * Tp + 256, dtype=bf, device=dev), att=z(M, D, bf, dev),
+                 qkv=z(M, 3 * D, bf, dev), att=z(M, D, bf, dev),
                  lse=torch.zeros(B, cfg.heads, Tp, device=dev), u=z(M, I, bf, dev))
         if i == cfg.trainable_layer():   # dW operands
             L.update(h1=z(M, D, bf, dev), h2=z(M, D, bf, dev), g=z(M, I, bf, dev))
@@ -272,13 +272,11 @@ class OwlViT(nn.Module):
                 else:       # (xs + delta1) + delta2, same operands and order as the two separate adds
                     ops.layernorm(xs, lw["g1"], lw["be1"], h, M, D, Ls["st1"] if sv else None, cfg.ln_eps, delta=pending1, delta2=pending,
                                   x_out=x_cur)
-            # ONE row-major QKV GEMM per layer; the fused attention reads V where that GEMM leaves it (LDS transpose-reads), so no
-            # layer needs a V^T copy.  Layers whose attention runs backward also keep per-head Q^T / K^T (an HBM-bound token
-            # transpose of the row-major result: same bits as a second GEMM with the transposing epilogue, a third of its time).
+            # ONE row-major QKV GEMM per layer.  The attention kernels (forward and backward) read every transposed MFMA operand
+            # (V^T; Q^T, K^T, dO^T) out of the row-major tiles with the LDS hardware transpose (ds_read_b64_tr_b16): no transposed
+            # copy of anything exists in HBM.
             qkv_l = Ls["qkv"] if sv else qkv
             ops.gemm(ops.EPI_BIAS_BF16, h, lw["wqkv"], qkv_l, bias=lw["bqkv"], M=M, N=3 * D, K=D, ldo=3 * D)
-            if sv:
-                ops.transpose_tokens(qkv_l, Ls["qkvT"], B, Tp, 2 * D, out_cols=3 * D)
             att_l = Ls["att"] if sv else att
             ops.attention_fwd_vrow(qkv_l, qkv_l[:, D:], qkv_l[:, 2 * D:], 3 * D, att_l, D, Ls["lse"] if sv else None, B, H, T, Tp, scale)
             ops.gemm(ops.EPI_BIAS_BF16, att_l, lw["wo"], d1, bias=lw["bo"], M=M, N=D, K=D)

@@ -163,8 +163,8 @@ def colsum_f32(src, colsum, R, C):
     _lib.call("owl_colsum_f32", stream(), src, colsum, R, C)
 
 
-def attention_bwd(qkv, qkvT, dO, dOT, O, lse, dvec, dqkv, B, H, T, Tp, scale):
-    _lib.call("owl_attention_bwd_bf16", stream(), qkv, qkvT, dO, dOT, O, lse, dvec, dqkv, B, H, T, Tp, float(scale))
+def attention_bwd(qkv, dO, O, lse, dvec, dqkv, B, H, T, Tp, scale):
+    _lib.call("owl_attention_bwd_bf16", stream(), qkv, dO, O, lse, dvec, dqkv, B, H, T, Tp, float(scale))
 
 
 _pp_ws = {}

@@ -101,7 +101,7 @@ def test_attention_bwd_bitwise_repeatable():
     def run():
         dqkv = torch.zeros(ops.pad_rows(M), 3 * D, device=DEV, dtype=torch.bfloat16)
         dvec = torch.zeros(B, H, Tp, device=DEV)
-        ops.attention_bwd(qkv, qkvT, dO, dOT, O, lse, dvec, dqkv, B, H, T, Tp, 0.125)
+        ops.attention_bwd(qkv, dO, O, lse, dvec, dqkv, B, H, T, Tp, 0.125)
         torch.cuda.synchronize()
         return dqkv
 

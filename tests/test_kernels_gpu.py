@@ -377,3 +377,30 @@ def test_attention_fwd_vrow_matches_vt_variant_bitwise(B, H, T):
     ops.attention_fwd_vrow(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, o2, D, l2, B, H, T, Tp, 0.125)
     assert torch.equal(o1, o2) and torch.equal(l1, l2)
     assert bool(torch.isfinite(o2.float()).all())
+
+
+@pytest.mark.parametrize("B,H,T", [(2, 3, 333), (1, 2, 37), (1, 12, 577)])
+def test_attention_bwd_matches_torch_autograd(B, H, T):
+    """dQ / dK / dV of the fused backward (every transposed operand read by the LDS transpose hardware) against f32 autograd of
+    softmax(QK^T/8)V on the same bf16 inputs; bf16 outputs -> 2e-2 of the largest gradient."""
+    torch.manual_seed(B + T)
+    Tp = (T + 7) // 8 * 8; D = H * 64; M = B * Tp
+    qkv = torch.zeros(ops.pad_rows(M), 3 * D, device=DEV, dtype=torch.bfloat16)
+    qkv[:M] = torch.randn(M, 3 * D, device=DEV).bfloat16()
+    o = torch.zeros(ops.pad_rows(M), D, device=DEV, dtype=torch.bfloat16); lse = torch.zeros(B, H, Tp, device=DEV)
+    ops.attention_fwd_vrow(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, o, D, lse, B, H, T, Tp, 0.125)
+    do = torch.zeros_like(o)
+    do[:M].view(B, Tp, D)[:, :T] = (torch.randn(B, T, D, device=DEV) * 0.1).bfloat16()
+    dvec = torch.zeros(B, H, Tp, device=DEV); dqkv = torch.zeros_like(qkv)
+    ops.attention_bwd(qkv, do, o, lse, dvec, dqkv, B, H, T, Tp, 0.125)
+    x = qkv[:M].view(B, Tp, 3, H, 64)[:, :T].float()
+    q = x[:, :, 0].permute(0, 2, 1, 3).clone().requires_grad_(True)
+    k = x[:, :, 1].permute(0, 2, 1, 3).clone().requires_grad_(True)
+    v = x[:, :, 2].permute(0, 2, 1, 3).clone().requires_grad_(True)
+    ref = torch.softmax((q @ k.transpose(2, 3)) * 0.125, -1) @ v
+    ref.backward(do[:M].view(B, Tp, H, 64)[:, :T].permute(0, 2, 1, 3).float())
+    got = dqkv[:M].view(B, Tp, 3, H, 64)[:, :T].float()
+    for i, g in enumerate((q.grad, k.grad, v.grad)):
+        d = (got[:, :, i].permute(0, 2, 1, 3) - g).abs().max().item()
+        assert d < 2e-2 * max(g.abs().max().item(), 1e-3), (i, d, g.abs().max().item())
+    assert float(dqkv[:M].view(B, Tp, 3 * D)[:, T:].abs().max()) == 0.0 if Tp > T else True      # pad tokens get no gradient
