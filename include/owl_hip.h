@@ -172,11 +172,6 @@ int owl_adamw_step(void* stream, float* p, const float* g, float* m, float* v, v
 /* ---- utilities ------------------------------------------------------------------------------------ */
 int owl_cast_f32_bf16(void* stream, const float* in, void* out, int64_t n);
 int owl_transpose_bf16(void* stream, const void* in, int64_t ld_in, void* out, int64_t ld_out, int64_t R, int64_t C);
-/* out[b][c][t] = in[b*Tp + t][c], c < ncols (per-image token transpose of row-major activations into the per-head
- * transposed layout of epilogue 6; replaces the second, transposing QKV GEMM of the layers whose attention runs backward:
- * HF5:428-459 saved-for-backward operands).  Tp % 8 == 0, ncols % 64 == 0, ld_in % 8 == 0; `out` holds out_cols (>= ncols,
- * 0 = ncols) rows per image, of which the first ncols are written. */
-int owl_transpose_tokens_bf16(void* stream, const void* in, int64_t ld_in, void* out, int64_t B, int64_t Tp, int64_t ncols, int64_t out_cols);
 
 #ifdef __cplusplus
 }

@@ -44,58 +44,6 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
     }
 }
 
-// Per-image token transpose: out[b][c][t] = in[b*Tp + t][c] for c < ncols (the attention-backward operands Q^T / K^T / V^T
-// from the row-major QKV the forward GEMM has just written: HBM-bound, 4 B per element, instead of a second GEMM with a
-// transposing epilogue -- same bits, since both round the same f32 accumulator + bias once).  64 x 64 tiles; 16-byte global
-// loads (8 columns of a token) are scattered into a [c][t] LDS image with a 66-element pitch, read back as dwords and stored
-// as 16 bytes = 8 tokens of one column, 8 lanes per 128-byte output row segment.
-template <int TT, int TC>      // tile: TT tokens x TC columns
-__global__ __launch_bounds__(256) void transpose_tokens_kernel(const bf16_t* __restrict__ in, int64_t ld_in, bf16_t* __restrict__ out,
-                                                               int Tp, int ncols) {   // ncols here = rows per image of `out`
-    __shared__ bf16_t tile[TC][TT + 2];
-    const int b = blockIdx.z, t0 = blockIdx.y * TT, c0 = blockIdx.x * TC;
-    const int i = threadIdx.x;
-    constexpr int CPR = TC / 8;                      // 16-byte chunks per token row of the tile
-    constexpr int RPI = 256 / CPR;                   // token rows per iteration
-#pragma unroll
-    for (int it = 0; it < TT / RPI; it++) {
-        const int t = it * RPI + i / CPR, ch = i % CPR;
-        us8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (t0 + t < Tp) v = *(const us8*)(in + ((int64_t)b * Tp + t0 + t) * ld_in + c0 + ch * 8);
-#pragma unroll
-        for (int e = 0; e < 8; e++) tile[ch * 8 + e][t] = v[e];
-    }
-    __syncthreads();
-    constexpr int TPR = TT / 8;                      // 16-byte chunks per output row of the tile
-    constexpr int CPI = 256 / TPR;                   // output rows per iteration
-#pragma unroll
-    for (int it = 0; it < TC / CPI; it++) {
-        const int c = it * CPI + i / TPR, tch = i % TPR;
-        if (t0 + tch * 8 < Tp) {                     // Tp % 8 == 0: a chunk is entirely inside or outside
-            const unsigned* src = (const unsigned*)&tile[c][tch * 8];
-            const uint4 o = make_uint4(src[0], src[1], src[2], src[3]);
-            *(uint4*)(out + ((int64_t)b * ncols + c0 + c) * Tp + t0 + tch * 8) = o;
-        }
-    }
-}
-
-extern "C" int owl_transpose_tokens_bf16(void* stream, const void* in, int64_t ld_in, void* out, int64_t B, int64_t Tp, int64_t ncols,
-                                         int64_t out_cols) {
-    OWL_CHECK_ARG(in && out && B > 0 && Tp > 0 && ncols > 0, "owl_transpose_tokens_bf16: bad args");
-    OWL_CHECK_ARG(Tp % 8 == 0 && ncols % 64 == 0 && ld_in % 8 == 0, "owl_transpose_tokens_bf16: Tp %% 8, ncols %% 64, ld_in %% 8");
-    if (out_cols <= 0) out_cols = ncols;
-    OWL_CHECK_ARG(out_cols >= ncols, "owl_transpose_tokens_bf16: out_cols < ncols");
-    if (ncols % 128 == 0 && Tp >= 512) {             // 256-byte segments on both sides
-        dim3 grid((unsigned)(ncols / 128), (unsigned)((Tp + 127) / 128), (unsigned)B);
-        hipLaunchKernelGGL((transpose_tokens_kernel<128, 128>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, ld_in, (bf16_t*)out, (int)Tp, (int)out_cols);
-    } else {
-        dim3 grid((unsigned)(ncols / 64), (unsigned)((Tp + 63) / 64), (unsigned)B);
-        hipLaunchKernelGGL((transpose_tokens_kernel<64, 64>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, ld_in, (bf16_t*)out, (int)Tp, (int)out_cols);
-    }
-    OWL_LAUNCH_CHECK();
-    return 0;
-}
-
 extern "C" int owl_transpose_bf16(void* stream, const void* in, int64_t ld_in, void* out, int64_t ld_out, int64_t R, int64_t C) {
     OWL_CHECK_ARG(in && out && R > 0 && C > 0, "owl_transpose_bf16: bad args");
     dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64));

@@ -126,14 +126,6 @@ def transpose_bf16(src, dst, R, C, ld_in=None, ld_out=None):
     return dst
 
 
-def transpose_tokens(src, dst, B, Tp, ncols, ld_in=None, out_cols=0):
-    """dst[b][c][t] = src[b*Tp + t][c], c < ncols: the per-head transposed layout of EPI_TRANS from row-major activations
-    (`out_cols` >= ncols rows per image in dst, default ncols)."""
-    _chk(src, torch.bfloat16, "src"); _chk(dst, torch.bfloat16, "dst")
-    _lib.call("owl_transpose_tokens_bf16", stream(), src, ld_in if ld_in is not None else src.shape[-1], dst, B, Tp, ncols, out_cols)
-    return dst
-
-
 # ---- backward-side wrappers ---------------------------------------------------------------------------
 def layernorm_bwd(dy, x, stats, gamma, dres, dx, dgamma, dbeta, rows, D, dx_bf16=None):
     """dx (f32) = LN backward (+ dres); optionally also its bf16 copy `dx_bf16` (the operand of the next dX GEMM)."""

@@ -324,19 +324,6 @@ def test_colsum_f32(R, C):
     assert (out.double() - ref).abs().max().item() <= 1e-4 * R ** 0.5 + 1e-4
 
 
-@pytest.mark.parametrize("B,T,ncols,ld", [(3, 577, 192, 192), (2, 2305, 2304, 2304), (1, 37, 64, 192)])
-def test_transpose_tokens_matches_torch(B, T, ncols, ld):
-    """out[b][c][t] = in[b*Tp + t][c] -- the per-head transposed layout of the transposing GEMM epilogue, bit for bit."""
-    Tp = (T + 7) // 8 * 8
-    torch.manual_seed(11)
-    src = torch.randn(ops.pad_rows(B * Tp), ld, device=DEV).bfloat16()
-    dst = torch.zeros(B * ncols * Tp + 64, device=DEV, dtype=torch.bfloat16)
-    ops.transpose_tokens(src, dst, B, Tp, ncols, ld_in=ld)
-    ref = src[: B * Tp].view(B, Tp, ld)[:, :, :ncols].transpose(1, 2).contiguous()
-    assert torch.equal(dst[: B * ncols * Tp].view(B, ncols, Tp), ref)
-    assert float(dst[B * ncols * Tp:].abs().max()) == 0.0          # nothing written past the end
-
-
 def test_add2_layernorm_matches_two_separate_adds():
     """(x + d1) + d2 formed inside the LayerNorm equals storing x + d1 first and adding d2 in the next call, bit for bit;
     store_x=False leaves x untouched."""
