@@ -98,11 +98,13 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
             const int ch = (lane & 7) ^ ((r >> 1) & 7);
             int key = kv * 64 + r;
             if (key >= p.T) key = p.T - 1;
-            __builtin_amdgcn_global_load_lds(GPTR(kbase + (int64_t)key * p.ld_qk + ch * 8), LPTR(base + r0 * 128), 16, 0, 0);
+            // (32-bit buffer offsets: 64-bit per-lane pointers here get hoisted out of the tile loop and spilled across it)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, LPTR(base + r0 * 128), 16, (key * (int)p.ld_qk + ch * 8) * 2, 0, 0, 0);
             if constexpr (VROW)          // same clamp as K: a row past T would be multiplied by P = 0, but must be finite
-                __builtin_amdgcn_global_load_lds(GPTR(vbase + (int64_t)key * p.ld_qk + ((lane & 7) ^ swz_vrow(r)) * 8), LPTR(base + 8192 + r0 * 128), 16, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, LPTR(base + 8192 + r0 * 128), 16,
+                                                         (key * (int)p.ld_qk + ((lane & 7) ^ swz_vrow(r)) * 8) * 2, 0, 0, 0);
             else                         // reads past T are finite junk, masked by P = 0
-                __builtin_amdgcn_global_load_lds(GPTR(vbase + (int64_t)r * p.Tp + kv * 64 + ch * 8), LPTR(base + 8192 + r0 * 128), 16, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, LPTR(base + 8192 + r0 * 128), 16, (r * p.Tp + ch * 8) * 2, kv * 128, 0, 0);
         }
     };
 
@@ -335,16 +337,21 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
     // ---- epilogue: normalise, write O (row-major, head h) and LSE ---------------------------------
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
-    const int qr = q0 + (lane & 31);
+    // The epilogue's addresses are formed HERE, from scalars made opaque after the loop: left to itself the compiler computes the
+    // per-lane output pointers in the prologue and, at 168 registers, spills them across the whole loop -- 4 VGPRs x 29 184 waves =
+    // 30 MB of scratch written and read back per launch (PMC: WRITE_SIZE 143 MB for 114 MB of output).
+    int q0e = q0, be = b, he = h;
+    asm volatile("" : "+s"(q0e), "+s"(be), "+s"(he));
+    const int qr = q0e + (lane & 31);
     uint4 st[2][2];
     pack_token_rows(o, inv, st);                    // 16-byte stores (common.h)
     if (qr < p.T) {
-        bf16_t* op = p.out + ((int64_t)b * p.Tp + qr) * p.ld_out + h * 64;
+        bf16_t* op = p.out + ((int64_t)be * p.Tp + qr) * p.ld_out + he * 64;
 #pragma unroll
         for (int d = 0; d < 2; d++)
 #pragma unroll
             for (int pr = 0; pr < 2; pr++) *(uint4*)(op + d * 32 + 16 * pr + 8 * hi) = st[d][pr];
-        if (p.lse && hi == 0) p.lse[((int64_t)b * p.H + h) * p.Tp + qr] = M + __builtin_amdgcn_logf(l_tot);
+        if (p.lse && hi == 0) p.lse[((int64_t)be * p.H + he) * p.Tp + qr] = M + __builtin_amdgcn_logf(l_tot);
     }
 }
 
