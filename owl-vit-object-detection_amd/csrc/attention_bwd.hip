@@ -246,8 +246,12 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkdv_kernel(AttnBwdP p) {
     uint4 stk[2][2], stv[2][2];
     pack_token_rows(dk, p.scale, stk);              // 16-byte stores (common.h)
     pack_token_rows(dv, 1.0f, stv);
-    if (key_ok) {
-        bf16_t* orow = p.dqkv + ((int64_t)b * p.Tp + key) * p.ld_qkv + h * 64;
+    // (output addresses formed after the loop from opaque scalars: computed in the prologue they are spilled across the whole loop)
+    int k0e = k0, be = b, he = h;
+    asm volatile("" : "+s"(k0e), "+s"(be), "+s"(he));
+    const int key_e = k0e + l31;
+    if (key_e < p.T) {
+        bf16_t* orow = p.dqkv + ((int64_t)be * p.Tp + key_e) * p.ld_qkv + he * 64;
 #pragma unroll
         for (int d = 0; d < 2; d++)
 #pragma unroll
@@ -413,8 +417,11 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnBwdP p) {
     if (nfull < nkv) tile(cur, nfull, std::true_type{});
     uint4 stq[2][2];
     pack_token_rows(dq, p.scale, stq);              // 16-byte stores (common.h)
-    if (q_ok) {
-        bf16_t* orow = p.dqkv + ((int64_t)b * p.Tp + q) * p.ld_qkv + h * 64;
+    int q0e = q0, be = b, he = h;                   // (see the dK/dV epilogue)
+    asm volatile("" : "+s"(q0e), "+s"(be), "+s"(he));
+    const int q_e = q0e + l31;
+    if (q_e < p.T) {
+        bf16_t* orow = p.dqkv + ((int64_t)be * p.Tp + q_e) * p.ld_qkv + he * 64;
 #pragma unroll
         for (int d = 0; d < 2; d++)
 #pragma unroll
