@@ -126,13 +126,14 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkdv_kernel(AttnBwdP p) {
     // per tile (the global_load_lds form needs a 64-bit VGPR address per piece).  Only the partial last tile clamps rows.
     // Both tiles are row-major [64 query][64 d] in the transpose-friendly image (common.h): the dV / dK MFMAs' dO^T / Q^T operands
     // are read out of them by ds_read_b64_tr_b16 -- no transposed copies in HBM, half the LDS-DMA pieces per tile.
-    unsigned row_voff[2][2];                                       // [qd]: {Q, dO} row-major pieces
-#pragma unroll
-    for (int qd = 0; qd < 2; qd++) {
-        const int r = (w * 2 + qd) * 8 + (lane >> 3);
+    // A wave's two pieces of a tile are rows w*8 + (lane>>3) and 32 further: the swizzle has period 16 rows, so both share ONE
+    // lane offset per operand and the 32-row step rides in the scalar offset (two live VGPRs instead of four across the loop).
+    unsigned row_voff[2];                                          // {Q, dO}
+    {
+        const int r = w * 8 + (lane >> 3);
         const int ch = (lane & 7) ^ swz_vrow(r);
-        row_voff[qd][0] = (unsigned)((r * p.ld_qkv + ch * 8) * 2);
-        row_voff[qd][1] = (unsigned)((r * p.ld_do + ch * 8) * 2);
+        row_voff[0] = (unsigned)((r * p.ld_qkv + ch * 8) * 2);
+        row_voff[1] = (unsigned)((r * p.ld_do + ch * 8) * 2);
     }
     const __amdgpu_buffer_rsrc_t q_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)qbase, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t do_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dobase, 0, 0x7fffffff, 0x00020000);
@@ -141,16 +142,16 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkdv_kernel(AttnBwdP p) {
         unsigned char* base = lds + buf * BWD1_STAGE;
 #pragma unroll
         for (int qd = 0; qd < 2; qd++) {
-            const int r0 = (w * 2 + qd) * 8;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(q_rsrc, LPTR(base + r0 * 128), 16, (int)row_voff[qd][0], qt * q_tile_bytes, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(do_rsrc, LPTR(base + 8192 + r0 * 128), 16, (int)row_voff[qd][1], qt * do_tile_bytes, 0, 0);
+            const int r0 = w * 8 + qd * 32;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(q_rsrc, LPTR(base + r0 * 128), 16, (int)row_voff[0], qt * q_tile_bytes + qd * (q_tile_bytes >> 1), 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(do_rsrc, LPTR(base + 8192 + r0 * 128), 16, (int)row_voff[1], qt * do_tile_bytes + qd * (do_tile_bytes >> 1), 0, 0);
         }
     };
     auto stage_clamped = [&](int buf, int qt) {                    // partial last tile: rows >= T re-read row T-1 (32-bit offsets only)
         unsigned char* base = lds + buf * BWD1_STAGE;
 #pragma unroll
         for (int qd = 0; qd < 2; qd++) {
-            const int r0 = (w * 2 + qd) * 8;
+            const int r0 = w * 8 + qd * 32;
             const int r = r0 + (lane >> 3);
             const int ch = (lane & 7) ^ swz_vrow(r);
             int q = qt * 64 + r;
@@ -305,12 +306,11 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnBwdP p) {
     // staging: buffer loads with scalar tile offsets for full tiles, clamped rows for the last one.  Both tiles are row-major
     // [64 key][64 d] with the transpose-friendly chunk swizzle (common.h): the dQ MFMA's K^T operand is read out of the K tile by
     // ds_read_b64_tr_b16 -- no K^T copy in HBM, a third less LDS-DMA per tile.
-    unsigned row_voff[2];
-#pragma unroll
-    for (int qd = 0; qd < 2; qd++) {
-        const int r = (w * 2 + qd) * 8 + (lane >> 3);
+    unsigned row_voff;                                             // one lane offset for both pieces and both tiles (see the dK/dV kernel)
+    {
+        const int r = w * 8 + (lane >> 3);
         const int ch = (lane & 7) ^ swz_vrow(r);
-        row_voff[qd] = (unsigned)((r * p.ld_qkv + ch * 8) * 2);
+        row_voff = (unsigned)((r * p.ld_qkv + ch * 8) * 2);
     }
     const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(kbase + D), 0, 0x7fffffff, 0x00020000);
@@ -319,16 +319,16 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnBwdP p) {
         unsigned char* base = lds + buf * BWD2_STAGE;
 #pragma unroll
         for (int qd = 0; qd < 2; qd++) {
-            const int r0 = (w * 2 + qd) * 8;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, LPTR(base + r0 * 128), 16, (int)row_voff[qd], kv * k_tile_bytes, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, LPTR(base + 8192 + r0 * 128), 16, (int)row_voff[qd], kv * k_tile_bytes, 0, 0);
+            const int r0 = w * 8 + qd * 32;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, LPTR(base + r0 * 128), 16, (int)row_voff, kv * k_tile_bytes + qd * (k_tile_bytes >> 1), 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, LPTR(base + 8192 + r0 * 128), 16, (int)row_voff, kv * k_tile_bytes + qd * (k_tile_bytes >> 1), 0, 0);
         }
     };
     auto stage_clamped = [&](int buf, int kv) {
         unsigned char* base = lds + buf * BWD2_STAGE;
 #pragma unroll
         for (int qd = 0; qd < 2; qd++) {
-            const int r0 = (w * 2 + qd) * 8;
+            const int r0 = w * 8 + qd * 32;
             const int r = r0 + (lane >> 3);
             const int ch = (lane & 7) ^ swz_vrow(r);
             int key = kv * 64 + r;
