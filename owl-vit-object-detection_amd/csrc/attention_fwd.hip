@@ -65,14 +65,15 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
     // Per-lane byte offsets of this lane's two DMA rows inside a 64-key tile (K) / inside the head's V^T block; the
     // tile's own offset is wave-uniform and is added on the scalar unit, so staging costs no VALU work per tile
     // (the kernel is VALU-bound; the per-tile 64-bit address products were ~10 % of its VALU time).
-    unsigned k_voff[2], v_voff[2];
-#pragma unroll
-    for (int qd = 0; qd < 2; qd++) {
-        const int r = (w * 2 + qd) * 8 + (lane >> 3);
+    // A wave's two pieces of a tile are rows w*8 + (lane>>3) and 32 further: both swizzles have period 16 rows, so the pieces share
+    // ONE lane offset per operand and the 32-row step rides in the scalar offset.
+    unsigned k_voff, v_voff;
+    {
+        const int r = w * 8 + (lane >> 3);
         const int ch = (lane & 7) ^ ((r >> 1) & 7);
-        k_voff[qd] = (unsigned)((r * p.ld_qk + ch * 8) * 2);
-        if constexpr (VROW) v_voff[qd] = (unsigned)((r * p.ld_qk + ((lane & 7) ^ swz_vrow(r)) * 8) * 2);    // V row r = key
-        else v_voff[qd] = (unsigned)((r * p.Tp + ch * 8) * 2);     // V^T row r = d; 8 keys per chunk
+        k_voff = (unsigned)((r * p.ld_qk + ch * 8) * 2);
+        if constexpr (VROW) v_voff = (unsigned)((r * p.ld_qk + ((lane & 7) ^ swz_vrow(r)) * 8) * 2);    // V row r = key
+        else v_voff = (unsigned)((r * p.Tp + ch * 8) * 2);         // V^T row r = d; 8 keys per chunk
     }
     // Full tiles go through `buffer_load_dwordx4 ... offen lds`: the (image, head) base sits in a buffer descriptor, the
     // tile offset in an SGPR and the lane's row/chunk offset in one VGPR computed once -- no VALU work per tile (the
@@ -84,16 +85,17 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
         unsigned char* base = lds + buf * 16384;
 #pragma unroll
         for (int qd = 0; qd < 2; qd++) {
-            const int r0 = (w * 2 + qd) * 8;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, LPTR(base + r0 * 128), 16, (int)k_voff[qd], kv * k_tile_bytes, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, LPTR(base + 8192 + r0 * 128), 16, (int)v_voff[qd], VROW ? kv * k_tile_bytes : kv * 128, 0, 0);
+            const int r0 = w * 8 + qd * 32;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, LPTR(base + r0 * 128), 16, (int)k_voff, kv * k_tile_bytes + qd * (k_tile_bytes >> 1), 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, LPTR(base + 8192 + r0 * 128), 16, (int)v_voff,
+                                                     VROW ? kv * k_tile_bytes + qd * (k_tile_bytes >> 1) : kv * 128 + qd * 32 * p.Tp * 2, 0, 0);
         }
     };
     auto stage_clamped = [&](int buf, int kv) {                    // the partial last tile: key rows >= T re-read row T-1
         unsigned char* base = lds + buf * 16384;
 #pragma unroll
         for (int qd = 0; qd < 2; qd++) {
-            const int r0 = (w * 2 + qd) * 8;
+            const int r0 = w * 8 + qd * 32;
             const int r = r0 + (lane >> 3);
             const int ch = (lane & 7) ^ ((r >> 1) & 7);
             int key = kv * 64 + r;
