@@ -193,7 +193,7 @@ def main():
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                          # HBM bytes per launch from PMC (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_attn_fwd.md): measured for
                          # the default workload only (algorithmic = 4*M*D*2 B = 454 MB; r01_pmc_final.md)
-                         "traffic": 476.0e6 if (cfg.name == "owlvit-base-patch16" and B == 32) else None,
+                         "traffic": 462.0e6 if (cfg.name == "owlvit-base-patch16" and B == 32) else None,
                          "launches_timed": len(attn_events), "ms_per_launch": round(attn_ms, 4)},
         }
         if world == 1 and not args.no_cpu_baseline:
