@@ -10,6 +10,9 @@
  * Conventions:
  *   - every function enqueues on the hipStream_t passed as `stream` and returns immediately;
  *     0 = OK, <0 = error (message via owl_last_error(), thread-local);
+ *   - re-entrant: the library keeps NO process-global mutable state (kernel choices are per-call arguments; the tuning
+ *     switches of tools/ exist only in an OWL_TUNING build, include/owl_hip_tuning.h);
+ *   - ops that need device scratch take it from the caller (`*_workspace_bytes` / `*_workspace` queries size it);
  *   - the library never allocates or frees device memory; all pointers are device pointers to
  *     contiguous row-major buffers owned by the caller; outputs are pre-allocated;
  *   - bf16 buffers are passed as `void*` (raw 16-bit words), f32 as `float*`;
@@ -38,17 +41,14 @@ int owl_abi_version(void);
  *      3 resid+acc+bias->f32 | 4 alpha*acc(+bias)->f32 | 5 atomicAdd f32 (split-K) |
  *      6 per-head transposed bf16 out_t[b][n][t] (m = b*Tp + t) | 8 acc*quick_gelu'(aux)->bf16 |
  *      9 acc*gelu'(aux)->bf16 | 10 out f32 += acc | 11 split-K slab.
- * a_rows / w_rows clamp the tile loads; M, N guard the stores; K % 64 == 0.                      */
-int owl_gemm_nt_bf16(void* stream, int epi, const void* A, int64_t lda, int64_t a_rows, const void* W, int64_t ldw, int64_t w_rows, const float* bias, void* out, int64_t ldo, const float* resid, void* aux, int64_t ld_aux, int64_t M, int64_t N, int64_t K, float alpha, int splits, int64_t Tp);
-
-/* tile override for tests / tuning: 0 auto (256x256x64 8-wave tiles for large shapes, 128x128x64 otherwise), 128, 256 */
-int owl_gemm_set_tile(int tile);
-/* persistent scheduling (one workgroup per CU walks tiles with cross-tile prefetch): 1 on (default), 0 off */
-int owl_gemm_set_persistent(int on);
-int owl_gemm_debug_nostore(int on);
-int owl_gemm_debug_slots(int n);
+ * a_rows / w_rows clamp the tile loads; M, N guard the stores; K % 64 == 0.
+ * tile: kernel choice, per call (no global state): 0 = automatic (256x256x64 ping-pong / 8-wave tiles for large shapes, 128x128x64
+ *       otherwise); tests pin one kernel with 128 | 256 | 8 (ping-pong schedule where it applies) | 4 (experimental four-wave).  */
+int owl_gemm_nt_bf16(void* stream, int epi, const void* A, int64_t lda, int64_t a_rows, const void* W, int64_t ldw, int64_t w_rows, const float* bias, void* out, int64_t ldo, const float* resid, void* aux, int64_t ld_aux, int64_t M, int64_t N, int64_t K, float alpha, int splits, int64_t Tp, int tile);
 /* epi 11 = split-K partial slabs out[split][M][ldo] (f32, no atomics); reduce them with owl_slab_reduce */
 int owl_gemm_effective_splits(int64_t K, int splits);
+/* f32 slab scratch of an epi-11 call (M, N, K, splits): bytes = owl_gemm_effective_splits(K, splits) * M * ldo * 4 (`bytes`: HOST pointer) */
+int owl_gemm_slab_workspace_bytes(int64_t M, int64_t ldo, int64_t K, int splits, int64_t* bytes);
 int owl_slab_reduce(void* stream, const float* slabs, float* out, int64_t n, int64_t slab_stride, int nsplit, int accumulate);
 
 /* ---- patch embedding (HF5:282-288 Conv2d k=s=patch, no bias; HF5:336-343 flatten + positions) ----
@@ -75,11 +75,10 @@ int owl_attention_fwd_bf16(void* stream, const void* q, const void* k, int64_t l
  * need no V^T copy and run ONE N = 3D QKV GEMM (HF5:437-439).  Bit-identical to owl_attention_fwd_bf16 on the same data. */
 int owl_attention_fwd_vrow_bf16(void* stream, const void* q, const void* k, const void* v, int64_t ld_qkv, void* out, int64_t ld_out, float* lse, int64_t B, int64_t H, int64_t T, int64_t Tp, float scale);
 
-/* tuning / race-hunting switches (bit 0: always rescale, bit 1: plain block mapping, bit 2: lgkmcnt(0) before barriers) */
-int owl_attention_debug(int flags);
 /* backward of the fused attention (layers whose attention runs backward): qkv row-major [B*Tp,3D] (q|k|v), dO / O row-major
  * [B*Tp,D], lse from the forward; writes dqkv [B*Tp,3D] (dq|dk|dv, bf16).  Every transposed operand of the dK/dV/dQ MFMAs is read
  * out of the row-major tiles by the LDS hardware (ds_read_b64_tr_b16): no Q^T / K^T / dO^T copies exist.  dvec_ws: f32 [B,H,Tp]. */
+int owl_attention_bwd_workspace_bytes(int64_t B, int64_t H, int64_t Tp, int64_t* bytes);   /* dvec_ws; `bytes` is a HOST pointer */
 int owl_attention_bwd_bf16(void* stream, const void* qkv, const void* dO, const void* O, const float* lse, float* dvec_ws, void* dqkv, int64_t B, int64_t H, int64_t T, int64_t Tp, float scale);
 
 /* ---- post_layernorm on all tokens + class-token merge + post_post_layernorm (ref src/models.py:80-86);
@@ -96,7 +95,12 @@ int owl_box_final_fwd(void* stream, const void* h_bf16, const float* w2, const f
 
 /* ---- Hungarian-matched push-pull loss, fully on device (no host sync) --------------------------------
  * Targets are padded: labels [B,Nmax] i64, tgt_boxes [B,Nmax,4] f32, counts [B] i32.
- * costT[b][j][p] = w_bbox*|box_p - tgt_j|_1 - w_class*softmax(sims_p)[label_j] - w_giou*GIoU   (ref src/matcher.py:106-131) */
+ * costT[b][j][p] = w_bbox*|box_p - tgt_j|_1 - w_class*softmax(sims_p)[label_j] - w_giou*GIoU   (ref src/matcher.py:106-131).
+ * A label outside [0, C) never indexes sims: its class term is 0 and owl_push_pull_loss returns loss_ce = NaN for that batch
+ * (the reference raises IndexError / one_hot error; validate on the host where the labels are host tensors). */
+/* ragged per-image target lists (ref main.py:77-79; src/matcher.py:94-104 `targets`) -> the padded form in ONE launch: labels_cat i64 [N],
+ * boxes_cat f32 [N,4] = the lists concatenated in image order, offsets i32 [B+1] (device) = image boundaries; pads are zero-filled. */
+int owl_pack_targets(void* stream, const int64_t* labels_cat, const float* boxes_cat, const int* offsets, int64_t* labels, float* boxes, int* counts, int64_t B, int64_t Nmax);
 int owl_match_cost(void* stream, const float* sims, const float* boxes, const int64_t* labels, const float* tgt_boxes, const int* counts, float* costT, int64_t B, int64_t P, int64_t C, int64_t Nmax, float w_class, float w_bbox, float w_giou);
 /* rectangular LSAP per image (replaces scipy.optimize.linear_sum_assignment at ref src/matcher.py:134-137, f64 duals,
  * scipy's tie rule) + target scatter (ref src/matcher.py:146-157): pairs ordered by prediction index             */
@@ -144,16 +148,23 @@ int owl_text_pool_project(void* stream, const float* x, const int64_t* ids, cons
  * zero_row: >= 512 B of device zeros (source of rows m >= M); slabs [splits_used][N][K] f32 are reduced by owl_slab_reduce;
  * splits_used is a HOST pointer.  owl_colsum_bf16: colsum[c] += sum_r in[r][c] (bias gradients).                       */
 int owl_gemm_tn_slab_bf16(void* stream, const void* dY, int64_t ldy, const void* X, int64_t ldx, const void* zero_row, float* slab, int64_t M, int64_t N, int64_t K, int splits, int* splits_used);
-int owl_colsum_bf16(void* stream, const void* in_bf16, int64_t ld, float* colsum, int64_t R, int64_t C);
+int owl_colsum_bf16(void* stream, const void* in_bf16, int64_t ld, float* colsum, int64_t R, int64_t C, float* partials, int64_t partials_floats);
+/* f32 slab scratch of the call above for (M, N, K, splits): bytes = splits_used * N * K * 4 (`bytes` is a HOST pointer) */
+int owl_gemm_tn_slab_workspace_bytes(int64_t M, int64_t N, int64_t K, int splits, int64_t* bytes);
 
 /* pairwise out3 = {iou, union, giou} each [N,M] (free functions box_iou / generalized_box_iou, ref src/matcher.py:8-44) */
 int owl_box_pairwise(void* stream, const float* boxes1, const float* boxes2, float* out3, int64_t N, int64_t M);
 
 /* ---- backward of the row-wise pieces (autograd forms of the entries above) --------------------------
- * parameter-gradient outputs (dgamma, dbeta, dw2, db2, dqueries, colsum) ACCUMULATE (atomics) into
- * buffers the caller zeroes once per step -- they are views of the flat gradient bucket.              */
-int owl_layernorm_bwd(void* stream, const void* dy, int dy_bf16, const float* x, const float* stats, const float* gamma, const float* dres, float* dx, float* dgamma, float* dbeta, int64_t rows, int64_t D, void* dx_bf16);
-int owl_merge_ln_bwd(void* stream, const float* dfeats, const float* x, const float* cls_ln, const float* stats1, const float* stats2, const float* g1, const float* b1, const float* g2, float* dx, float* dcls_ws, float* dg1, float* db1, float* dg2, float* db2, int64_t B, int64_t P, int64_t Tp, int64_t D);
+ * parameter-gradient outputs (dgamma, dbeta, dw2, db2, dqueries, colsum) ACCUMULATE into buffers the caller zeroes once per
+ * step -- they are views of the flat gradient bucket.  No atomics: every workgroup writes its partial sums into `partials`
+ * (caller-provided f32 scratch, `partials_floats` elements; size it once with owl_rowreduce_workspace_bytes) and a second
+ * kernel adds them in a fixed order, so the bucket is bitwise reproducible run to run.                                  */
+/* bytes of partial-sum scratch that serve every entry below for activations of `groups` images x `rows_per_group` rows x up
+ * to C columns (C = the widest matrix reduced over rows, e.g. the MLP width for the fc1 bias gradient); HOST pointer.   */
+int owl_rowreduce_workspace_bytes(int64_t groups, int64_t rows_per_group, int64_t C, int64_t* bytes);
+int owl_layernorm_bwd(void* stream, const void* dy, int dy_bf16, const float* x, const float* stats, const float* gamma, const float* dres, float* dx, float* dgamma, float* dbeta, int64_t rows, int64_t D, void* dx_bf16, float* partials, int64_t partials_floats);
+int owl_merge_ln_bwd(void* stream, const float* dfeats, const float* x, const float* cls_ln, const float* stats1, const float* stats2, const float* g1, const float* b1, const float* g2, float* dx, float* dcls_ws, float* dg1, float* db1, float* dg2, float* db2, int64_t B, int64_t P, int64_t Tp, int64_t D, float* partials, int64_t partials_floats);
 /* class head backward, row-parallel part: de (bf16 [rows,Dt]), routed upstream G (bf16 [rows,32]) and a bf16 copy of e;
  * dqhat[32,Dt] = G^T e is then a split-K owl_gemm_nt_bf16, and owl_query_normalize_bwd maps it onto dqueries            */
 int owl_class_sims_bwd(void* stream, const float* dsims, const float* sims, const unsigned char* argmax, const float* inv_norm, const float* e, const float* qhat32, void* de_bf16, void* g_bf16, void* e_bf16, int64_t rows, int64_t Dt, int64_t C);
@@ -161,8 +172,8 @@ int owl_query_normalize_bwd(void* stream, const float* dqhat, const float* queri
 /* dw2 [4,D] and db2 [4] must be contiguous (dw2 then db2); partials = f32 [owl_box_final_bwd_blocks(rows)][4*D+4] */
 int owl_box_final_bwd_blocks(int64_t rows);
 int owl_box_final_bwd(void* stream, const float* dboxes, const float* sig, const void* h1_bf16, const void* u1_bf16, const float* w2, void* du1_bf16, float* partials, float* dw2_db2, int64_t rows, int64_t D);
-int owl_transpose_colsum_bf16(void* stream, const void* in, int64_t ld_in, void* out_t, int64_t ld_out, float* colsum, int64_t R, int64_t C);
-int owl_colsum_f32(void* stream, const float* in, float* colsum, int64_t R, int64_t C);
+int owl_transpose_colsum_bf16(void* stream, const void* in, int64_t ld_in, void* out_t, int64_t ld_out, float* colsum, int64_t R, int64_t C, float* partials, int64_t partials_floats);
+int owl_colsum_f32(void* stream, const float* in, float* colsum, int64_t R, int64_t C, float* partials, int64_t partials_floats);
 
 /* ---- fused AdamW on the flat trainable bucket (replaces torch.optim.AdamW.step, ref main.py:56-60,91) -----
  * decoupled weight decay, bias-corrected; g is pre-scaled by grad_scale (1/world after the sum all-reduce);

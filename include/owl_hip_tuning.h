@@ -1,0 +1,22 @@
+/*
+ * Tuning / race-hunting switches of libowlhip -- NOT part of the product ABI.  They are process-global mutable state and
+ * only exist when the library is built with OWL_TUNING=1 (owl-vit-object-detection_amd/csrc/build.sh); the default build
+ * does not export them and `_lib.py` only binds them when OWL_TUNING=1 is set in the environment.  Used by tools/*.py.
+ */
+#ifndef OWL_HIP_TUNING_H
+#define OWL_HIP_TUNING_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* persistent scheduling (one workgroup per CU walks tiles with cross-tile prefetch): 1 on (default), 0 off */
+int owl_gemm_set_persistent(int on);
+/* 1: run the GEMM main loop but skip every epilogue store; 8: ping-pong trace run (tools/pp_trace.py) */
+int owl_gemm_debug_nostore(int on);
+/* override the persistent grid size */
+int owl_gemm_debug_slots(int n);
+/* attention forward: bit 0 always rescale, bit 1 plain block mapping, bit 2 the first tile always sets the softmax offset */
+int owl_attention_debug(int flags);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -11,6 +11,7 @@ import re
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 HEADER = os.path.join(_ROOT, "include", "owl_hip.h")
+TUNING_HEADER = os.path.join(_ROOT, "include", "owl_hip_tuning.h")      # bound only when OWL_TUNING=1 (tools/, tuning builds)
 LIB_PATH = os.path.join(_PKG, "libowlhip.so")
 
 _CTYPES = {
@@ -62,6 +63,8 @@ def load():
             "(or owl-vit-object-detection_amd/csrc/build.sh). There is no CPU fallback.")
     lib = ctypes.CDLL(LIB_PATH)
     _protos = parse_header()
+    if os.environ.get("OWL_TUNING", "0") == "1":
+        _protos.update(parse_header(TUNING_HEADER))
     for name, (ret, args) in _protos.items():
         try:
             fn = getattr(lib, name)

@@ -47,11 +47,18 @@ class OwlViTFunction(torch.autograd.Function):
         ctx.model = model
         ctx.B = image.shape[0]
         ctx.sims = sims
+        ctx.gen = model._workspace(ctx.B)["gen"]
         return boxes, sims
 
     @staticmethod
     def backward(ctx, d_boxes, d_sims):
         model, B = ctx.model, ctx.B
+        if model._workspace(B)["gen"] != ctx.gen:
+            # saved activations live in per-batch-size workspaces (not in ctx): a later gradient-recording forward at this batch
+            # size has overwritten them (e.g. two forwards, then (l1 + l2).backward())
+            raise RuntimeError(
+                f"OwlViT backward: the activations of this forward (batch size {B}) were overwritten by a later gradient-recording "
+                "forward at the same batch size; call backward() before the next training forward (no-grad / eval forwards are fine)")
         backward_impl(model, B, d_boxes, d_sims, ctx.sims)
         return (None, None) + (None,) * len(model.flat_offsets)
 
@@ -77,6 +84,9 @@ def _bws(model, B):
         dx=z(M, D, f32, dev), dxb=z(M, D, bf, dev), du=z(M, I, bf, dev), dh=z(M, D, bf, dev), dxm=z(M, D, f32, dev),
         datt=z(M, D, bf, dev), dqkv=z(M, 3 * D, bf, dev),
         dvec=torch.zeros(B, H, Tp, device=dev),
+        # partial sums of the deterministic row reductions (bias / LayerNorm-affine gradients): written by one kernel, added in a
+        # fixed order by the next -- no f32 atomics into the gradient bucket
+        part=ops.rowreduce_workspace(B, Tp, max(3 * D, I, Dt), dev),
         # transposed-operand scratch for the dW GEMMs; token-row and head-row users get their own buffers so
         # that the zero pad columns [rows, rows_pad) of each are never dirtied by the other row count
         # (only the shapes the TN kernel does not take need them: feature counts that are not multiples of 256 -- the
@@ -113,6 +123,8 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
     Mp, Mhp = ops.pad_rows(M), ops.pad_rows(Mh)
     ws, bw = model._workspace(B), _bws(model, B)
     P_ = model._byname
+    model._wait_params()
+    model._grad_clean = False
     _attach_grads(model)
     G = lambda n: P_[n].grad                      # views into model.flat_grad (accumulated into)
     tv = model._tview
@@ -133,7 +145,7 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
         if n_out % 256 == 0 and n_in % 256 == 0:
             # TN kernel: reads dy / x where they lie (LDS transpose-reads), no token-major copies
             if grad_b is not None:
-                ops.colsum_bf16(dy, grad_b, rows, n_out)
+                ops.colsum_bf16(dy, grad_b, rows, n_out, partials=bw["part"])
             tiles = (n_out // 256) * (n_in // 256)
             ns = ops.gemm_tn_slab(dy, x, bw["slab"], rows, n_out, n_in, max(1, 256 // tiles))
             _lib.call("owl_slab_reduce", ops.stream(), bw["slab"], grad_w, n_out * n_in, n_out * n_in, ns, accumulate)
@@ -141,7 +153,7 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
         tA, tB = (bw["tAh"], bw["tBh"]) if rows == Mh else (bw["tA"], bw["tB"])
         ld = tA.shape[1]
         assert ld == rows_pad
-        ops.transpose_colsum(dy, tA, grad_b, rows, n_out, ld_in=dy.shape[-1], ld_out=ld)
+        ops.transpose_colsum(dy, tA, grad_b, rows, n_out, ld_in=dy.shape[-1], ld_out=ld, partials=bw["part"])
         ops.transpose_colsum(x, tB, None, rows, n_in, ld_in=x.shape[-1], ld_out=ld)
         want = _split_k(n_out, n_in, rows_pad)
         ns = _lib.load().owl_gemm_effective_splits(rows_pad, want)
@@ -167,7 +179,7 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
     ops.merge_ln_bwd(bw["dfeats"], ws["x"], ws["cls_ln"], ws["st_post"], ws["st_pp"], P_["backbone.post_layernorm.weight"],
                      P_["backbone.post_layernorm.bias"], P_["post_post_layernorm.weight"], bw["dx"], bw["dcls"],
                      G("backbone.post_layernorm.weight"), G("backbone.post_layernorm.bias"), G("post_post_layernorm.weight"),
-                     G("post_post_layernorm.bias"), B, P, Tp, D)
+                     G("post_post_layernorm.bias"), B, P, Tp, D, partials=bw["part"])
     scale = cfg.head_dim ** -0.5
     dxb_fresh = False        # bw["dxb"] already holds the bf16 copy of bw["dx"] (written by the last LayerNorm backward)
     # ---- frozen layers ABOVE the trainable one (literal "layers.11" rule on a deeper model): dX only ----------
@@ -191,15 +203,15 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
     # ---- trainable encoder layer: MLP ---------------------------------------------------------------------
     if not dxb_fresh:
         ops.cast_bf16(bw["dx"], bw["dxb"])
-    ops.colsum_f32(bw["dx"], G(tl + "mlp.fc2.bias"), M, D)
+    ops.colsum_f32(bw["dx"], G(tl + "mlp.fc2.bias"), M, D, partials=bw["part"])
     dW(bw["dxb"], Lt["g"], G(tl + "mlp.fc2.weight"), D, I, M, Mp)
     ops.gemm(ops.EPI_DQGELU_BF16, bw["dxb"], wT(tl + "mlp.fc2.weight", D, I), bw["du"], aux=Lt["u"], M=M, N=I, K=D)
     dW(bw["du"], Lt["h2"], G(tl + "mlp.fc1.weight"), I, D, M, Mp, G(tl + "mlp.fc1.bias"))
     ops.gemm(ops.EPI_BIAS_BF16, bw["du"], wT(tl + "mlp.fc1.weight", I, D), bw["dh"], M=M, N=D, K=I)
     ops.layernorm_bwd(bw["dh"], Lt["x_mid"], Lt["st2"], P_[tl + "layer_norm2.weight"], bw["dx"], bw["dxm"],
-                      G(tl + "layer_norm2.weight"), G(tl + "layer_norm2.bias"), M, D, dx_bf16=bw["dxb"])
+                      G(tl + "layer_norm2.weight"), G(tl + "layer_norm2.bias"), M, D, dx_bf16=bw["dxb"], partials=bw["part"])
     # ---- trainable encoder layer: attention -----------------------------------------------------------------
-    ops.colsum_f32(bw["dxm"], G(tl + "self_attn.out_proj.bias"), M, D)
+    ops.colsum_f32(bw["dxm"], G(tl + "self_attn.out_proj.bias"), M, D, partials=bw["part"])
     dW(bw["dxb"], Lt["att"], G(tl + "self_attn.out_proj.weight"), D, D, M, Mp)
     woT = wT(tl + "self_attn.out_proj.weight", D, D)
     ops.gemm(ops.EPI_BIAS_BF16, bw["dxb"], woT, bw["datt"], M=M, N=D, K=D)
@@ -216,4 +228,4 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
     ops.gemm(ops.EPI_BIAS_BF16, bw["dqkv"], wqkvT, bw["dh"], M=M, N=D, K=3 * D)
     # everything below layer_norm1 is frozen: only its affine parameters need gradients
     ops.layernorm_bwd(bw["dh"], Lt["x_in"], Lt["st1"], P_[tl + "layer_norm1.weight"], None, None,
-                      G(tl + "layer_norm1.weight"), G(tl + "layer_norm1.bias"), M, D)
+                      G(tl + "layer_norm1.weight"), G(tl + "layer_norm1.bias"), M, D, partials=bw["part"])

@@ -357,8 +357,12 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
     }
 }
 
+#ifdef OWL_TUNING   // tuning / race-hunting switches exist only in an OWL_TUNING build (include/owl_hip_tuning.h)
 static int g_attn_dbg = 0;
 extern "C" int owl_attention_debug(int flags) { g_attn_dbg = flags; return 0; }
+#else
+static constexpr int g_attn_dbg = 0;
+#endif
 
 static int attn_fwd_launch(void* stream, const void* q, const void* k, int64_t ld_qk, const void* v, int v_row_major,
                            int64_t vt_img_stride, void* out, int64_t ld_out, float* lse, int64_t B, int64_t H, int64_t T,

@@ -1,11 +1,61 @@
 // Backward kernels for the row-wise (HBM-bound) pieces of the train path: LayerNorm, class-token merge,
 // class head, box head tail, bias gradients.  The GEMM-shaped backward work (dX, dW) reuses gemm.hip.
 // Reference: these are the autograd forms of ref src/models.py:24-38, 65-73, 80-86 and HF5:484-509.
-// Parameter-gradient reductions over rows use per-workgroup partial sums followed by f32 atomics
-// into the flat gradient bucket (which the host zeroes once per step).
+// Parameter-gradient reductions over rows are DETERMINISTIC: every workgroup writes its partial sums to a caller-provided
+// f32 workspace and a second kernel adds them in a fixed order into the flat gradient bucket (no f32 atomics anywhere:
+// the bucket is bitwise reproducible run to run, tests/test_determinism_gpu.py).
 #include "common.h"
 
 static constexpr int LN_MAXV = 4;
+
+// out_k[c] (+)= sum_{s < nblk} part[g*group_stride + s*stride + k*seg + c]   for k < nseg, c < seg, every group g = blockIdx.y
+// (out_k advanced by g*out_group_stride).  Fixed summation order: a thread adds slabs s = j, j+16, ... in order, then the 16
+// partial sums of a column are added in order 0..15.  seg % 4 == 0.
+struct ReduceOuts { float* o[5]; };
+__global__ __launch_bounds__(256) void partials_reduce_kernel(const float* __restrict__ part, ReduceOuts outs, int nseg, int seg, int64_t stride,
+                                                              int nblk, int64_t group_stride, int64_t out_group_stride, int accumulate) {
+    __shared__ float4 red[16][16];
+    const int cq = threadIdx.x & 15, j = threadIdx.x >> 4;          // 16 column quads x 16 slab lanes
+    const int64_t n = (int64_t)nseg * seg;
+    const int64_t c = ((int64_t)blockIdx.x * 16 + cq) * 4;
+    const float* base = part + (int64_t)blockIdx.y * group_stride + c;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < n) {
+#pragma unroll 4
+        for (int s = j; s < nblk; s += 16) {
+            const float4 v = *(const float4*)(base + (int64_t)s * stride);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+    }
+    red[j][cq] = a;
+    __syncthreads();
+    if (j == 0 && c < n) {
+        float4 t = red[0][cq];
+#pragma unroll
+        for (int k = 1; k < 16; k++) { const float4 v = red[k][cq]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        const int k = (int)(c / seg);
+        float* o = outs.o[k] + (int64_t)blockIdx.y * out_group_stride + (c - (int64_t)k * seg);
+        if (accumulate) { const float4 r = *(const float4*)o; t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w; }
+        *(float4*)o = t;
+    }
+}
+
+static int partials_reduce(hipStream_t s, const float* part, ReduceOuts outs, int nseg, int seg, int64_t stride, int nblk, int groups,
+                           int64_t group_stride, int64_t out_group_stride, int accumulate) {
+    const int64_t n = (int64_t)nseg * seg;
+    hipLaunchKernelGGL(partials_reduce_kernel, dim3((unsigned)((n / 4 + 15) / 16), (unsigned)groups), dim3(256), 0, s, part, outs, nseg, seg, stride,
+                       nblk, group_stride, out_group_stride, accumulate);
+    OWL_LAUNCH_CHECK();
+    return 0;
+}
+
+// f32 elements of partial-sum scratch that serve every row-reduction entry below for activations of `groups` images x
+// `rows_per_group` rows x up to C columns (C = the widest reduced matrix, e.g. the MLP width for the fc1 bias gradient)
+extern "C" int owl_rowreduce_workspace_bytes(int64_t groups, int64_t rows_per_group, int64_t C, int64_t* bytes) {
+    OWL_CHECK_ARG(bytes && groups >= 1 && rows_per_group >= 1 && C >= 4, "owl_rowreduce_workspace_bytes: bad arguments");
+    *bytes = groups * ((rows_per_group + 63) / 64) * 5 * C * (int64_t)sizeof(float);
+    return 0;
+}
 
 // ---------------------------------------------------------------------------------------------------
 // LayerNorm backward: dx = (dres) + rstd * (g*dy - mean(g*dy) - xhat*mean(g*dy*xhat));  dgamma += dy*xhat,
@@ -14,7 +64,7 @@ static constexpr int LN_MAXV = 4;
 template <bool DY_BF16>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy_, const float* __restrict__ x,
                                                      const float2* __restrict__ stats, const float* __restrict__ gamma,
-                                                     const float* dres, float* dx, float* dgamma, float* dbeta, int64_t rows,
+                                                     const float* dres, float* dx, float* part, int64_t rows,
                                                      int D, int rows_per_block, bf16_t* dx_bf16) {
     __shared__ float red[2][4][LN_MAXV * 256 + 4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -70,34 +120,44 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
             }
         }
     }
-    if (!dgamma) return;
-    // reduce the 4 waves' partials through LDS, then one atomic per column per workgroup
+    if (!part) return;
+    // reduce the 4 waves' partials through LDS; this workgroup's sums go to part[blockIdx.x][{dgamma, dbeta}][D]
 #pragma unroll
     for (int i = 0; i < LN_MAXV; i++) {
         const int idx = lane + i * 64;
         if (idx < nvec) { *(float4*)&red[0][w][idx * 4] = ag[i]; *(float4*)&red[1][w][idx * 4] = ab[i]; }
     }
     __syncthreads();
+    float* mine = part + (int64_t)blockIdx.x * 2 * D;
     for (int c = threadIdx.x; c < D; c += 256) {
-        atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
-        atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+        mine[c] = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+        mine[D + c] = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
     }
 }
 
 extern "C" int owl_layernorm_bwd(void* stream, const void* dy, int dy_bf16, const float* x, const float* stats, const float* gamma,
-                                 const float* dres, float* dx, float* dgamma, float* dbeta, int64_t rows, int64_t D, void* dx_bf16) {
+                                 const float* dres, float* dx, float* dgamma, float* dbeta, int64_t rows, int64_t D, void* dx_bf16,
+                                 float* partials, int64_t partials_floats) {
     OWL_CHECK_ARG(dy && x && stats && gamma, "owl_layernorm_bwd: null pointer");
     OWL_CHECK_ARG(D % 4 == 0 && D <= 256 * LN_MAXV, "owl_layernorm_bwd: D must be a multiple of 4 and <= 1024");
     OWL_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "owl_layernorm_bwd: dgamma/dbeta both or neither");
     OWL_CHECK_ARG(!dx_bf16 || dx, "owl_layernorm_bwd: dx_bf16 needs dx");
     const int rpb = 64;
-    dim3 grid((unsigned)((rows + rpb - 1) / rpb));
+    const int nblk = (int)((rows + rpb - 1) / rpb);
+    dim3 grid((unsigned)nblk);
+    float* part = nullptr;
+    if (dgamma) {
+        OWL_CHECK_ARG(partials && partials_floats >= (int64_t)nblk * 2 * D, "owl_layernorm_bwd: parameter gradients need %lld floats of partial-sum scratch (owl_rowreduce_workspace_bytes)", (long long)nblk * 2 * D);
+        part = partials;
+    }
     if (dy_bf16)
-        hipLaunchKernelGGL(ln_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dy, x, (const float2*)stats, gamma, dres, dx, dgamma, dbeta, rows, (int)D, rpb, (bf16_t*)dx_bf16);
+        hipLaunchKernelGGL(ln_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dy, x, (const float2*)stats, gamma, dres, dx, part, rows, (int)D, rpb, (bf16_t*)dx_bf16);
     else
-        hipLaunchKernelGGL(ln_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dy, x, (const float2*)stats, gamma, dres, dx, dgamma, dbeta, rows, (int)D, rpb, (bf16_t*)dx_bf16);
+        hipLaunchKernelGGL(ln_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dy, x, (const float2*)stats, gamma, dres, dx, part, rows, (int)D, rpb, (bf16_t*)dx_bf16);
     OWL_LAUNCH_CHECK();
-    return 0;
+    if (!part) return 0;
+    ReduceOuts outs{}; outs.o[0] = dgamma; outs.o[1] = dbeta;
+    return partials_reduce((hipStream_t)stream, part, outs, 2, (int)D, 2 * D, nblk, 1, 0, 0, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -109,8 +169,7 @@ __global__ __launch_bounds__(256) void merge_ln_bwd_kernel(const float* __restri
                                                            const float* __restrict__ cls_ln, const float2* __restrict__ stats1,
                                                            const float2* __restrict__ stats2, const float* __restrict__ g1,
                                                            const float* __restrict__ b1, const float* __restrict__ g2, float* dx,
-                                                           float* dcls, float* dg1, float* db1, float* dg2, float* db2, int64_t P,
-                                                           int64_t Tp, int D, int rows_per_block) {
+                                                           float* part, int64_t P, int64_t Tp, int D, int rows_per_block) {
     __shared__ float red[4][LN_MAXV * 256 + 4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t b = blockIdx.y;
@@ -172,7 +231,8 @@ __global__ __launch_bounds__(256) void merge_ln_bwd_kernel(const float* __restri
                                                               s1.y * (gd[i].z - n1 - xh[i].z * n2), s1.y * (gd[i].w - n1 - xh[i].w * n2));
         }
     }
-    // five column reductions: 4 waves -> LDS -> atomics
+    // five column reductions: 4 waves -> LDS -> this workgroup's slab part[b][blockIdx.x][{dcls, dg1, db1, dg2, db2}][D]
+    float* mine = part + ((int64_t)b * gridDim.x + blockIdx.x) * 5 * D;
     auto flush = [&](float4 (&acc)[LN_MAXV], float* dst) {
         __syncthreads();
 #pragma unroll
@@ -181,16 +241,16 @@ __global__ __launch_bounds__(256) void merge_ln_bwd_kernel(const float* __restri
             if (idx < nvec) *(float4*)&red[w][idx * 4] = acc[i];
         }
         __syncthreads();
-        for (int c = threadIdx.x; c < D; c += 256) atomicAdd(dst + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+        for (int c = threadIdx.x; c < D; c += 256) dst[c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
     };
-    flush(a_c, dcls + b * D);
-    flush(a_g1, dg1); flush(a_b1, db1); flush(a_g2, dg2); flush(a_b2, db2);
+    flush(a_c, mine);
+    flush(a_g1, mine + D); flush(a_b1, mine + 2 * D); flush(a_g2, mine + 3 * D); flush(a_b2, mine + 4 * D);
 }
 
 // cls rows: dy0 = dcls[b,:] -> LN1 backward on token 0 of image b
 __global__ __launch_bounds__(64) void cls_ln_bwd_kernel(const float* __restrict__ dcls, const float* __restrict__ x,
                                                         const float2* __restrict__ stats1, const float* __restrict__ g1, float* dx,
-                                                        float* dg1, float* db1, int64_t Tp, int D) {
+                                                        float* part, int64_t Tp, int D) {
     const int lane = threadIdx.x;
     const int64_t b = blockIdx.x, row = b * Tp;
     const int nvec = D >> 2;
@@ -206,9 +266,9 @@ __global__ __launch_bounds__(64) void cls_ln_bwd_kernel(const float* __restrict_
             gd[i] = make_float4(dy.x * g.x, dy.y * g.y, dy.z * g.z, dy.w * g.w);
             s1 += gd[i].x + gd[i].y + gd[i].z + gd[i].w;
             s2 += gd[i].x * xh[i].x + gd[i].y * xh[i].y + gd[i].z * xh[i].z + gd[i].w * xh[i].w;
-            float* pg = dg1 + idx * 4; float* pb = db1 + idx * 4;
-            atomicAdd(pg + 0, dy.x * xh[i].x); atomicAdd(pg + 1, dy.y * xh[i].y); atomicAdd(pg + 2, dy.z * xh[i].z); atomicAdd(pg + 3, dy.w * xh[i].w);
-            atomicAdd(pb + 0, dy.x); atomicAdd(pb + 1, dy.y); atomicAdd(pb + 2, dy.z); atomicAdd(pb + 3, dy.w);
+            // this image's contribution to (dg1, db1): part[b][{dg1, db1}][D], reduced in image order afterwards
+            ((float4*)(part + b * 2 * D))[idx] = make_float4(dy.x * xh[i].x, dy.y * xh[i].y, dy.z * xh[i].z, dy.w * xh[i].w);
+            ((float4*)(part + b * 2 * D + D))[idx] = dy;
         }
     }
     s1 = wave_sum(s1) / (float)D; s2 = wave_sum(s2) / (float)D;
@@ -223,19 +283,29 @@ __global__ __launch_bounds__(64) void cls_ln_bwd_kernel(const float* __restrict_
 
 extern "C" int owl_merge_ln_bwd(void* stream, const float* dfeats, const float* x, const float* cls_ln, const float* stats1,
                                 const float* stats2, const float* g1, const float* b1, const float* g2, float* dx, float* dcls_ws,
-                                float* dg1, float* db1, float* dg2, float* db2, int64_t B, int64_t P, int64_t Tp, int64_t D) {
-    OWL_CHECK_ARG(dfeats && x && cls_ln && stats1 && stats2 && g1 && b1 && g2 && dx && dcls_ws && dg1 && db1 && dg2 && db2, "owl_merge_ln_bwd: null pointer");
+                                float* dg1, float* db1, float* dg2, float* db2, int64_t B, int64_t P, int64_t Tp, int64_t D,
+                                float* partials, int64_t partials_floats) {
+    OWL_CHECK_ARG(dfeats && x && cls_ln && stats1 && stats2 && g1 && b1 && g2 && dx && dcls_ws && dg1 && db1 && dg2 && db2 && partials, "owl_merge_ln_bwd: null pointer");
     OWL_CHECK_ARG(D % 4 == 0 && D <= 256 * LN_MAXV, "owl_merge_ln_bwd: D must be a multiple of 4 and <= 1024");
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(dcls_ws, 0, (size_t)(B * D) * sizeof(float), s);
-    OWL_CHECK_ARG(e == hipSuccess, "owl_merge_ln_bwd: memset failed");
     const int rpb = 64;
-    hipLaunchKernelGGL(merge_ln_bwd_kernel, dim3((unsigned)((P + rpb - 1) / rpb), (unsigned)B), dim3(256), 0, s, dfeats, x, cls_ln,
-                       (const float2*)stats1, (const float2*)stats2, g1, b1, g2, dx, dcls_ws, dg1, db1, dg2, db2, P, Tp, (int)D, rpb);
+    const int nbx = (int)((P + rpb - 1) / rpb);
+    OWL_CHECK_ARG(partials_floats >= B * nbx * 5 * D, "owl_merge_ln_bwd: needs %lld floats of partial-sum scratch (owl_rowreduce_workspace_bytes)", (long long)(B * nbx * 5 * D));
+    hipLaunchKernelGGL(merge_ln_bwd_kernel, dim3((unsigned)nbx, (unsigned)B), dim3(256), 0, s, dfeats, x, cls_ln,
+                       (const float2*)stats1, (const float2*)stats2, g1, b1, g2, dx, partials, P, Tp, (int)D, rpb);
     OWL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(cls_ln_bwd_kernel, dim3((unsigned)B), dim3(64), 0, s, dcls_ws, x, (const float2*)stats1, g1, dx, dg1, db1, Tp, (int)D);
+    // d(cls_ln)[b] = sum over the image's row blocks (per-image groups); the four LN parameter gradients += sum over all slabs
+    ReduceOuts oc{}; oc.o[0] = dcls_ws;
+    int rc = partials_reduce(s, partials, oc, 1, (int)D, 5 * D, nbx, (int)B, (int64_t)nbx * 5 * D, D, 0);
+    if (rc) return rc;
+    ReduceOuts op{}; op.o[0] = dg1; op.o[1] = db1; op.o[2] = dg2; op.o[3] = db2;
+    rc = partials_reduce(s, partials + D, op, 4, (int)D, 5 * D, (int)(B * nbx), 1, 0, 0, 1);
+    if (rc) return rc;
+    // class-token rows: the slabs above have been consumed (stream order), so the scratch is reused for part[b][{dg1, db1}][D]
+    hipLaunchKernelGGL(cls_ln_bwd_kernel, dim3((unsigned)B), dim3(64), 0, s, dcls_ws, x, (const float2*)stats1, g1, dx, partials, Tp, (int)D);
     OWL_LAUNCH_CHECK();
-    return 0;
+    ReduceOuts o2{}; o2.o[0] = dg1; o2.o[1] = db1;
+    return partials_reduce(s, partials, o2, 2, (int)D, 2 * D, (int)B, 1, 0, 0, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -445,7 +515,7 @@ extern "C" int owl_box_final_bwd(void* stream, const float* dboxes, const float*
 // consecutive rows (= 8 consecutive output columns) per thread.  R must be a multiple of 8 for the vector store path
 // (token counts are; the scalar tail handles the rest), C a multiple of 8.
 __global__ __launch_bounds__(256) void transpose_colsum_kernel(const bf16_t* __restrict__ in, int64_t ld_in, bf16_t* __restrict__ out,
-                                                               int64_t ld_out, float* colsum, int64_t R, int64_t C, int row_tiles) {
+                                                               int64_t ld_out, float* colsum, int64_t R, int64_t C, int row_tiles, int64_t Cpad) {
     __shared__ __attribute__((aligned(16))) bf16_t tile[64][72];
     __shared__ float cs[32][65];
     const int64_t c0 = (int64_t)blockIdx.x * 64;
@@ -493,25 +563,30 @@ __global__ __launch_bounds__(256) void transpose_colsum_kernel(const bf16_t* __r
         if (t < 64 && c0 + t < C) {
             float s = 0.f;
             for (int k = 0; k < 32; k++) s += cs[k][t];
-            atomicAdd(colsum + c0 + t, s);
+            colsum[(int64_t)blockIdx.y * Cpad + c0 + t] = s;         // this row-block's partial (colsum = the partials scratch here)
         }
     }
 }
 
 extern "C" int owl_transpose_colsum_bf16(void* stream, const void* in, int64_t ld_in, void* out_t, int64_t ld_out, float* colsum,
-                                         int64_t R, int64_t C) {
+                                         int64_t R, int64_t C, float* partials, int64_t partials_floats) {
     OWL_CHECK_ARG(in && (out_t || colsum) && R > 0 && C > 0, "owl_transpose_colsum_bf16: bad args");
     OWL_CHECK_ARG(ld_in % 8 == 0 && (!out_t || ld_out % 8 == 0), "owl_transpose_colsum_bf16: leading dimensions must be multiples of 8");
     const int row_tiles = 8;
     dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + 64 * row_tiles - 1) / (64 * row_tiles)));
-    hipLaunchKernelGGL(transpose_colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, ld_in, (bf16_t*)out_t, ld_out, colsum, R, C, row_tiles);
+    const int64_t Cpad = (C + 3) / 4 * 4;
+    if (colsum) OWL_CHECK_ARG(C % 4 == 0 && partials && partials_floats >= (int64_t)grid.y * Cpad, "owl_transpose_colsum_bf16: column sums need C %% 4 == 0 and %lld floats of partial-sum scratch", (long long)grid.y * Cpad);
+    hipLaunchKernelGGL(transpose_colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, ld_in, (bf16_t*)out_t, ld_out,
+                       colsum ? partials : nullptr, R, C, row_tiles, Cpad);
     OWL_LAUNCH_CHECK();
-    return 0;
+    if (!colsum) return 0;
+    ReduceOuts o{}; o.o[0] = colsum;
+    return partials_reduce((hipStream_t)stream, partials, o, 1, (int)C, Cpad, (int)grid.y, 1, 0, 0, 1);
 }
 
 // f32 column sums (bias gradient of an f32 upstream, e.g. the residual-stream gradient); colsum += sum_r in[r][c].
 // A workgroup owns 256 columns x 256 rows: lane -> 4 columns (16-byte loads), its 4 waves take rows r0+w, r0+w+4, ...;
-// partials meet in LDS, one f32 atomicAdd per column and workgroup (the first version: one thread per column, 1.9 TB/s).
+// partials meet in LDS, one partial sum per column and workgroup, reduced in fixed order afterwards (the first version: one thread per column, 1.9 TB/s).
 __global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ in, float* colsum, int64_t R, int64_t C) {
     __shared__ float part[4][256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -527,19 +602,22 @@ __global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict
     part[w][lane * 4 + 0] = acc.x; part[w][lane * 4 + 1] = acc.y; part[w][lane * 4 + 2] = acc.z; part[w][lane * 4 + 3] = acc.w;
     __syncthreads();
     const int64_t cc = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (cc < C) atomicAdd(colsum + cc, (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]));
+    if (cc < C) colsum[(int64_t)blockIdx.y * C + cc] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
-extern "C" int owl_colsum_f32(void* stream, const float* in, float* colsum, int64_t R, int64_t C) {
-    OWL_CHECK_ARG(in && colsum && R > 0 && C > 0 && C % 4 == 0, "owl_colsum_f32: bad arguments (C %% 4 == 0)");
-    hipLaunchKernelGGL(colsum_f32_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)((R + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, colsum, R, C);
+extern "C" int owl_colsum_f32(void* stream, const float* in, float* colsum, int64_t R, int64_t C, float* partials, int64_t partials_floats) {
+    OWL_CHECK_ARG(in && colsum && partials && R > 0 && C > 0 && C % 4 == 0, "owl_colsum_f32: bad arguments (C %% 4 == 0)");
+    const int gy = (int)((R + 255) / 256);
+    OWL_CHECK_ARG(partials_floats >= (int64_t)gy * C, "owl_colsum_f32: needs %lld floats of partial-sum scratch", (long long)gy * C);
+    hipLaunchKernelGGL(colsum_f32_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)gy), dim3(256), 0, (hipStream_t)stream, in, partials, R, C);
     OWL_LAUNCH_CHECK();
-    return 0;
+    ReduceOuts o{}; o.o[0] = colsum;
+    return partials_reduce((hipStream_t)stream, partials, o, 1, (int)C, C, gy, 1, 0, 0, 1);
 }
 
 // bf16 column sums (bias gradient when the weight gradient reads dY in place: gemm_tn.hip); colsum += sum_r in[r][c].
 // A workgroup owns 512 columns x 256 rows: lane -> 8 columns (16-byte loads, a wave reads 1 KiB of a row), its 4 waves
-// take rows r0+w, r0+w+4, ...; partial sums meet in LDS, one f32 atomicAdd per column and workgroup.  HBM-bound:
+// take rows r0+w, r0+w+4, ...; partial sums meet in LDS, one partial sum per column and workgroup (reduced in fixed order afterwards).  HBM-bound:
 // reads R*C*2 bytes once.
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ in, int64_t ld, float* colsum, int64_t R, int64_t C) {
     __shared__ float part[4][512];
@@ -560,14 +638,17 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
     __syncthreads();
     for (int i = threadIdx.x; i < 512; i += 256) {
         const int64_t cc = (int64_t)blockIdx.x * 512 + i;
-        if (cc < C) atomicAdd(colsum + cc, (part[0][i] + part[1][i]) + (part[2][i] + part[3][i]));
+        if (cc < C) colsum[(int64_t)blockIdx.y * C + cc] = (part[0][i] + part[1][i]) + (part[2][i] + part[3][i]);
     }
 }
 
-extern "C" int owl_colsum_bf16(void* stream, const void* in_bf16, int64_t ld, float* colsum, int64_t R, int64_t C) {
-    OWL_CHECK_ARG(in_bf16 && colsum && R > 0 && C > 0 && C % 8 == 0 && ld % 8 == 0, "owl_colsum_bf16: bad arguments (C, ld %% 8 == 0)");
-    hipLaunchKernelGGL(colsum_bf16_kernel, dim3((unsigned)((C + 511) / 512), (unsigned)((R + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)in_bf16, ld, colsum, R, C);
+extern "C" int owl_colsum_bf16(void* stream, const void* in_bf16, int64_t ld, float* colsum, int64_t R, int64_t C, float* partials, int64_t partials_floats) {
+    OWL_CHECK_ARG(in_bf16 && colsum && partials && R > 0 && C > 0 && C % 8 == 0 && ld % 8 == 0, "owl_colsum_bf16: bad arguments (C, ld %% 8 == 0)");
+    const int gy = (int)((R + 255) / 256);
+    OWL_CHECK_ARG(partials_floats >= (int64_t)gy * C, "owl_colsum_bf16: needs %lld floats of partial-sum scratch", (long long)gy * C);
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3((unsigned)((C + 511) / 512), (unsigned)gy), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)in_bf16, ld, partials, R, C);
     OWL_LAUNCH_CHECK();
-    return 0;
+    ReduceOuts o{}; o.o[0] = colsum;
+    return partials_reduce((hipStream_t)stream, partials, o, 1, (int)C, C, gy, 1, 0, 0, 1);
 }

@@ -4,6 +4,8 @@ set -e
 cd "$(dirname "$0")"
 ARCH=${OWL_ARCH:-gfx950}
 FLAGS="--offload-arch=${ARCH} -O3 -std=c++17 -fPIC -Wno-unused-value"
+# OWL_TUNING=1: also export the process-global tuning switches of include/owl_hip_tuning.h (tools/ only; never the shipped build)
+if [ "${OWL_TUNING:-0}" = "1" ]; then FLAGS="$FLAGS -DOWL_TUNING"; fi
 mkdir -p build
 objs=""
 for f in *.hip; do

@@ -22,12 +22,19 @@
 
 static constexpr int BK = 64;
 
-static int g_persistent = 1;
+// The shipped library has NO process-global mutable state (SURVEY.md section 8b "re-entrant"): the kernel choice is a per-call
+// argument (`tile`) and the tuning switches below only exist in an OWL_TUNING build (csrc/build.sh with OWL_TUNING=1;
+// prototypes in include/owl_hip_tuning.h), where tools/ uses them for A/B experiments.
+#ifdef OWL_TUNING
+static int g_persistent = 1;      // persistent scheduling (one workgroup per CU walks tiles with cross-tile prefetch)
 extern "C" int owl_gemm_set_persistent(int on) { g_persistent = on; return 0; }
-static int g_debug_slots = 0;     // tuning experiments only: override the persistent grid size
+static int g_debug_slots = 0;     // override the persistent grid size
 extern "C" int owl_gemm_debug_slots(int n) { g_debug_slots = n; return 0; }
-static int g_debug_nostore = 0;   // tuning experiments only: run the main loop but skip every epilogue store
+static int g_debug_nostore = 0;   // 1: run the main loop but skip every epilogue store; 8: ping-pong trace run
 extern "C" int owl_gemm_debug_nostore(int on) { g_debug_nostore = on; return 0; }
+#else
+static constexpr int g_persistent = 1, g_debug_slots = 0, g_debug_nostore = 0;
+#endif
 
 template <int EPI, int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_nt_kernel(GemmP p) {
@@ -291,13 +298,11 @@ static int launch_cfg(hipStream_t s, GemmP p, int splits) {
     return 0;
 }
 
-static int g_force_tile = 0;   // 0 auto, 128, 256, 8 = ping-pong schedule (gemm_pp.hip) where it applies (tests / tuning)
-extern "C" int owl_gemm_set_tile(int tile) { g_force_tile = tile; return 0; }
 int owl_gemm_pp_launch(hipStream_t s, int epi, const GemmP& p, int slots_override, int persistent_on, int nostore);   // gemm_pp.hip
 int owl_gemm_w4_launch(hipStream_t s, int epi, const GemmP& p);                                                       // gemm_w4.hip
 
 template <int EPI>
-static int launch(hipStream_t s, const GemmP& p, int splits) {
+static int launch(hipStream_t s, const GemmP& p, int splits, int g_force_tile = 0) {
     // 256-wide tiles only when they give the chip enough work items (batch-1 out-proj is 10 x 3 of them: the 128x128
     // kernel's 114 tiles finish sooner)
     const int64_t t256 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
@@ -309,8 +314,10 @@ static int launch(hipStream_t s, const GemmP& p, int splits) {
 extern "C" int owl_gemm_nt_bf16(void* stream, int epi, const void* A, int64_t lda, int64_t a_rows, const void* W,
                                 int64_t ldw, int64_t w_rows, const float* bias, void* out, int64_t ldo,
                                 const float* resid, void* aux, int64_t ld_aux, int64_t M, int64_t N, int64_t K,
-                                float alpha, int splits, int64_t Tp) {
+                                float alpha, int splits, int64_t Tp, int tile) {
     OWL_CHECK_ARG(A && W && out, "owl_gemm_nt_bf16: null pointer");
+    OWL_CHECK_ARG(tile == 0 || tile == 128 || tile == 256 || tile == 8 || tile == 4, "owl_gemm_nt_bf16: tile must be 0 (auto), 128, 256, 8 or 4");
+    const int g_force_tile = tile;
     OWL_CHECK_ARG(K > 0 && K % BK == 0, "owl_gemm_nt_bf16: K=%lld must be a positive multiple of 64", (long long)K);
     OWL_CHECK_ARG(M > 0 && N > 0 && N % 8 == 0, "owl_gemm_nt_bf16: bad M=%lld N=%lld (N %% 8 == 0)", (long long)M, (long long)N);
     OWL_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0, "owl_gemm_nt_bf16: lda/ldw must be multiples of 8 elements");
@@ -341,19 +348,19 @@ extern "C" int owl_gemm_nt_bf16(void* stream, int epi, const void* A, int64_t ld
         if (rc <= 0) return rc;      // 1 = epilogue not handled there: fall through
     }
     switch (epi) {
-        case EPI_BIAS_BF16: return launch<EPI_BIAS_BF16>(s, p, 1);
-        case EPI_QGELU_BF16: return launch<EPI_QGELU_BF16>(s, p, 1);
-        case EPI_GELU_BF16: return launch<EPI_GELU_BF16>(s, p, 1);
-        case EPI_RESID_F32: OWL_CHECK_ARG(resid, "EPI_RESID_F32 needs resid"); return launch<EPI_RESID_F32>(s, p, 1);
-        case EPI_ACC_F32: p.resid = (const float*)out; return launch<EPI_ACC_F32>(s, p, 1);
-        case EPI_F32: return launch<EPI_F32>(s, p, 1);
-        case EPI_ATOMIC_F32: OWL_CHECK_ARG(!bias, "atomic epilogue takes no bias"); return launch<EPI_ATOMIC_F32>(s, p, splits);
-        case EPI_SLAB_F32: OWL_CHECK_ARG(!bias, "slab epilogue takes no bias"); return launch<EPI_SLAB_F32>(s, p, splits);
+        case EPI_BIAS_BF16: return launch<EPI_BIAS_BF16>(s, p, 1, g_force_tile);
+        case EPI_QGELU_BF16: return launch<EPI_QGELU_BF16>(s, p, 1, g_force_tile);
+        case EPI_GELU_BF16: return launch<EPI_GELU_BF16>(s, p, 1, g_force_tile);
+        case EPI_RESID_F32: OWL_CHECK_ARG(resid, "EPI_RESID_F32 needs resid"); return launch<EPI_RESID_F32>(s, p, 1, g_force_tile);
+        case EPI_ACC_F32: p.resid = (const float*)out; return launch<EPI_ACC_F32>(s, p, 1, g_force_tile);
+        case EPI_F32: return launch<EPI_F32>(s, p, 1, g_force_tile);
+        case EPI_ATOMIC_F32: OWL_CHECK_ARG(!bias, "atomic epilogue takes no bias"); return launch<EPI_ATOMIC_F32>(s, p, splits, g_force_tile);
+        case EPI_SLAB_F32: OWL_CHECK_ARG(!bias, "slab epilogue takes no bias"); return launch<EPI_SLAB_F32>(s, p, splits, g_force_tile);
         case EPI_TRANS_BF16:
             OWL_CHECK_ARG(Tp > 0 && Tp % 4 == 0 && N % 64 == 0, "EPI_TRANS_BF16: Tp %% 4, N %% 64");
-            return launch<EPI_TRANS_BF16>(s, p, 1);
-        case EPI_DQGELU_BF16: OWL_CHECK_ARG(aux, "EPI_DQGELU needs aux"); return launch<EPI_DQGELU_BF16>(s, p, 1);
-        case EPI_DGELU_BF16: OWL_CHECK_ARG(aux, "EPI_DGELU needs aux"); return launch<EPI_DGELU_BF16>(s, p, 1);
+            return launch<EPI_TRANS_BF16>(s, p, 1, g_force_tile);
+        case EPI_DQGELU_BF16: OWL_CHECK_ARG(aux, "EPI_DQGELU needs aux"); return launch<EPI_DQGELU_BF16>(s, p, 1, g_force_tile);
+        case EPI_DGELU_BF16: OWL_CHECK_ARG(aux, "EPI_DGELU needs aux"); return launch<EPI_DGELU_BF16>(s, p, 1, g_force_tile);
         default: owl_set_error("owl_gemm_nt_bf16: unknown epilogue %d", epi); return -1;
     }
 }
@@ -365,6 +372,12 @@ extern "C" int owl_gemm_effective_splits(int64_t K, int splits) {
     if (splits < 1) splits = 1;
     const int per = (nk + splits - 1) / splits;
     return (nk + per - 1) / per;
+}
+
+extern "C" int owl_gemm_slab_workspace_bytes(int64_t M, int64_t ldo, int64_t K, int splits, int64_t* bytes) {
+    OWL_CHECK_ARG(bytes && M > 0 && ldo > 0 && K >= BK, "owl_gemm_slab_workspace_bytes: bad arguments");
+    *bytes = (int64_t)owl_gemm_effective_splits(K, splits) * M * ldo * (int64_t)sizeof(float);
+    return 0;
 }
 
 // out[i] (+)= sum_s slab[s][i]  -- deterministic split-K reduction (accumulate = 1 adds into out)

@@ -39,8 +39,10 @@ __global__ __launch_bounds__(256) void match_cost_kernel(const float* __restrict
     for (int c = 0; c < C; c++) den += expf(s[c] - mx);
     const float4 bx = *(const float4*)(boxes + ((int64_t)b * P + p) * 4);
     for (int j = 0; j < n; j++) {
+        // a label outside [0, C) must not index sims (the reference raises IndexError at src/matcher.py:118); it gets a zero class
+        // term here and turns loss_ce into NaN in class_loss_kernel, so the failure is loud without a host sync
         const int64_t lab = labels[(int64_t)b * Nmax + j];
-        const float prob = expf(s[lab] - mx) / den;
+        const float prob = (lab >= 0 && lab < C) ? expf(s[lab] - mx) / den : 0.f;
         const float4 t = *(const float4*)(tgt + ((int64_t)b * Nmax + j) * 4);
         const float l1 = fabsf(bx.x - t.x) + fabsf(bx.y - t.y) + fabsf(bx.z - t.z) + fabsf(bx.w - t.w);
         const float g = giou_pair(bx, t, nullptr);
@@ -159,6 +161,7 @@ __global__ __launch_bounds__(512) void hungarian_kernel(const float* __restrict_
         tgt_idx[(int64_t)b * Nmax + rank] = i;
         tc[c] = labels[(int64_t)b * Nmax + i];
     }
+    for (int i = n + tid; i < Nmax; i += NT) { pred_idx[(int64_t)b * Nmax + i] = 0; tgt_idx[(int64_t)b * Nmax + i] = 0; }   // padding is defined
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -253,7 +256,8 @@ __global__ __launch_bounds__(1024) void class_loss_kernel(const float* __restric
         const int lab = (int)tc[p];
         const bool pos = lab != bg;
         const float inv_rows = pos ? 1.f / npos : 1.f / nbg;
-        float row = 0.f;
+        // (a matched / spread label outside [0, C): the reference's one_hot raises, src/losses.py:29 -> poison loss_ce instead of a silent all-zero target)
+        float row = (pos && (lab < 0 || lab >= C)) ? __builtin_nanf("") : 0.f;
         for (int c = 0; c < C; c++) {
             const float s = sims[((int64_t)b * P + p) * C + c];
             const float a = fabsf(s);
@@ -384,6 +388,30 @@ extern "C" int owl_box_pairwise(void* stream, const float* boxes1, const float* 
     OWL_CHECK_ARG(boxes1 && boxes2 && out3, "owl_box_pairwise: null pointer");
     if (N * M == 0) return 0;
     hipLaunchKernelGGL(box_pairwise_kernel, dim3((unsigned)((N * M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, boxes1, boxes2, out3, N, M);
+    OWL_LAUNCH_CHECK();
+    return 0;
+}
+
+// 9. ragged -> padded targets: one launch for the whole batch (the DETR-style per-image lists of ref main.py:77-79 /
+//    src/matcher.py:94-104 concatenated by the caller; offsets[B+1] are the image boundaries)
+__global__ __launch_bounds__(256) void pack_targets_kernel(const int64_t* __restrict__ labels_cat, const float* __restrict__ boxes_cat,
+                                                           const int* __restrict__ offsets, int64_t* labels, float* boxes, int* counts, int Nmax) {
+    const int b = blockIdx.x;
+    const int o = offsets[b], n = offsets[b + 1] - o;
+    if (threadIdx.x == 0) counts[b] = n;
+    for (int j = threadIdx.x; j < Nmax; j += blockDim.x) {
+        const bool live = j < n;
+        labels[(int64_t)b * Nmax + j] = live ? labels_cat[o + j] : 0;
+        *(float4*)(boxes + ((int64_t)b * Nmax + j) * 4) = live ? *(const float4*)(boxes_cat + (int64_t)(o + j) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+extern "C" int owl_pack_targets(void* stream, const int64_t* labels_cat, const float* boxes_cat, const int* offsets, int64_t* labels,
+                                float* boxes, int* counts, int64_t B, int64_t Nmax) {
+    OWL_CHECK_ARG(labels_cat && boxes_cat && offsets && labels && boxes && counts, "owl_pack_targets: null pointer");
+    OWL_CHECK_ARG(B >= 1 && Nmax >= 1, "owl_pack_targets: need B >= 1 and Nmax >= 1");
+    hipLaunchKernelGGL(pack_targets_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, labels_cat, boxes_cat, offsets, labels,
+                       boxes, counts, (int)Nmax);
     OWL_LAUNCH_CHECK();
     return 0;
 }

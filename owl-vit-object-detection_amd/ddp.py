@@ -4,15 +4,32 @@ The reference has no distributed code; images are indepe
 shards the batch across ranks (pure data parallel, full weight replica per GPU) and exchanges exactly one
 contiguous buffer per step: the flat gradient bucket (8 684 292 f32 = 34.7 MB for B/16, C = 10).  On ROCm
 the "nccl" backend IS RCCL; over xGMI a ring all-reduce of 34.7 MB on 8 GPUs is ~0.4 ms, far below the
-compute time of a step, so it is issued once after backward on the compute stream (no bucketing games).
+compute time of a step.
 Loss semantics: mean over images; with equal per-rank batches the mean of per-rank
-means equals the global mean, so the summed bucket is scaled by 1/world inside the fused optimizer.
-The same code runs on CPU tensors with the gloo backend (tests/test_ddp_cpu.py).
+means equals the global mean, so the summed bucket is scaled by 1/world (inside the fused optimizer, or by
+one multiply for any other optimizer).
+Two schedules:
+  * in-line (default): all-reduce -> AdamW on the compute stream right after backward;
+  * `overlap=True`: all-reduce -> AdamW -> zero the bucket run on a SIDE stream and the next step's forward
+    starts at once -- embeddings and encoder layers 0..10 are frozen (ref src/models.py:173-184), so nothing
+    before the trainable layer depends on the update; the compute stream waits for the side stream exactly
+    where the first trainable tensor is read (models.OwlViT._wait_params).  Same arithmetic, same order:
+    parameters are bitwise equal to the in-line schedule (tests/test_ddp_overlap_gpu.py).
+The same code runs on CPU tensors with the gloo backend (tests/test_ddp_cpu.py; in-line schedule).
 """
 import os
+import socket
 
 import torch
 import torch.distributed as dist
+
+
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
 
 
 def init_from_env(backend: str = None):
@@ -23,19 +40,28 @@ def init_from_env(backend: str = None):
     force = os.environ.get("OWL_FORCE_DIST", "0") == "1"      # exercise the RCCL path with a single rank (testing)
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        if "MASTER_PORT" not in os.environ:
+            if world > 1:
+                raise RuntimeError("WORLD_SIZE > 1 needs MASTER_PORT (launch with torch.distributed.run, or `bench.py --gpus N`)")
+            os.environ["MASTER_PORT"] = str(_free_port())    # single forced rank: any free port
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
+            if torch.cuda.device_count() <= local:
+                raise RuntimeError(f"LOCAL_RANK={local} but only {torch.cuda.device_count()} GPU(s) are visible")
             torch.cuda.set_device(local)
         kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 
 
+def _active(group=None) -> bool:
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or os.environ.get("OWL_FORCE_DIST", "0") == "1")
+
+
 def allreduce_flat(flat_grad: torch.Tensor, group=None) -> torch.Tensor:
     """SUM all-reduce of the flat gradient bucket, in place (single collective per step)."""
-    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or os.environ.get("OWL_FORCE_DIST", "0") == "1"):
+    if _active(group):
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
     return flat_grad
 
@@ -48,16 +74,56 @@ def broadcast_flat(flat_param: torch.Tensor, src: int = 0, group=None) -> torch.
 
 
 class DataParallel:
-    """Couples a model (anything exposing .flat_grad) with a fused optimizer (anything exposing
-    .grad_scale / .step / .zero_grad): `sync_and_step()` = all-reduce(sum) -> scale 1/world -> AdamW."""
+    """Couples a model (anything exposing .flat_grad) with an optimizer: `sync_and_step()` = all-reduce(sum) -> scale
+    1/world -> optimizer step.  A fused optimizer (anything exposing .grad_scale) folds the 1/world into its own pass; for
+    any other optimizer (e.g. torch.optim.AdamW over model.parameters()) the summed bucket is scaled explicitly."""
 
-    def __init__(self, model, optimizer, group=None):
+    def __init__(self, model, optimizer, group=None, overlap: bool = False):
         self.model, self.optimizer, self.group = model, optimizer, group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-        self.optimizer.grad_scale = 1.0 / self.world
+        self.fused = hasattr(optimizer, "grad_scale")
+        if self.fused:
+            self.optimizer.grad_scale = 1.0 / self.world
         if hasattr(model, "flat_param"):
             broadcast_flat(model.flat_param, 0, group)
+            if hasattr(model, "refresh_compute_weights"):
+                model.refresh_compute_weights(force=True)
+        self.overlap = bool(overlap) and model.flat_grad.is_cuda and self.fused
+        self.side = torch.cuda.Stream(device=model.flat_grad.device) if self.overlap else None
+        self._checked_batch = False
+
+    def check_equal_batches(self, batch_size: int):
+        """mean-of-means == global mean only for equal per-rank batches: verify once (one tiny collective)."""
+        if self.world > 1 and not self._checked_batch:
+            t = torch.tensor([batch_size, -batch_size], dtype=torch.int64, device=self.model.flat_grad.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            if int(t[0]) != -int(t[1]):
+                raise RuntimeError(f"per-rank batch sizes differ (min {-int(t[1])}, max {int(t[0])}): the data-parallel mean would be biased")
+        self._checked_batch = True
+
+    def _step(self):
+        allreduce_flat(self.model.flat_grad, self.group)
+        if not self.fused and self.world > 1:
+            self.model.flat_grad.mul_(1.0 / self.world)
+        self.optimizer.step()
 
     def sync_and_step(self):
-        allreduce_flat(self.model.flat_grad, self.group)
-        self.optimizer.step()
+        if not self.overlap:
+            self._step()
+            return
+        main = torch.cuda.current_stream()
+        self.side.wait_stream(main)                     # backward finished writing the bucket
+        with torch.cuda.stream(self.side):
+            self._step()                                # RCCL + fused AdamW are enqueued on the side stream
+            self.model.flat_grad.zero_()                # next step's zero_grad(), done where nothing races with the reads above
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+        self.model._param_event = ev                    # compute stream waits where the first trainable tensor is read
+        self.model._grad_clean = True
+
+    def finish(self):
+        """Make the current stream wait for a deferred step (before reading parameters outside the model's forward)."""
+        ev = getattr(self.model, "_param_event", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            self.model._param_event = None

@@ -33,14 +33,17 @@ class _PushPullFn(torch.autograd.Function):
                   losses, dsims, dl1, dgiou, B, P, C, tg.Nmax, crit.background_label)
         ctx.saved = (tc, dsims, dl1, dgiou, B, P, C, crit.background_label)
         crit.last = dict(target_classes=tc, pred_idx=pred_idx, tgt_idx=tgt_idx, per_image=per_image, sizes=tg.sizes)
-        return losses
+        # four scalar outputs (not one 4-vector indexed afterwards: each index would cost a zero-fill + a copy in its backward)
+        return losses[0], losses[1], losses[2], losses[3]
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g0, g1, g2, g3):
         tc, dsims, dl1, dgiou, B, P, C, bg = ctx.saved
-        out_sims = torch.empty(B, P, C, device=g.device)
-        out_boxes = torch.empty(B, P, 4, device=g.device)
-        _lib.call("owl_push_pull_loss_bwd", ops.stream(), g.contiguous().float(), tc, dsims, dl1, dgiou, out_sims, out_boxes, B, P, C, bg)
+        dev = tc.device
+        g = torch.stack([g0, g1, g2, g3]).to(device=dev, dtype=torch.float32)
+        out_sims = torch.empty(B, P, C, device=dev)
+        out_boxes = torch.empty(B, P, 4, device=dev)
+        _lib.call("owl_push_pull_loss_bwd", ops.stream(), g, tc, dsims, dl1, dgiou, out_sims, out_boxes, B, P, C, bg)
         return out_sims, out_boxes, None, None
 
 
@@ -57,7 +60,7 @@ class PushPullLoss(nn.Module):
             return target_classes
         labels = list(target_classes) if not torch.is_tensor(target_classes) else list(target_classes.unbind(0))
         boxes = list(target_boxes) if not torch.is_tensor(target_boxes) else list(target_boxes.unbind(0))
-        return PackedTargets(labels, boxes, device)
+        return PackedTargets(labels, boxes, device, self.background_label)
 
     def forward(self, predicted_classes, target_classes, predicted_boxes, target_boxes=None):
         dev = predicted_classes.device
@@ -66,5 +69,5 @@ class PushPullLoss(nn.Module):
         tg = self.pack(target_classes, target_boxes, dev)
         if len(tg.sizes) != predicted_classes.shape[0]:
             raise ValueError("batch size mismatch between predictions and targets")
-        losses = _PushPullFn.apply(predicted_classes, predicted_boxes, self, tg)
-        return {"loss_ce": losses[0], "loss_bg": losses[1], "loss_bbox": losses[2], "loss_giou": losses[3]}
+        ce, bg, l1, giou = _PushPullFn.apply(predicted_classes, predicted_boxes, self, tg)
+        return {"loss_ce": ce, "loss_bg": bg, "loss_bbox": l1, "loss_giou": giou}

@@ -11,29 +11,102 @@ import torch.nn as nn
 from . import _lib, ops
 
 
-class PackedTargets:
-    """Padded device form of the DETR-style target list: labels [B,Nmax] i64, boxes [B,Nmax,4] f32,
-    counts [B] i32 (+ the host-side sizes, known without a sync)."""
+class _PinnedRing:
+    """A few pinned host staging buffers reused round-robin.  The host enqueues a step long before the GPU runs it, so a
+    staging buffer may only be rewritten once the H2D copy that last read it has executed: each slot carries the event
+    recorded behind its copy and is waited for (normally long done) before reuse."""
 
-    def __init__(self, labels, boxes, device):
+    def __init__(self, slots: int = 4):
+        self.slots = [dict(buf=None, event=None) for _ in range(slots)]
+        self.next = 0
+
+    def take(self, nbytes: int):
+        slot = self.slots[self.next]
+        self.next = (self.next + 1) % len(self.slots)
+        if slot["event"] is not None:
+            slot["event"].synchronize()
+        if slot["buf"] is None or slot["buf"].numel() < nbytes:
+            slot["buf"] = torch.empty(max(nbytes, 4096), dtype=torch.uint8, pin_memory=True)
+        return slot
+
+
+_ring = {}
+
+
+class PackedTargets:
+    """Padded device form of the DETR-style target list (ref src/matcher.py:94-104 `targets`; ref main.py:77-79 labels / boxes):
+    labels [B,Nmax] i64, boxes [B,Nmax,4] f32, counts [B] i32 (+ the host-side sizes, known without a sync).
+
+    Host tensors are packed on the host into ONE pinned staging buffer and cross PCIe in ONE async copy; device tensors are
+    concatenated and padded by one kernel (owl_pack_targets) -- never B small copies.  `n_classes` (optional) validates the
+    label range where the labels are still host tensors (the reference raises IndexError for such a label, src/matcher.py:118);
+    for device-resident labels the kernels refuse to index with a bad label and poison loss_ce with NaN instead."""
+
+    def __init__(self, labels, boxes, device, n_classes=None):
+        labels, boxes = list(labels), list(boxes)
         sizes = [int(l.shape[0]) for l in labels]
         if any(int(b.shape[0]) != n for b, n in zip(boxes, sizes)):
             raise ValueError("labels / boxes length mismatch")
-        if min(sizes) < 1:
+        if not sizes or min(sizes) < 1:
             raise ValueError("every image needs at least one target box (the reference drops empty images, src/dataset.py:33)")
+        device = torch.device(device)
         B, Nmax = len(sizes), max(sizes)
-        self.sizes = sizes
-        self.Nmax = Nmax
-        self.labels = torch.zeros(B, Nmax, dtype=torch.int64, device=device)
-        self.boxes = torch.zeros(B, Nmax, 4, dtype=torch.float32, device=device)
-        for b, (l, bx) in enumerate(zip(labels, boxes)):
-            self.labels[b, : sizes[b]] = l.to(device=device, dtype=torch.int64)
-            self.boxes[b, : sizes[b]] = bx.to(device=device, dtype=torch.float32)
-        self.counts = torch.tensor(sizes, dtype=torch.int32).to(device, non_blocking=True)
+        self.sizes, self.Nmax = sizes, Nmax
+        nl, nb = B * Nmax * 8, B * Nmax * 16
+        on_host = all(not t.is_cuda for t in labels) and all(not t.is_cuda for t in boxes)
+        if on_host:
+            if n_classes is not None:
+                for l in labels:
+                    if l.numel() and (int(l.min()) < 0 or int(l.max()) >= n_classes):
+                        raise IndexError(f"target label outside [0, {n_classes})")
+            if device.type != "cuda":
+                self.labels = torch.zeros(B, Nmax, dtype=torch.int64)
+                self.boxes = torch.zeros(B, Nmax, 4, dtype=torch.float32)
+                for b, (l, bx) in enumerate(zip(labels, boxes)):
+                    self.labels[b, : sizes[b]] = l.to(torch.int64)
+                    self.boxes[b, : sizes[b]] = bx.to(torch.float32)
+                self.counts = torch.tensor(sizes, dtype=torch.int32)
+                return
+            slot = _ring.setdefault(device, _PinnedRing()).take(nl + nb + 4 * B)
+            host = slot["buf"]
+            host[: nl + nb + 4 * B].zero_()
+            hl = host[:nl].view(torch.int64).view(B, Nmax)
+            hb = host[nl: nl + nb].view(torch.float32).view(B, Nmax, 4)
+            hc = host[nl + nb: nl + nb + 4 * B].view(torch.int32)
+            for b, (l, bx) in enumerate(zip(labels, boxes)):
+                hl[b, : sizes[b]] = l
+                hb[b, : sizes[b]] = bx
+                hc[b] = sizes[b]
+            dev = torch.empty(nl + nb + 4 * B, dtype=torch.uint8, device=device)
+            dev.copy_(host[: nl + nb + 4 * B], non_blocking=True)
+            slot["event"] = torch.cuda.Event()
+            slot["event"].record()
+            self.labels = dev[:nl].view(torch.int64).view(B, Nmax)
+            self.boxes = dev[nl: nl + nb].view(torch.float32).view(B, Nmax, 4)
+            self.counts = dev[nl + nb:].view(torch.int32)
+            return
+        # device-resident lists (ref main.py:78-79 moves them with .to(device) before the criterion): concat + one pad kernel
+        lab_cat = torch.cat([l.to(device=device, dtype=torch.int64).reshape(-1) for l in labels])
+        box_cat = torch.cat([b.to(device=device, dtype=torch.float32).reshape(-1, 4) for b in boxes]).contiguous()
+        slot = _ring.setdefault(device, _PinnedRing()).take(4 * (B + 1))
+        ho = slot["buf"][: 4 * (B + 1)].view(torch.int32)
+        acc = 0
+        for b, n in enumerate(sizes):
+            ho[b] = acc
+            acc += n
+        ho[B] = acc
+        offsets = torch.empty(B + 1, dtype=torch.int32, device=device)
+        offsets.copy_(ho, non_blocking=True)
+        slot["event"] = torch.cuda.Event()
+        slot["event"].record()
+        self.labels = torch.empty(B, Nmax, dtype=torch.int64, device=device)
+        self.boxes = torch.empty(B, Nmax, 4, dtype=torch.float32, device=device)
+        self.counts = torch.empty(B, dtype=torch.int32, device=device)
+        _lib.call("owl_pack_targets", ops.stream(), lab_cat, box_cat, offsets, self.labels, self.boxes, self.counts, B, Nmax)
 
     @staticmethod
-    def from_lists(targets, device):
-        return PackedTargets([t["labels"] for t in targets], [t["boxes"] for t in targets], device)
+    def from_lists(targets, device, n_classes=None):
+        return PackedTargets([t["labels"] for t in targets], [t["boxes"] for t in targets], device, n_classes)
 
 
 def _pairwise(boxes1, boxes2, want):
@@ -80,8 +153,8 @@ class HungarianMatcher(nn.Module):
         sims = pred_logits.detach().contiguous().float()
         boxes = pred_boxes.detach().contiguous().float()
         costT = torch.empty(B, tg.Nmax, P, dtype=torch.float32, device=dev)
-        pred_idx = torch.zeros(B, tg.Nmax, dtype=torch.int64, device=dev)
-        tgt_idx = torch.zeros(B, tg.Nmax, dtype=torch.int64, device=dev)
+        pred_idx = torch.empty(B, tg.Nmax, dtype=torch.int64, device=dev)      # (the solver zero-fills the padding itself)
+        tgt_idx = torch.empty(B, tg.Nmax, dtype=torch.int64, device=dev)
         tc = torch.empty(B, P, dtype=torch.int64, device=dev)
         s = ops.stream()
         _lib.call("owl_match_cost", s, sims, boxes, tg.labels, tg.boxes, tg.counts, costT, B, P, C, tg.Nmax,
@@ -98,7 +171,7 @@ class HungarianMatcher(nn.Module):
     @torch.no_grad()
     def forward(self, outputs, targets):
         """Same contract as the reference: returns (target_classes, indices, idx)."""
-        tg = targets if isinstance(targets, PackedTargets) else PackedTargets.from_lists(targets, outputs["pred_logits"].device)
+        tg = targets if isinstance(targets, PackedTargets) else PackedTargets.from_lists(targets, outputs["pred_logits"].device, self.n_classes)
         tc, pred_idx, tgt_idx, _ = self.match_packed(outputs["pred_logits"], outputs["pred_boxes"], tg)
         indices = [(pred_idx[b, :n], tgt_idx[b, :n]) for b, n in enumerate(tg.sizes)]
         return tc, indices, self._get_src_permutation_idx(indices)

@@ -135,6 +135,10 @@ class OwlViT(nn.Module):
         self.box_bias = box_bias_table(cfg.grid).to(self.device_)
         self._ws = {}
         self._saved = None
+        self._bf16_version = None          # flat_param._version the bf16 compute copy was cast from
+        self._param_event = None           # ddp.DataParallel(overlap=True): the deferred all-reduce + AdamW of the previous step
+        self._grad_clean = False           # ... which also left flat_grad zeroed for this step
+        self._trainable = frozenset(order)
 
     # -- module-tree plumbing -----------------------------------------------------------------------
     def _attach(self, dotted: str, p: nn.Parameter):
@@ -175,9 +179,13 @@ class OwlViT(nn.Module):
                     g2=P_[pre + "layer_norm2.weight"], be2=P_[pre + "layer_norm2.bias"])
 
     # -- workspaces -----------------------------------------------------------------------------------
-    def _workspace(self, B: int):
-        if B in self._ws:
-            return self._ws[B]
+    def _workspace(self, B: int, train: bool = True):
+        """Activation workspace of batch size B.  Gradient-recording forwards and no-grad (eval) forwards use SEPARATE sets, so an
+        eval forward between a training forward and its backward cannot overwrite what that backward reads; two recording forwards
+        at the same batch size do share one set -- the autograd node checks `gen` and refuses to run on overwritten activations."""
+        key = B if train else ("eval", B)
+        if key in self._ws:
+            return self._ws[key]
         cfg, dev = self.cfg, self.device_
         D, I, Tp, P, Dt, C = cfg.hidden, cfg.mlp, cfg.tokens_padded, cfg.patches, cfg.text_dim, cfg.n_classes
         M, Mh = B * Tp, B * P
@@ -194,8 +202,9 @@ class OwlViT(nn.Module):
             qhat=torch.zeros(32, Dt, device=dev), qnorm=torch.zeros(32, device=dev),
             argmax=torch.zeros(Mh, C, dtype=torch.uint8, device=dev), inv_norm=torch.zeros(Mh, device=dev),
             img=torch.zeros(B, 3, cfg.image_size, cfg.image_size, dtype=bf, device=dev),
+            gen=0,
         )
-        self._ws[B] = ws
+        self._ws[key] = ws
         return ws
 
     def _layer_ws(self, B: int, i: int):
@@ -216,9 +225,32 @@ class OwlViT(nn.Module):
         self._ws[key] = L
         return L
 
-    def refresh_compute_weights(self):
-        """bf16 copies of the trainable tensors (one cast over the flat bucket)."""
-        ops.cast_bf16(self.flat_param, self.flat_bf16)
+    def refresh_compute_weights(self, force: bool = False):
+        """bf16 copies of the trainable tensors (one cast over the flat bucket) -- skipped while the copy is current: the fused AdamW
+        refreshes it in its own pass (optim.FusedAdamW.step) and leaves the version counter alone; every torch-level write to a
+        parameter (torch.optim.AdamW, copy_, load_state_dict ...) bumps the counter the views share with the bucket."""
+        v = self.flat_param._version
+        if force or self._bf16_version != v:
+            ops.cast_bf16(self.flat_param, self.flat_bf16)
+            self._bf16_version = v
+
+    def _wait_params(self):
+        """Order the compute stream behind a deferred optimizer step (ddp.DataParallel(overlap=True)): called right before the
+        first trainable tensor is read, i.e. after the frozen prefix (embeddings + encoder layers below the trainable one)."""
+        if self._param_event is not None:
+            torch.cuda.current_stream().wait_event(self._param_event)
+            self._param_event = None
+
+    def _check_trainable_set(self):
+        """The backward is built for exactly the reference's freeze rule (ref src/models.py:173-184).  The reference's rule is a
+        user-editable loop over requires_grad; here a different set would silently get no gradient (or still be updated by the
+        optimizer), so a mismatch is an error rather than a silent difference."""
+        for n, p in self._byname.items():
+            if p.requires_grad != (n in self._trainable):
+                raise RuntimeError(
+                    f"parameter `{n}` has requires_grad={p.requires_grad}, but this build's hand-written backward computes gradients for "
+                    "exactly the reference's trainable set (layers.11 / box / post_layernorm / class_predictor / queries, ref "
+                    "src/models.py:173-184); freezing or unfreezing individual tensors is not supported")
 
     # -- forward ---------------------------------------------------------------------------------------
     def _forward_impl(self, image: torch.Tensor, save: bool):
@@ -227,10 +259,13 @@ class OwlViT(nn.Module):
         B = image.shape[0]
         if tuple(image.shape[1:]) != (3, cfg.image_size, cfg.image_size):
             raise ValueError(f"image must be [B,3,{cfg.image_size},{cfg.image_size}], got {tuple(image.shape)}")
-        ws = self._workspace(B)
+        ws = self._workspace(B, train=save)
+        ws["gen"] += 1
         M, Mh = B * Tp, B * P
         P_ = self._byname
-        self.refresh_compute_weights()
+        if self._bf16_version != self.flat_param._version:
+            self._wait_params()
+            self.refresh_compute_weights()
 
         if image.dtype == torch.float32:
             ops.cast_bf16(image.contiguous(), ws["img"])
@@ -254,6 +289,8 @@ class OwlViT(nn.Module):
         pending1 = None         # ... and of its out-proj, when that layer's second LayerNorm did not store x + delta1 (frozen layers)
         tl = cfg.trainable_layer()
         for i in range(cfg.layers):
+            if i == tl:
+                self._wait_params()        # everything above ran on frozen weights only
             lw = self._layer_weights(i)
             sv = save and i >= tl          # the backward passes through this layer: keep its activations
             full = sv and i == tl          # ... and, for the trainable layer, the dW operands too
@@ -319,6 +356,7 @@ class OwlViT(nn.Module):
         """ref src/models.py:98-119: returns (pred_boxes xyxy, None, pred_sims, None)."""
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if need_grad:
+            self._check_trainable_set()
             from .autograd import OwlViTFunction
             names = list(self.flat_offsets.keys())
             boxes, sims = OwlViTFunction.apply(self, image, *[self._byname[n] for n in names])

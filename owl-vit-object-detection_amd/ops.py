@@ -11,6 +11,7 @@ EPI_BIAS_BF16, EPI_QGELU_BF16, EPI_GELU_BF16, EPI_RESID_F32, EPI_F32, EPI_ATOMIC
 EPI_TRANS_BF16, EPI_PATCH_F32, EPI_DQGELU_BF16, EPI_DGELU_BF16, EPI_ACC_F32, EPI_SLAB_F32 = 6, 7, 8, 9, 10, 11
 
 ROW_PAD = 128
+GEMM_TILE = 0      # default `tile` argument of gemm(): 0 = automatic kernel choice; tests / tools pin one kernel (128 | 256 | 8 | 4)
 
 
 def stream() -> int:
@@ -38,7 +39,7 @@ def _chk(t, dtype, name):
 
 
 def gemm(epi, A, W, out, bias=None, resid=None, aux=None, M=None, N=None, K=None, lda=None, ldw=None, ldo=None,
-         ld_aux=0, a_rows=None, w_rows=None, alpha=1.0, splits=1, Tp=0):
+         ld_aux=0, a_rows=None, w_rows=None, alpha=1.0, splits=1, Tp=0, tile=None):
     """out = epilogue(A[M,K] @ W[N,K]^T).  A/W bf16; see include/owl_hip.h for epilogues."""
     _chk(A, torch.bfloat16, "A"); _chk(W, torch.bfloat16, "W"); _chk(bias, torch.float32, "bias")
     K = K if K is not None else A.shape[-1]
@@ -52,7 +53,7 @@ def gemm(epi, A, W, out, bias=None, resid=None, aux=None, M=None, N=None, K=None
     if aux is not None and ld_aux == 0:
         ld_aux = aux.shape[-1]
     _lib.call("owl_gemm_nt_bf16", stream(), epi, A, lda, a_rows, W, ldw, w_rows, bias, out, ldo, resid, aux, ld_aux,
-              M, N, K, float(alpha), int(splits), int(Tp))
+              M, N, K, float(alpha), int(splits), int(Tp), int(GEMM_TILE if tile is None else tile))
     return out
 
 
@@ -127,15 +128,40 @@ def transpose_bf16(src, dst, R, C, ld_in=None, ld_out=None):
 
 
 # ---- backward-side wrappers ---------------------------------------------------------------------------
-def layernorm_bwd(dy, x, stats, gamma, dres, dx, dgamma, dbeta, rows, D, dx_bf16=None):
+_partials = {}
+
+
+def rowreduce_workspace(groups, rows_per_group, C, device):
+    """f32 partial-sum scratch for the deterministic row reductions (owl_rowreduce_workspace_bytes)."""
+    nbytes = torch.zeros(1, dtype=torch.int64)
+    _lib.call("owl_rowreduce_workspace_bytes", int(groups), int(rows_per_group), int(C), nbytes)
+    return torch.empty(int(nbytes.item()) // 4, dtype=torch.float32, device=device)
+
+
+def _part(partials, rows, C, device):
+    """The caller's scratch, or (stand-alone use: tests, tools) a cached per-device buffer grown on demand."""
+    if partials is not None:
+        return partials
+    need = ((int(rows) + 63) // 64 + 1) * 5 * max(int(C), 4)
+    buf = _partials.get(device)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(need, dtype=torch.float32, device=device)
+        _partials[device] = buf
+    return buf
+
+
+def layernorm_bwd(dy, x, stats, gamma, dres, dx, dgamma, dbeta, rows, D, dx_bf16=None, partials=None):
     """dx (f32) = LN backward (+ dres); optionally also its bf16 copy `dx_bf16` (the operand of the next dX GEMM)."""
     _chk(dx_bf16, torch.bfloat16, "dx_bf16")
+    part = _part(partials, rows, D, x.device) if dgamma is not None else None
     _lib.call("owl_layernorm_bwd", stream(), dy, 1 if dy.dtype == torch.bfloat16 else 0, x, stats, gamma, dres, dx,
-              dgamma, dbeta, rows, D, dx_bf16)
+              dgamma, dbeta, rows, D, dx_bf16, part, part.numel() if part is not None else 0)
 
 
-def merge_ln_bwd(dfeats, x, cls_ln, st1, st2, g1, b1, g2, dx, dcls_ws, dg1, db1, dg2, db2, B, P, Tp, D):
-    _lib.call("owl_merge_ln_bwd", stream(), dfeats, x, cls_ln, st1, st2, g1, b1, g2, dx, dcls_ws, dg1, db1, dg2, db2, B, P, Tp, D)
+def merge_ln_bwd(dfeats, x, cls_ln, st1, st2, g1, b1, g2, dx, dcls_ws, dg1, db1, dg2, db2, B, P, Tp, D, partials=None):
+    part = partials if partials is not None else _part(None, B * ((P + 63) // 64) * 64, D, x.device)
+    _lib.call("owl_merge_ln_bwd", stream(), dfeats, x, cls_ln, st1, st2, g1, b1, g2, dx, dcls_ws, dg1, db1, dg2, db2, B, P, Tp, D,
+              part, part.numel())
 
 
 def class_sims_bwd(dsims, sims, argmax, inv_norm, e, qhat32, de, g32, e_bf16, rows, Dt, C):
@@ -146,13 +172,16 @@ def box_final_bwd(dboxes, sig, h1, u1, w2, du1, partials, dw2_db2, rows, D):
     _lib.call("owl_box_final_bwd", stream(), dboxes, sig, h1, u1, w2, du1, partials, dw2_db2, rows, D)
 
 
-def transpose_colsum(src, dst, colsum, R, C, ld_in=None, ld_out=None):
+def transpose_colsum(src, dst, colsum, R, C, ld_in=None, ld_out=None, partials=None):
+    part = _part(partials, R, C, src.device) if colsum is not None else None
     _lib.call("owl_transpose_colsum_bf16", stream(), src, ld_in if ld_in is not None else src.shape[-1], dst,
-              (ld_out if ld_out is not None else dst.shape[-1]) if dst is not None else 0, colsum, R, C)
+              (ld_out if ld_out is not None else dst.shape[-1]) if dst is not None else 0, colsum, R, C,
+              part, part.numel() if part is not None else 0)
 
 
-def colsum_f32(src, colsum, R, C):
-    _lib.call("owl_colsum_f32", stream(), src, colsum, R, C)
+def colsum_f32(src, colsum, R, C, partials=None):
+    part = _part(partials, R, C, src.device)
+    _lib.call("owl_colsum_f32", stream(), src, colsum, R, C, part, part.numel())
 
 
 def attention_bwd(qkv, dO, O, lse, dvec, dqkv, B, H, T, Tp, scale):
@@ -198,6 +227,7 @@ def gemm_tn_slab(dy, x, slab, rows, n_out, n_in, splits):
     return int(used.item())
 
 
-def colsum_bf16(src, colsum, rows, cols):
+def colsum_bf16(src, colsum, rows, cols, partials=None):
     _chk(src, torch.bfloat16, "src"); _chk(colsum, torch.float32, "colsum")
-    _lib.call("owl_colsum_bf16", stream(), src, src.shape[-1], colsum, rows, cols)
+    part = _part(partials, rows, cols, src.device)
+    _lib.call("owl_colsum_bf16", stream(), src, src.shape[-1], colsum, rows, cols, part, part.numel())

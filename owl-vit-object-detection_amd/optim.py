@@ -23,12 +23,16 @@ class FusedAdamW:
 
     def zero_grad(self, set_to_none: bool = False):
         _attach_grads(self.model)
+        if getattr(self.model, "_grad_clean", False):
+            return                       # a deferred step (ddp.DataParallel(overlap=True)) already zeroed the bucket on its stream
+        self.model._wait_params()
         self.model.flat_grad.zero_()
 
     @torch.no_grad()
     def step(self):
         m = self.model
         _attach_grads(m)
+        m._grad_clean = False
         self.step_count += 1
         _lib.call("owl_adamw_step", ops.stream(), m.flat_param, m.flat_grad, self.exp_avg, self.exp_avg_sq, m.flat_bf16,
                   m.flat_numel, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count,

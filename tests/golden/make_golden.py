@@ -481,6 +481,49 @@ def lsap():
     print("lsap cases:", len(res) // 3)
 
 
+def f9():
+    """F9 -- the input contract: reference `coco_to_model_input` / `model_output_to_image`
+    (src/train_util.py:4-24 -> BoxUtil.box_convert / scale_bounding_box, src/util.py:83-93,123-129) run on DataLoader-shaped
+    inputs: boxes [1,n,4] f32 absolute COCO xywh, metadata = default_collate of {"width": int, "height": int}.
+    `src/util.py` imports tensorboard / torchvision.io / torchvision.utils at module level (absent here): those are stubbed with
+    empty placeholders (never called on this path).  `torchvision.ops.box_convert` IS called; torchvision is a third-party
+    dependency absent from /root/reference, so its published xywh->xyxy rule (x, y, x+w, y+h via unbind/stack,
+    torchvision/ops/_box_convert.py `_box_xywh_to_xyxy`) is what the stub restates -- that one line is "parity unpinned" for
+    torchvision; the division by (width, height), its in-place behaviour, dtypes and shapes are the reference's own code."""
+    tb = types.ModuleType("torch.utils.tensorboard"); tb.SummaryWriter = object
+    sys.modules.setdefault("torch.utils.tensorboard", tb)
+    tvio = types.ModuleType("torchvision.io"); tvio.read_image = None
+    tvu = types.ModuleType("torchvision.utils"); tvu.draw_bounding_boxes = None
+    sys.modules["torchvision.io"] = tvio; sys.modules["torchvision.utils"] = tvu
+    tv.io = tvio; tv.utils = tvu
+
+    def _box_convert(boxes, in_fmt, out_fmt):
+        assert (in_fmt, out_fmt) == ("xywh", "xyxy")
+        x, y, w, h = boxes.unbind(-1)
+        return torch.stack([x, y, x + w, y + h], dim=-1)
+    tv_ops.box_convert = _box_convert
+    from src.train_util import coco_to_model_input as ref_c2m, model_output_to_image as ref_m2i
+    from torch.utils.data import default_collate
+    from owl_vit_object_detection_amd import rng
+    res = {}
+    sizes = [(640, 480), (500, 375), (333, 500), (1, 1), (4032, 3024), (427, 640)]
+    for k, (w, h) in enumerate(sizes):
+        n = 1 + k * 3
+        x0 = rng.uniform(17, f"f9/{k}", n, 0) * w * 0.7; y0 = rng.uniform(17, f"f9/{k}", n, 1) * h * 0.7
+        bw = 1.0 + rng.uniform(17, f"f9/{k}", n, 2) * w * 0.3; bh = 1.0 + rng.uniform(17, f"f9/{k}", n, 3) * h * 0.3
+        xywh = np.round(np.stack([x0, y0, bw, bh], 1), 2).astype(np.float32)          # COCO annotations carry 2 decimals
+        boxes = default_collate([torch.tensor(xywh.tolist())])                        # [1, n, 4] f32, as the DataLoader yields
+        meta = default_collate([{"width": w, "height": h}])                           # {"width": tensor([w]), "height": tensor([h])}
+        inp = boxes.clone()
+        out = ref_c2m(inp, meta)
+        assert torch.equal(inp, boxes)                                                # the reference does not touch its input here
+        back = ref_m2i(out.clone(), meta)
+        res[f"c{k}/xywh"] = boxes.numpy(); res[f"c{k}/wh"] = np.array([w, h], np.int64)
+        res[f"c{k}/xyxy_norm"] = out.numpy(); res[f"c{k}/back"] = back.numpy()
+    np.savez_compressed(os.path.join(HERE, "f9_input_contract.npz"), **res)
+    print("f9 cases:", len(sizes))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["f1", "f3", "f5", "lsap", "f2", "f4"]
     for w in which:

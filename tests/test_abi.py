@@ -20,7 +20,7 @@ def test_header_parses():
     protos = _lib.parse_header()
     assert "owl_gemm_nt_bf16" in protos and "owl_last_error" in protos
     ret, args = protos["owl_gemm_nt_bf16"]
-    assert ret == "int" and args[0] == ("void*", "stream") and len(args) == 20
+    assert ret == "int" and args[0] == ("void*", "stream") and len(args) == 21 and args[-1] == ("int", "tile")
     for name, (ret, args) in protos.items():
         for ty, _ in args:
             assert ty in _lib._CTYPES, (name, ty)
@@ -33,10 +33,28 @@ def test_library_exports_every_declared_symbol(built):
     assert built.owl_abi_version() >= 1
 
 
+def test_no_process_global_setters_in_the_product_abi(built):
+    """re-entrant, no global mutable state.  The tuning switches (kernel-choice override, store skipping,
+    attention debug flags) must be neither declared in the product header nor exported by the default build."""
+    protos = _lib.parse_header()
+    banned = ("owl_gemm_set_tile", "owl_gemm_set_persistent", "owl_gemm_debug_nostore", "owl_gemm_debug_slots", "owl_attention_debug")
+    for name in banned:
+        assert name not in protos, name
+    assert not any("_set_" in n or "_debug" in n for n in protos), [n for n in protos if "_set_" in n or "_debug" in n]
+    if os.environ.get("OWL_TUNING", "0") != "1":
+        lib = ctypes.CDLL(_lib.LIB_PATH)
+        for name in banned:
+            assert not hasattr(lib, name), f"{name} exported by the default build"
+    # every op that needs device scratch has a size query
+    for q in ("owl_postprocess_workspace", "owl_box_final_bwd_blocks", "owl_gemm_effective_splits", "owl_gemm_tn_slab_workspace_bytes",
+              "owl_attention_bwd_workspace_bytes", "owl_gemm_slab_workspace_bytes"):
+        assert q in protos, q
+
+
 def test_argument_validation_sets_error_without_gpu(built):
     # argument checks run before any HIP call: safe without a device
     with pytest.raises(_lib.OwlLibError, match="null pointer"):
-        _lib.call("owl_gemm_nt_bf16", None, 0, None, 0, 0, None, 0, 0, None, None, 0, None, None, 0, 1, 4, 64, 1.0, 1, 0)
+        _lib.call("owl_gemm_nt_bf16", None, 0, None, 0, 0, None, 0, 0, None, None, 0, None, None, 0, 1, 4, 64, 1.0, 1, 0, 0)
     assert "null pointer" in _lib.last_error()
 
 

@@ -1,0 +1,134 @@
+"""-m gpu: contracts of the coarse autograd edge and the optimizer schedules.
+
+* saved activations live in per-batch-size workspaces: an eval forward between a training forward and its backward must not
+  disturb the gradients; two recording forwards followed by one backward must fail loudly, not silently;
+* the trainable set is fixed by the reference's freeze rule (ref src/models.py:173-184): editing requires_grad raises;
+* target labels outside [0, C): IndexError on host tensors (like the reference), NaN loss_ce on device tensors;
+* ddp.DataParallel(overlap=True) (all-reduce + AdamW on a side stream under the next step's frozen prefix) gives the very bits of
+  the in-line schedule; a non-fused optimizer gets the 1/world scale explicitly.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from owl_vit_object_detection_amd import ddp, synth, weights  # noqa: E402
+from owl_vit_object_detection_amd.config import get_config  # noqa: E402
+from owl_vit_object_detection_amd.losses import PushPullLoss  # noqa: E402
+from owl_vit_object_detection_amd.matcher import PackedTargets  # noqa: E402
+from owl_vit_object_detection_amd.models import OwlViT  # noqa: E402
+from owl_vit_object_detection_amd.optim import FusedAdamW  # noqa: E402
+
+DEV = "cuda"
+
+
+def _setup(cname="tiny", B=2, seed=1234):
+    cfg = get_config(cname)
+    model = OwlViT(cfg, weights.make_weights(cfg), DEV)
+    img = torch.from_numpy(synth.make_images(cfg, B, seed=seed)).to(DEV)
+    labels, boxes = synth.make_targets(cfg, B, max_boxes=5, seed=seed)
+    lab = [torch.from_numpy(l).to(DEV) for l in labels]; box = [torch.from_numpy(b).to(DEV) for b in boxes]
+    return cfg, model, img, lab, box, PushPullLoss(cfg.n_classes, None)
+
+
+def _loss(crit, ps, lab, pb, box):
+    l = crit(ps, lab, pb, box)
+    return l["loss_ce"] + l["loss_bg"] + l["loss_bbox"] + l["loss_giou"]
+
+
+def test_eval_forward_between_forward_and_backward_does_not_disturb_gradients():
+    cfg, model, img, lab, box, crit = _setup()
+    model.flat_grad.zero_()
+    pb, _, ps, _ = model(img)
+    _loss(crit, ps, lab, pb, box).backward()
+    ref = model.flat_grad.clone()
+    model.flat_grad.zero_()
+    pb, _, ps, _ = model(img)
+    other = torch.from_numpy(synth.make_images(cfg, img.shape[0], seed=99)).to(DEV)
+    with torch.no_grad():
+        model(other)                          # same batch size, different pixels: uses the eval workspace
+    _loss(crit, ps, lab, pb, box).backward()
+    assert torch.equal(model.flat_grad, ref)
+
+
+def test_second_recording_forward_before_backward_raises():
+    cfg, model, img, lab, box, crit = _setup()
+    pb1, _, ps1, _ = model(img)
+    pb2, _, ps2, _ = model(img)
+    l1, l2 = _loss(crit, ps1, lab, pb1, box), _loss(crit, ps2, lab, pb2, box)
+    with pytest.raises(RuntimeError, match="overwritten"):
+        (l1 + l2).backward()
+
+
+def test_editing_the_trainable_set_raises():
+    cfg, model, img, lab, box, crit = _setup()
+    model.p("queries").requires_grad_(False)
+    with pytest.raises(RuntimeError, match="trainable set"):
+        model(img)
+    model.p("queries").requires_grad_(True)
+    model.p("backbone.pre_layernorm.weight").requires_grad_(True)
+    with pytest.raises(RuntimeError, match="trainable set"):
+        model(img)
+
+
+def test_out_of_range_labels_fail_loudly():
+    cfg, model, img, lab, box, crit = _setup()
+    bad_host = [l.cpu().clone() for l in lab]
+    bad_host[0][0] = cfg.n_classes
+    with pytest.raises(IndexError):
+        PackedTargets(bad_host, [b.cpu() for b in box], DEV, cfg.n_classes)
+    with torch.no_grad():
+        pb, _, ps, _ = model(img)
+    bad_dev = [l.clone() for l in lab]
+    bad_dev[1][0] = cfg.n_classes + 3
+    losses = crit(ps, bad_dev, pb, box)
+    assert bool(torch.isnan(losses["loss_ce"]))           # loud, no out-of-bounds read, no host sync
+    good = crit(ps, lab, pb, box)
+    assert all(bool(torch.isfinite(v)) for v in good.values())
+
+
+def test_host_and_device_target_lists_pack_identically():
+    cfg, model, img, lab, box, crit = _setup(B=3)
+    a = PackedTargets(lab, box, DEV, cfg.n_classes)                                   # device lists: cat + one pad kernel
+    b = PackedTargets([l.cpu() for l in lab], [x.cpu() for x in box], DEV, cfg.n_classes)   # host lists: one pinned copy
+    assert torch.equal(a.labels, b.labels) and torch.equal(a.boxes, b.boxes) and torch.equal(a.counts, b.counts)
+    assert a.sizes == b.sizes and a.Nmax == b.Nmax
+
+
+@pytest.mark.parametrize("cname,B", [("tiny", 2), ("small", 2)])
+def test_overlapped_optimizer_schedule_is_bitwise_the_inline_schedule(cname, B):
+    def train(overlap, steps=4):
+        cfg, model, img, lab, box, crit = _setup(cname, B)
+        opt = FusedAdamW(model, lr=1e-3, weight_decay=0.1)
+        dp = ddp.DataParallel(model, opt, overlap=overlap)
+        assert dp.overlap == overlap
+        hist = []
+        for _ in range(steps):
+            opt.zero_grad()
+            pb, _, ps, _ = model(img)
+            loss = _loss(crit, ps, lab, pb, box)
+            loss.backward()
+            dp.sync_and_step()
+            hist.append(loss.detach())
+        dp.finish()
+        torch.cuda.synchronize()
+        return model.flat_param.clone(), torch.stack(hist).cpu(), opt.exp_avg.clone()
+
+    p0, h0, m0 = train(False)
+    p1, h1, m1 = train(True)
+    assert torch.equal(h0, h1) and torch.equal(m0, m1) and torch.equal(p0, p1)
+    assert float(h0[-1]) < float(h0[0])
+
+
+def test_data_parallel_scales_for_a_non_fused_optimizer(monkeypatch):
+    """With torch.optim.AdamW (no grad_scale attribute) the summed bucket must be averaged explicitly."""
+    cfg, model, img, lab, box, crit = _setup()
+    opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=0.0)
+    dp = ddp.DataParallel(model, opt)
+    assert not dp.fused and dp.world == 1
+    dp.world = 4                                                     # pretend: 4 ranks already summed into the bucket
+    monkeypatch.setattr(ddp, "allreduce_flat", lambda g, group=None: g)
+    model.flat_grad.fill_(8.0)
+    dp.sync_and_step()
+    assert float(model.flat_grad[0]) == 2.0

@@ -1,0 +1,121 @@
+"""-m gpu: the RCCL leg of the data-parallel path and the bench launcher contract.
+
+* `bench.py --gpus N` launches N ranks itself; on a box with fewer GPUs it must exit non-zero with a clear message
+  instead of quietly benchmarking one GPU;
+* one forced rank over the real `nccl` (= RCCL) backend: the bench line carries rccl_ranks / backend / allreduce_ms;
+* two ranks over RCCL (skipped with fewer than 2 GPUs): identical replicas after a step, and the data-parallel identity
+  against the single-process global batch.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env(**kw):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "OWL_FORCE_DIST"):
+        env.pop(k, None)
+    env.update(kw)
+    return env
+
+
+def _last_json(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert lines, stdout[-2000:]
+    return json.loads(lines[-1])
+
+
+@pytest.mark.timeout(600)
+def test_bench_refuses_more_gpus_than_visible():
+    n = torch.cuda.device_count()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1), "--steps", "1", "--warmup", "0",
+                        "--arch", "tiny", "--batch", "2", "--no-cpu-baseline"], capture_output=True, text=True, env=_env(), timeout=500)
+    assert r.returncode != 0
+    assert f"only {n} GPU" in r.stderr and "n_gpus" not in r.stdout
+
+
+@pytest.mark.timeout(900)
+def test_bench_single_forced_rccl_rank_reports_the_collective():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--arch", "small",
+                        "--batch", "4", "--no-cpu-baseline"], capture_output=True, text=True, env=_env(OWL_FORCE_DIST="1"), timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _last_json(r.stdout)
+    assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and out["backend"].startswith("nccl")
+    assert out["allreduce_ms"] > 0 and out["allreduce_bytes"] > 0 and out["value"] > 0
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+from owl_vit_object_detection_amd import ddp, synth, weights
+from owl_vit_object_detection_amd.config import get_config
+from owl_vit_object_detection_amd.losses import PushPullLoss
+from owl_vit_object_detection_amd.models import OwlViT
+from owl_vit_object_detection_amd.optim import FusedAdamW
+rank, world, local = ddp.init_from_env("nccl")
+dev = torch.device("cuda", local)
+cfg = get_config("small")
+model = OwlViT(cfg, weights.make_weights(cfg), dev)
+if rank == 1:
+    model.flat_param.add_(0.5)                    # the broadcast from rank 0 must undo this
+opt = FusedAdamW(model, lr=1e-3, weight_decay=0.1)
+dp = ddp.DataParallel(model, opt, overlap={overlap})
+per = 2
+dp.check_equal_batches(per)
+img = torch.from_numpy(synth.make_images(cfg, per, first=rank * per)).to(dev)
+labels, boxes = synth.make_targets(cfg, per, first=rank * per, max_boxes=5)
+crit = PushPullLoss(cfg.n_classes, None)
+opt.zero_grad()
+pb, _, ps, _ = model(img)
+l = crit(ps, [torch.from_numpy(x).to(dev) for x in labels], pb, [torch.from_numpy(x).to(dev) for x in boxes])
+(l["loss_ce"] + l["loss_bg"] + l["loss_bbox"] + l["loss_giou"]).backward()
+local_grad = model.flat_grad.clone()
+dp.sync_and_step(); dp.finish(); torch.cuda.synchronize()
+np.savez(os.path.join({out!r}, f"rank{{rank}}.npz"), local=local_grad.cpu().numpy(), param=model.flat_param.cpu().numpy())
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("overlap", [False, True])
+def test_two_rank_rccl_step(tmp_path, overlap):
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (the driver's 8-GPU node); the same code runs on 2 gloo ranks in tests/test_ddp_cpu.py")
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT, out=str(tmp_path), overlap=overlap))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), str(script)], capture_output=True, text=True, env=_env(), timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    np.testing.assert_array_equal(r0["param"], r1["param"])            # identical replicas after the step
+    # data-parallel identity: mean of the per-rank gradients == gradient of the 4-image global batch on one GPU
+    from owl_vit_object_detection_amd import synth, weights
+    from owl_vit_object_detection_amd.config import get_config
+    from owl_vit_object_detection_amd.losses import PushPullLoss
+    from owl_vit_object_detection_amd.models import OwlViT
+    cfg = get_config("small")
+    model = OwlViT(cfg, weights.make_weights(cfg), "cuda")
+    img = torch.from_numpy(synth.make_images(cfg, 4)).cuda()
+    labels, boxes = synth.make_targets(cfg, 4, max_boxes=5)
+    crit = PushPullLoss(cfg.n_classes, None)
+    pb, _, ps, _ = model(img)
+    l = crit(ps, [torch.from_numpy(x).cuda() for x in labels], pb, [torch.from_numpy(x).cuda() for x in boxes])
+    (l["loss_ce"] + l["loss_bg"] + l["loss_bbox"] + l["loss_giou"]).backward()
+    glob = model.flat_grad.cpu().numpy()
+    mean = 0.5 * (r0["local"] + r1["local"])
+    np.testing.assert_allclose(mean, glob, rtol=1e-3, atol=1e-5 * float(np.abs(glob).max()))

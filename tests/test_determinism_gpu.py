@@ -67,11 +67,11 @@ def test_gemm_pingpong_matches_tile256_bitwise(N, K, epi):
     W = (torch.randn(N, K, device=DEV) * 0.05).bfloat16(); bias = torch.randn(N, device=DEV)
 
     def run(tile):
-        _lib.call("owl_gemm_set_tile", tile)
+        ops.GEMM_TILE = tile
         out = torch.zeros(ops.pad_rows(M), N, device=DEV, dtype=torch.bfloat16)
         ops.gemm(epi, A, W, out, bias=bias, M=M)
         torch.cuda.synchronize()
-        _lib.call("owl_gemm_set_tile", 0)
+        ops.GEMM_TILE = 0
         return out
 
     ref = run(256)
@@ -127,3 +127,35 @@ def test_attention_fwd_vrow_bitwise_repeatable():
     for _ in range(30):
         got = run()
         assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+
+
+@pytest.mark.parametrize("arch,B", [("owlvit-base-patch16", 4), ("tiny-l14", 3)])
+def test_flat_grad_bitwise_repeatable_after_a_full_step(arch, B):
+    """Every gradient of the bucket -- weight gradients (split-K slabs), bias gradients and LayerNorm-affine gradients (row
+    reductions through fixed-order partial sums, no f32 atomics) -- comes out with identical bits on every run of the same step."""
+    from owl_vit_object_detection_amd import synth, weights
+    from owl_vit_object_detection_amd.config import get_config
+    from owl_vit_object_detection_amd.losses import PushPullLoss
+    from owl_vit_object_detection_amd.models import OwlViT
+    cfg = get_config(arch)
+    model = OwlViT(cfg, weights.make_weights(cfg), DEV)
+    img = torch.from_numpy(synth.make_images(cfg, B)).to(DEV)
+    labels, boxes = synth.make_targets(cfg, B, max_boxes=8)
+    lab = [torch.from_numpy(l).to(DEV) for l in labels]; box = [torch.from_numpy(b).to(DEV) for b in boxes]
+    crit = PushPullLoss(cfg.n_classes, synth.class_scales(cfg, labels))
+
+    def run():
+        model.flat_grad.zero_()
+        pb, _, ps, _ = model(img)
+        l = crit(ps, lab, pb, box)
+        (l["loss_ce"] + l["loss_bg"] + l["loss_bbox"] + l["loss_giou"]).backward()
+        torch.cuda.synchronize()
+        return model.flat_grad.clone(), pb.detach().clone(), ps.detach().clone()
+
+    ref = run()
+    assert float(ref[0].abs().max()) > 0
+    for _ in range(6):
+        got = run()
+        assert torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2])
+        bad = torch.nonzero(got[0] != ref[0]).flatten()
+        assert bad.numel() == 0, f"{bad.numel()} gradient elements differ run to run, first at {int(bad[0])}"

@@ -15,6 +15,11 @@ from owl_vit_object_detection_amd.config import get_config  # noqa: E402
 from owl_vit_object_detection_amd.models import OwlViT  # noqa: E402
 
 DEV = "cuda"
+# north-star bf16 bar: 1e-2.  Asserted at ~2x the error measured on the final build (tools/errstudy.py: full-size B/16 boxes 2.0e-3 /
+# sims 9.1e-4, L/14 1.8e-3 / 7.3e-4) so that a regression which doubles the forward error fails.
+TOL_BOXES, TOL_SIMS = 4e-3, 2e-3
+# end-to-end gradient sanity bands of the full-size fixtures (the strict all-element check is the backward-chain test)
+REL_NORM, MIN_COS = 0.3, 0.9
 
 
 def _maxerr(a, b):
@@ -35,7 +40,7 @@ def test_forward_matches_oracle(cname, B):
     rb, rs = O.model_forward(cfg, w, torch.from_numpy(img))
     eb, es = _maxerr(pb, rb), _maxerr(ps, rs)
     print(f"{cname} B={B}: max|d boxes|={eb:.3e} max|d sims|={es:.3e}")
-    assert eb < 1e-2 and es < 1e-2
+    assert eb < TOL_BOXES and es < TOL_SIMS, (eb, es)
 
 
 def test_forward_matches_reference_fixture_f1(golden_dir):
@@ -45,8 +50,9 @@ def test_forward_matches_reference_fixture_f1(golden_dir):
     img = torch.from_numpy(synth.make_images(cfg, 1)).to(DEV)
     with torch.no_grad():
         pb, _, ps, _ = model(img)
-    assert _maxerr(pb, torch.from_numpy(g["pred_boxes"])) < 1e-2
-    assert _maxerr(ps, torch.from_numpy(g["pred_sims"])) < 1e-2
+    eb, es = _maxerr(pb, torch.from_numpy(g["pred_boxes"])), _maxerr(ps, torch.from_numpy(g["pred_sims"]))
+    print(f"tiny vs reference fixture F1: max|d boxes|={eb:.3e} max|d sims|={es:.3e}")
+    assert eb < TOL_BOXES and es < TOL_SIMS, (eb, es)
 
 
 def test_forward_b16_matches_reference_fixture_f2(golden_dir):
@@ -59,7 +65,7 @@ def test_forward_b16_matches_reference_fixture_f2(golden_dir):
         pb, _, ps, _ = model(img)
     eb, es = _maxerr(pb, torch.from_numpy(g["pred_boxes"])), _maxerr(ps, torch.from_numpy(g["pred_sims"]))
     print(f"B/16 vs reference fixture: max|d boxes|={eb:.3e} max|d sims|={es:.3e}")
-    assert eb < 1e-2 and es < 1e-2
+    assert eb < TOL_BOXES and es < TOL_SIMS, (eb, es)
     # batch invariance: image 0 inside a batch of 8 gives the same outputs
     imgs = torch.from_numpy(synth.make_images(cfg, 8)).to(DEV)
     with torch.no_grad():
@@ -83,7 +89,7 @@ def test_forward_b32_default_arch_matches_oracle():
     rb, rs = O.model_forward(cfg, w, torch.from_numpy(img))
     eb, es = _maxerr(pb, rb), _maxerr(ps, rs)
     print(f"B/32: max|d boxes|={eb:.3e} max|d sims|={es:.3e}")
-    assert eb < 1e-2 and es < 1e-2
+    assert eb < TOL_BOXES and es < TOL_SIMS, (eb, es)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -168,7 +174,9 @@ def test_train_step_matches_oracle(cname, B):
     w = {k: torch.from_numpy(v) for k, v in Wnp.items()}
     (rb, rs), lo, gref = O.train_step(cfg, w, torch.from_numpy(img), [torch.from_numpy(l) for l in labels],
                                       [torch.from_numpy(b) for b in boxes], torch.from_numpy(scales))
-    assert _maxerr(pb, rb) < 1e-2 and _maxerr(ps, rs) < 1e-2
+    eb, es = _maxerr(pb, rb), _maxerr(ps, rs)
+    print(f"train step {cname} B={B}: max|d boxes|={eb:.3e} max|d sims|={es:.3e}")
+    assert eb < TOL_BOXES and es < TOL_SIMS, (eb, es)
     # matched loss within the bf16 bar (relative for the large class terms)
     for k in LOSS_KEYS:
         assert lg[k] == pytest.approx(float(lo[k]), rel=2e-2, abs=1e-2), (k, lg[k], float(lo[k]))
@@ -269,12 +277,13 @@ def test_train_step_b16_matches_reference_fixture_f2(golden_dir):
     print("B/16 losses", lg, "ref", {k: float(g[k]) for k in LOSS_KEYS}, "target_classes agreement", same)
     assert same == 1.0
     eb, es = _maxerr(pb, torch.from_numpy(g["pred_boxes"])), _maxerr(ps, torch.from_numpy(g["pred_sims"]))
-    assert eb < 1e-2 and es < 1e-2
+    assert eb < TOL_BOXES and es < TOL_SIMS, (eb, es)
     bound = _class_loss_bound(cfg, g, es)
     for k in LOSS_KEYS:
         assert abs(lg[k] - float(g[k])) <= max(2e-2 * abs(float(g[k])), 1e-2, bound.get(k, 0.0)), (k, lg[k], float(g[k]), bound)
     near_tie = _near_tie(g, boxes)
     big = max(float(g["gradnorm/" + n]) for n in grads)
+    worst_norm, worst_cos = 0.0, 1.0
     for n, gr in grads.items():
         ref_norm = float(g["gradnorm/" + n])
         if ref_norm < 1e-5:
@@ -282,14 +291,17 @@ def test_train_step_b16_matches_reference_fixture_f2(golden_dir):
             continue
         if near_tie and n.startswith("box_head"):
             continue
-        assert float(gr.double().norm()) == pytest.approx(ref_norm, rel=0.3), n
+        worst_norm = max(worst_norm, abs(float(gr.double().norm()) / ref_norm - 1.0))
+        assert float(gr.double().norm()) == pytest.approx(ref_norm, rel=REL_NORM), n
         if ref_norm < 1e-2 * big:
             continue      # q/k projections: gradients are differences of near-equal terms (near-uniform softmax at random
                           # init), 100x smaller than the rest -- a 64-element sample of them is bf16 noise; norm checked above
         head = torch.from_numpy(g["gradhead/" + n])
         cos = float((gr.reshape(-1)[:64] * head).sum() / (gr.reshape(-1)[:64].norm() * head.norm() + 1e-20))
-        assert cos > 0.9, (n, cos)    # 64-element sample of an end-to-end gradient (loss-amplified bf16 noise);
+        worst_cos = min(worst_cos, cos)
+        assert cos > MIN_COS, (n, cos)    # 64-element sample of an end-to-end gradient (loss-amplified bf16 noise);
                                       # the strict all-element check is test_backward_chain_...[owlvit-base-patch16-1]
+    print(f"B/16 end-to-end gradients vs F2: worst |norm ratio - 1| = {worst_norm:.3e}, worst 64-element cos = {worst_cos:.5f}")
 
 
 def test_l14_train_step_matches_reference_fixture_f4(golden_dir):
@@ -307,7 +319,7 @@ def test_l14_train_step_matches_reference_fixture_f4(golden_dir):
     same = float((crit.last["target_classes"][0].cpu() == torch.from_numpy(g["target_classes"])).float().mean())
     print(f"L/14 vs reference fixture: max|d boxes|={eb:.3e} max|d sims|={es:.3e}; losses", lg,
           "ref", {k: float(g[k]) for k in LOSS_KEYS}, "target agreement", same)
-    assert eb < 1e-2 and es < 1e-2
+    assert eb < TOL_BOXES and es < TOL_SIMS, (eb, es)
     bound = _class_loss_bound(cfg, g, es)
     ref_l, n_swaps, n_rows = _reference_losses_for_decisions(cfg, g, labels, boxes, crit, eb, es)
     print("near-tie decisions differing from the fixture: assignment swaps", n_swaps, "label rows", n_rows,
@@ -317,9 +329,12 @@ def test_l14_train_step_matches_reference_fixture_f4(golden_dir):
         assert abs(lg[k] - ref) <= max(2e-2 * abs(ref), 1e-2, bound.get(k, 0.0)), (k, lg[k], ref, bound)
     near_tie = _near_tie(g, boxes)      # (here row 610: x1 = 0.1997 vs 0.1996)
     big = max(float(g["gradnorm/" + n]) for n in grads)
+    worst_norm = 0.0
     for n, gr in grads.items():
         ref_norm = float(g["gradnorm/" + n])
         if ref_norm < 1e-2 * big or (near_tie and n.startswith("box_head")):
             continue
-        assert float(gr.double().norm()) == pytest.approx(ref_norm, rel=0.3), n
+        worst_norm = max(worst_norm, abs(float(gr.double().norm()) / ref_norm - 1.0))
+        assert float(gr.double().norm()) == pytest.approx(ref_norm, rel=REL_NORM), n
+    print(f"L/14 end-to-end gradients vs F4: worst |norm ratio - 1| = {worst_norm:.3e}")
     print("near-tie between a matched prediction and its target:", near_tie)

@@ -25,3 +25,21 @@ def test_batched_metadata():
         x, y, bw, bh = boxes[b].unbind(-1)
         ref = torch.stack([x / w, y / h, (x + bw) / w, (y + bh) / h], -1)
         torch.testing.assert_close(out[b], ref)
+
+
+def test_input_contract_matches_reference_fixture_f9(golden_dir):
+    """F9 = the reference's own `coco_to_model_input` / `model_output_to_image` (ref src/train_util.py:4-24, src/util.py:83-93,
+    123-129) run on DataLoader-shaped inputs in the build container (tests/golden/make_golden.py f9): bit-exact f32."""
+    import os
+    g = np.load(os.path.join(golden_dir, "f9_input_contract.npz"))
+    cases = sorted({k.split("/")[0] for k in g.files})
+    assert len(cases) >= 6
+    for c in cases:
+        boxes = torch.from_numpy(g[c + "/xywh"])
+        w, h = (int(v) for v in g[c + "/wh"])
+        meta = {"width": torch.tensor([w]), "height": torch.tensor([h])}          # what default_collate makes of the dataset's ints
+        keep = boxes.clone()
+        out = coco_to_model_input(boxes, meta)
+        assert out.dtype == torch.float32 and out.shape == boxes.shape and torch.equal(boxes, keep)
+        assert torch.equal(out, torch.from_numpy(g[c + "/xyxy_norm"])), c
+        assert torch.equal(model_output_to_image(out, meta), torch.from_numpy(g[c + "/back"])), c

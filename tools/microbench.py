@@ -47,8 +47,8 @@ if __name__ == "__main__":
     for sh in shapes:
         for rep in range(2):
             for tile in (256, 8):
-                _lib.call("owl_gemm_set_tile", tile)
+                ops.GEMM_TILE = tile
                 print("single-phase 256x256:" if tile == 256 else "ping-pong 256x256:  ", end=" ")
                 bench_gemm(*sh)
-    _lib.call("owl_gemm_set_tile", 0)
+    ops.GEMM_TILE = 0
     bench_attn(32, 12, 2305)

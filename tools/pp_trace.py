@@ -17,7 +17,7 @@ W = (torch.randn(N, K, device=DEV) * 0.05).bfloat16()
 bias = torch.randn(N, device=DEV)
 out = torch.zeros(ops.pad_rows(M), N, device=DEV, dtype=torch.bfloat16)
 trace = torch.zeros(320, dtype=torch.int64, device=DEV)
-_lib.call("owl_gemm_set_tile", 8)
+ops.GEMM_TILE = 8
 for _ in range(5):
     ops.gemm(ops.EPI_BIAS_BF16, A, W, out, bias=bias, M=M)
 _lib.call("owl_gemm_debug_nostore", 8)

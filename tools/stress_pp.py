@@ -11,14 +11,14 @@ for (N, K, epi) in [(3072, 768, ops.EPI_QGELU_BF16), (768, 3072, ops.EPI_BIAS_BF
     W = (torch.randn(N, K, device=DEV) * 0.05).bfloat16(); bias = torch.randn(N, device=DEV)
     big = torch.empty(256 * 1024 * 1024, device=DEV, dtype=torch.uint8)
     def run(tile):
-        _lib.call("owl_gemm_set_tile", tile)
+        ops.GEMM_TILE = tile
         if epi == ops.EPI_TRANS_BF16:
             out = torch.zeros(32 * N * 2312 + 256, device=DEV, dtype=torch.bfloat16)
             ops.gemm(epi, A, W, out, bias=bias, M=M, N=N, K=K, Tp=2312)
         else:
             out = torch.zeros(ops.pad_rows(M), N, device=DEV, dtype=torch.bfloat16)
             ops.gemm(epi, A, W, out, bias=bias, M=M)
-        _lib.call("owl_gemm_set_tile", 0)
+        ops.GEMM_TILE = 0
         return out
     ref = run(256)
     s2 = torch.cuda.Stream()

@@ -6,10 +6,10 @@ DEV = "cuda"
 B, Tp, D = 32, 2312, 768; M = B * Tp
 A = torch.randn(ops.pad_rows(M), D, device=DEV).bfloat16(); W = (torch.randn(D, D, device=DEV) * 0.05).bfloat16(); bias = torch.randn(D, device=DEV)
 def run(tile):
-    _lib.call("owl_gemm_set_tile", tile)
+    ops.GEMM_TILE = tile
     out = torch.zeros(B * D * Tp + 256, device=DEV, dtype=torch.bfloat16)
     ops.gemm(ops.EPI_TRANS_BF16, A, W, out, bias=bias, M=M, N=D, K=D, Tp=Tp)
-    _lib.call("owl_gemm_set_tile", 0)
+    ops.GEMM_TILE = 0
     return out
 ref, got = run(256), run(8)
 print("TRANS pp vs single-phase equal:", torch.equal(ref, got))
@@ -24,6 +24,6 @@ def timeit(fn, iters=30):
 out = torch.zeros(B * D * Tp + 256, device=DEV, dtype=torch.bfloat16)
 for _ in range(2):
     for tile in (256, 8):
-        _lib.call("owl_gemm_set_tile", tile)
+        ops.GEMM_TILE = tile
         print("tile", tile, f"{timeit(lambda: ops.gemm(ops.EPI_TRANS_BF16, A, W, out, bias=bias, M=M, N=D, K=D, Tp=Tp)):.4f} ms", flush=True)
-_lib.call("owl_gemm_set_tile", 0)
+ops.GEMM_TILE = 0

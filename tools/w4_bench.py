@@ -11,12 +11,12 @@ def check(M, N, K, epi):
     W = (torch.randn(N, K, device=DEV) * 0.05).bfloat16(); bias = torch.randn(N, device=DEV)
     outs = []
     for tile in (8, 4):
-        _lib.call("owl_gemm_set_tile", tile)
+        ops.GEMM_TILE = tile
         out = torch.zeros(ops.pad_rows(M), N, device=DEV, dtype=torch.bfloat16)
         ops.gemm(epi, A, W, out, bias=bias, M=M)
         outs.append(out)
     torch.cuda.synchronize()
-    _lib.call("owl_gemm_set_tile", 0)
+    ops.GEMM_TILE = 0
     print(f"M={M} N={N} K={K} epi={epi}: bitwise equal = {torch.equal(outs[0], outs[1])}, max diff {(outs[0].float()-outs[1].float()).abs().max().item():.3g}", flush=True)
 for sh in [(M, 768, 768, 0), (M, 3072, 768, 1), (M, 768, 3072, 0), (1000, 512, 256, 0), (8192, 8192, 8192, 0)]:
     check(*sh)
@@ -27,7 +27,7 @@ shapes = [(M, 768, 768, ops.EPI_BIAS_BF16), (M, 1536, 768, ops.EPI_BIAS_BF16), (
 for sh in shapes:
     for rep in range(2):
         for tile in (8, 4):
-            _lib.call("owl_gemm_set_tile", tile)
+            ops.GEMM_TILE = tile
             print("ping-pong:" if tile == 8 else "four-wave:", end=" ")
             mb.bench_gemm(*sh)
-_lib.call("owl_gemm_set_tile", 0)
+ops.GEMM_TILE = 0
