@@ -90,7 +90,7 @@ def test_full_step_at_baseline_batch(arch, B, probe):
         for j, k in enumerate(KEYS):
             assert float(per[j]) == pytest.approx(l1[k], rel=1e-5, abs=1e-7), (i, k)
     print(f"{arch} B={B}: worst |batch - batch1| over all images {worst_inv:.3e}")
-    assert worst_inv <= 1e-6
+    assert worst_inv == 0.0                   # every image of the batch carries the very bits of its batch-1 forward
     for k in KEYS:
         assert lossB[k] == pytest.approx(loss_sum[k] / B, rel=2e-5, abs=1e-7), (k, lossB[k], loss_sum[k] / B)
     mean_grad = (grad_sum / B).float()
@@ -101,7 +101,7 @@ def test_full_step_at_baseline_batch(arch, B, probe):
         a, r = gradB[o: o + k], mean_grad[o: o + k]
         rel = float((a - r).norm() / max(float(r.norm()), floor))
         worst = max(worst, rel)
-        assert rel < 2e-3, (n, rel)           # f32 summation order only (the 1/B upstream scale is a power of two: exact in bf16)
+        assert rel < 2e-5, (n, rel)           # f32 summation order only (the 1/B upstream scale is a power of two: exact in bf16); measured 9e-7
     print(f"{arch} B={B}: worst rel-L2 |flat_grad(B) - mean_i flat_grad(i)| = {worst:.3e}")
 
     # ---- (iii) decisions + loss terms of >= 4 images vs the CPU oracle on the same predictions; forward vs the oracle ----

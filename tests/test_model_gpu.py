@@ -17,9 +17,17 @@ from owl_vit_object_detection_amd.models import OwlViT  # noqa: E402
 DEV = "cuda"
 # north-star bf16 bar: 1e-2.  Asserted at ~2x the error measured on the final build (tools/errstudy.py: full-size B/16 boxes 2.0e-3 /
 # sims 9.1e-4, L/14 1.8e-3 / 7.3e-4) so that a regression which doubles the forward error fails.
-TOL_BOXES, TOL_SIMS = 4e-3, 2e-3
-# end-to-end gradient sanity bands of the full-size fixtures (the strict all-element check is the backward-chain test)
-REL_NORM, MIN_COS = 0.3, 0.9
+# Measured on the round-2 build (gpurun_out/r2_t1.log): full size boxes <= 2.4e-3 / sims <= 9.1e-4 (B/16, all 8 images of configs[1]),
+# 1.9e-3 / 6.7e-4 (L/14), 1.7e-3 / 7.2e-4 (B/32); parity-test configs (tiny / small: 2 heads, D = 128 / 256, where one bf16 ulp of a
+# feature is a larger share of a cosine) boxes <= 1.7e-3 / sims <= 1.8e-3.
+TOL_BOXES, TOL_SIMS, TOL_SIMS_SMALLCFG = 4e-3, 2e-3, 3.5e-3
+# end-to-end gradient sanity bands of the full-size fixtures, ~2x the measured deviation (B/16 F2: worst norm ratio 8.1e-2, worst
+# 64-element cosine 0.944; L/14 F4: 5.1e-3).  The strict all-element check is the backward-chain test (measured <= 9.7e-3).
+REL_NORM, REL_NORM_L14, MIN_COS = 0.16, 0.02, 0.9
+
+
+def _tol_sims(cname):
+    return TOL_SIMS if cname.startswith("owlvit") else TOL_SIMS_SMALLCFG
 
 
 def _maxerr(a, b):
@@ -40,7 +48,7 @@ def test_forward_matches_oracle(cname, B):
     rb, rs = O.model_forward(cfg, w, torch.from_numpy(img))
     eb, es = _maxerr(pb, rb), _maxerr(ps, rs)
     print(f"{cname} B={B}: max|d boxes|={eb:.3e} max|d sims|={es:.3e}")
-    assert eb < TOL_BOXES and es < TOL_SIMS, (eb, es)
+    assert eb < TOL_BOXES and es < _tol_sims(cname), (eb, es)
 
 
 def test_forward_matches_reference_fixture_f1(golden_dir):
@@ -52,7 +60,7 @@ def test_forward_matches_reference_fixture_f1(golden_dir):
         pb, _, ps, _ = model(img)
     eb, es = _maxerr(pb, torch.from_numpy(g["pred_boxes"])), _maxerr(ps, torch.from_numpy(g["pred_sims"]))
     print(f"tiny vs reference fixture F1: max|d boxes|={eb:.3e} max|d sims|={es:.3e}")
-    assert eb < TOL_BOXES and es < TOL_SIMS, (eb, es)
+    assert eb < TOL_BOXES and es < TOL_SIMS_SMALLCFG, (eb, es)
 
 
 def test_forward_b16_matches_reference_fixture_f2(golden_dir):
@@ -160,7 +168,7 @@ def test_backward_chain_matches_oracle_given_same_upstream(cname, B):
     torch.autograd.backward([rb, rs], [d_boxes, d_sims])
     gref = {n: ww[n].grad for n in names}
     worst, worst_cos = _grad_report(grads, gref, f"backward-only {cname} B={B}")
-    assert worst < 3e-2 and worst_cos > 0.999
+    assert worst < 2e-2 and worst_cos > 0.9995          # measured <= 9.7e-3 / >= 0.99996 on every config
 
 
 @pytest.mark.parametrize("cname,B", [("tiny", 1), ("tiny", 3), ("small", 2)])
@@ -176,7 +184,7 @@ def test_train_step_matches_oracle(cname, B):
                                       [torch.from_numpy(b) for b in boxes], torch.from_numpy(scales))
     eb, es = _maxerr(pb, rb), _maxerr(ps, rs)
     print(f"train step {cname} B={B}: max|d boxes|={eb:.3e} max|d sims|={es:.3e}")
-    assert eb < TOL_BOXES and es < TOL_SIMS, (eb, es)
+    assert eb < TOL_BOXES and es < _tol_sims(cname), (eb, es)
     # matched loss within the bf16 bar (relative for the large class terms)
     for k in LOSS_KEYS:
         assert lg[k] == pytest.approx(float(lo[k]), rel=2e-2, abs=1e-2), (k, lg[k], float(lo[k]))
@@ -335,6 +343,6 @@ def test_l14_train_step_matches_reference_fixture_f4(golden_dir):
         if ref_norm < 1e-2 * big or (near_tie and n.startswith("box_head")):
             continue
         worst_norm = max(worst_norm, abs(float(gr.double().norm()) / ref_norm - 1.0))
-        assert float(gr.double().norm()) == pytest.approx(ref_norm, rel=REL_NORM), n
+        assert float(gr.double().norm()) == pytest.approx(ref_norm, rel=REL_NORM_L14), n
     print(f"L/14 end-to-end gradients vs F4: worst |norm ratio - 1| = {worst_norm:.3e}")
     print("near-tie between a matched prediction and its target:", near_tie)
