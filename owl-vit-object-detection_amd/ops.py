@@ -11,6 +11,7 @@ EPI_BIAS_BF16, EPI_QGELU_BF16, EPI_GELU_BF16, EPI_RESID_F32, EPI_F32, EPI_ATOMIC
 EPI_TRANS_BF16, EPI_PATCH_F32, EPI_DQGELU_BF16, EPI_DGELU_BF16, EPI_ACC_F32, EPI_SLAB_F32 = 6, 7, 8, 9, 10, 11
 
 ROW_PAD = 128
+ATTN_VARIANT = 0   # default `variant` of attention_fwd_vrow(): 0 = the library's choice; 1 classic, 2 / 3 pipelined (tests / tools)
 GEMM_TILE = 0      # default `tile` argument of gemm(): 0 = automatic kernel choice; tests / tools pin one kernel (128 | 256 | 8 | 4)
 
 
@@ -87,9 +88,10 @@ def attention_fwd(q, k, ld_qk, vt, vt_img_stride, out, ld_out, lse, B, H, T, Tp,
     return out
 
 
-def attention_fwd_vrow(q, k, v, ld_qkv, out, ld_out, lse, B, H, T, Tp, scale):
+def attention_fwd_vrow(q, k, v, ld_qkv, out, ld_out, lse, B, H, T, Tp, scale, variant=None):
     """attention_fwd with V row-major (a column slice of the qkv rows): no V^T copy."""
-    _lib.call("owl_attention_fwd_vrow_bf16", stream(), q, k, v, ld_qkv, out, ld_out, lse, B, H, T, Tp, float(scale))
+    _lib.call("owl_attention_fwd_vrow_bf16", stream(), q, k, v, ld_qkv, out, ld_out, lse, B, H, T, Tp, float(scale),
+              int(ATTN_VARIANT if variant is None else variant))
     return out
 
 

@@ -118,15 +118,15 @@ def test_attention_fwd_vrow_bitwise_repeatable():
     qkv = torch.zeros(ops.pad_rows(M), 3 * D, device=DEV, dtype=torch.bfloat16)
     qkv[:M] = torch.randn(M, 3 * D, device=DEV).bfloat16()
 
-    def run():
+    def run(variant=0):
         out = torch.zeros(ops.pad_rows(M), D, device=DEV, dtype=torch.bfloat16); lse = torch.zeros(B, H, Tp, device=DEV)
-        ops.attention_fwd_vrow(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, out, D, lse, B, H, T, Tp, 0.125)
+        ops.attention_fwd_vrow(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, out, D, lse, B, H, T, Tp, 0.125, variant=variant)
         return out, lse
 
-    ref = run()
-    for _ in range(30):
-        got = run()
-        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    ref = run(1)
+    for it in range(40):
+        got = run(it % 4)            # default / classic / pipelined / pipelined + hints: one result, every launch
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), it
 
 
 @pytest.mark.parametrize("arch,B", [("owlvit-base-patch16", 4), ("tiny-l14", 3)])

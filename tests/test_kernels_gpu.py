@@ -367,9 +367,55 @@ def test_attention_fwd_vrow_matches_vt_variant_bitwise(B, H, T):
     o1 = torch.zeros(ops.pad_rows(M), D, device=DEV, dtype=torch.bfloat16); l1 = torch.zeros(B, H, Tp, device=DEV)
     o2 = torch.zeros_like(o1); l2 = torch.zeros_like(l1)
     ops.attention_fwd(qkv, qkv[:, D:], 3 * D, vt, D * Tp, o1, D, l1, B, H, T, Tp, 0.125)
-    ops.attention_fwd_vrow(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, o2, D, l2, B, H, T, Tp, 0.125)
-    assert torch.equal(o1, o2) and torch.equal(l1, l2)
-    assert bool(torch.isfinite(o2.float()).all())
+    for variant in (0, 1, 2, 3):       # library default, classic sweep, software-pipelined sweep (without / with issue-order hints)
+        o2.zero_(); l2.zero_()
+        ops.attention_fwd_vrow(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, o2, D, l2, B, H, T, Tp, 0.125, variant=variant)
+        assert torch.equal(o1, o2) and torch.equal(l1, l2), variant
+        assert bool(torch.isfinite(o2.float()).all())
+
+
+@pytest.mark.parametrize("T", [1, 31, 33, 64, 65, 96, 97, 128, 129, 191, 192, 193, 256, 257, 300])
+def test_attention_fwd_pipelined_sweep_every_tail_shape(T):
+    """The software-pipelined sweep (prologue / steady state / final iteration / drain, partial and half-empty last tiles, query blocks
+    with idle waves) against the classic sweep at every tile-count / tail combination: identical bits, with and without LSE."""
+    B, H = 2, 2
+    torch.manual_seed(T)
+    Tp = (T + 7) // 8 * 8; D = H * 64; M = B * Tp
+    qkv = torch.zeros(ops.pad_rows(M), 3 * D, device=DEV, dtype=torch.bfloat16)
+    qkv[:M] = torch.randn(M, 3 * D, device=DEV).bfloat16()
+    ref = torch.zeros(ops.pad_rows(M), D, device=DEV, dtype=torch.bfloat16); lref = torch.zeros(B, H, Tp, device=DEV)
+    ops.attention_fwd_vrow(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, ref, D, lref, B, H, T, Tp, 0.125, variant=1)
+    for variant in (2, 3):
+        out = torch.zeros_like(ref); lse = torch.zeros_like(lref)
+        ops.attention_fwd_vrow(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, out, D, lse, B, H, T, Tp, 0.125, variant=variant)
+        assert torch.equal(out, ref) and torch.equal(lse, lref), (T, variant)
+        out2 = torch.zeros_like(ref)
+        ops.attention_fwd_vrow(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, out2, D, None, B, H, T, Tp, 0.125, variant=variant)
+        assert torch.equal(out2, ref)
+
+
+@pytest.mark.parametrize("spike_key,spike_q", [(250, 10), (5, 5), (2300, 2000), (70, 0)])
+def test_attention_fwd_pipelined_sweep_falls_back_on_overflow(spike_key, spike_q):
+    """The pipelined sweep carries no softmax offset: a row sum that overflows makes the whole workgroup redo its query block with the
+    classic (offset / rescale) sweep.  Spiked scores (one key x one query far above the rest, exp2 overflow without an offset) in
+    different tiles -- first, middle, last partial -- must give the classic sweep's bits and match f32 softmax."""
+    B, H, T = 1, 2, 2305
+    Tp = (T + 7) // 8 * 8; D = H * 64; M = B * Tp
+    x = rnd(B, T, 3 * D, seed=spike_key)
+    x[0, spike_key, D:D + 64] = 12.0 * torch.sign(x[0, spike_q, :64] + 1e-3)      # head 0: q . k ~ 12 * |q|_1 >> 2^40 after exp2
+    x[0, spike_q, :64] *= 6.0
+    qkv = ops.zeros_rows(M, 3 * D, torch.bfloat16, DEV)
+    qkv[:M].view(B, Tp, 3 * D)[:, :T] = x.bfloat16()
+    ref = torch.zeros(ops.pad_rows(M), D, device=DEV, dtype=torch.bfloat16); lref = torch.zeros(B, H, Tp, device=DEV)
+    ops.attention_fwd_vrow(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, ref, D, lref, B, H, T, Tp, 0.125, variant=1)
+    for variant in (2, 3):
+        out = torch.zeros_like(ref); lse = torch.zeros_like(lref)
+        ops.attention_fwd_vrow(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, out, D, lse, B, H, T, Tp, 0.125, variant=variant)
+        assert torch.equal(out, ref) and torch.equal(lse, lref), variant
+    v = qkv[:M].view(B, Tp, 3, H, 64)[:, :T].float()
+    q, k, vv = (v[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    want = (torch.softmax(q @ k.transpose(2, 3) * 0.125, -1) @ vv).permute(0, 2, 1, 3).reshape(B, T, D)
+    report("attn spiked (pipelined -> classic fallback)", ref[:M].view(B, Tp, D)[:, :T], want, 3e-2, 2e-2)
 
 
 @pytest.mark.parametrize("B,H,T", [(2, 3, 333), (1, 2, 37), (1, 12, 577), (1, 12, 2305), (2, 4, 2305), (1, 16, 3601)])
