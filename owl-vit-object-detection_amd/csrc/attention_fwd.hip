@@ -32,7 +32,10 @@ __device__ __forceinline__ int swap23(int m) { return (m & ~12) | ((m & 4) << 1)
 //               staged exactly like the K tile and transposed by the LDS hardware (`ds_read_b64_tr_b16`, two per fragment).
 // PIPE (VROW only): the software-pipelined sweep described at `pipe sweep` below (2 waves per SIMD instead of 3: it keeps the
 //               scores of two tiles and the probabilities of two tiles in registers); SCHED adds explicit issue-order hints.
-template <bool VROW, bool PIPE = false, bool SCHED = false>
+// OPT (classic structure): "optimistic" sweep -- tile 0 runs the checked tile code, every further tile runs WITHOUT the per-tile row-sum
+//               check, offset MFMA and rescale branch (5 VALU + ~20 SALU instructions and two branches per tile); the verdict is taken
+//               once, on the accumulated row sums, and a workgroup that fails it redoes its query block with the checked sweep.
+template <bool VROW, bool PIPE = false, bool SCHED = false, bool OPT = false>
 __global__ __launch_bounds__(256, PIPE ? 2 : 3) void attn_fwd_kernel(AttnFwdP p) {
     // dynamic LDS (one object): with a static array hipcc drains the just-issued LDS-DMA (vmcnt(0)) before the
     // first ds_read of every tile
@@ -222,9 +225,10 @@ __global__ __launch_bounds__(256, PIPE ? 2 : 3) void attn_fwd_kernel(AttnFwdP p)
     // one KV tile: S^T = K Q^T (+C), online softmax, O^T += V^T P^T.  BUF is a compile-time buffer index so that the
     // stage offset folds into the ds_read immediate; MASK only for the (peeled) partial last tile; FIRST forces the
     // explicit-maximum path.
-    auto tile = [&](auto buf_tag, int kv, auto mask_tag, bool first) {
+    auto tile = [&](auto buf_tag, int kv, auto mask_tag, bool first, auto opt_tag) {
         constexpr int BUF = decltype(buf_tag)::value;
         constexpr bool MASK = decltype(mask_tag)::value;
+        constexpr bool NOCHECK = decltype(opt_tag)::value;      // optimistic tile: no offset, no row-sum check, no rescale path
         typedef const __attribute__((address_space(3))) bf16x8* frag_ptr;
         f32x16 s[2];
         // the partial last tile often holds very few keys (T = 2305 = 36*64 + 1): when they all sit in its first 32-key
@@ -260,9 +264,18 @@ __global__ __launch_bounds__(256, PIPE ? 2 : 3) void attn_fwd_kernel(AttnFwdP p)
                     }
             }
         };
-        bool slow = (p.dbg & 1) || (first && (p.dbg & 4));    // (bit 2: old behaviour, the first tile always sets the offset)
+        bool slow = !NOCHECK && ((p.dbg & 1) || (first && (p.dbg & 4)));    // (bit 2: old behaviour, the first tile always sets the offset)
         float ts = 0.f;
-        if (!slow) {
+        if constexpr (NOCHECK) {
+            qk(std::false_type{});
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    s[t][r] = __builtin_amdgcn_exp2f(s[t][r]);
+                    ts += s[t][r];
+                }
+        } else if (!slow) {
             if (have_m) qk(std::true_type{}); else qk(std::false_type{});      // s = score*c - M   (M = 0: no offset MFMA)
 #pragma unroll
             for (int t = 0; t < 2; t++)
@@ -274,7 +287,7 @@ __global__ __launch_bounds__(256, PIPE ? 2 : 3) void attn_fwd_kernel(AttnFwdP p)
             // 2^40: P may have overflowed (or is about to); first tile only: 2^-60, the whole row may be about to underflow
             slow = __any(!(ts <= 1.0995116e12f) || (first && ts < 8.6736174e-19f));
         }
-        if (slow) {                                              // wave-uniform
+        if (!NOCHECK && slow) {                                  // wave-uniform
             qk(std::false_type{});                               // s = score*c
             float mx = s[0][0];
 #pragma unroll
@@ -603,8 +616,56 @@ __global__ __launch_bounds__(256, PIPE ? 2 : 3) void attn_fwd_kernel(AttnFwdP p)
         }
     }
 
+    // ---- optimistic sweep (classic structure, 3 waves per SIMD) -------------------------------------------------------------
+    if constexpr (OPT && !PIPE) {
+        volatile int* wg_flag = (volatile int*)(lds + 2 * 16384);
+        if (threadIdx.x == 0) *wg_flag = 0;
+        using T1 = std::true_type;
+        using F0 = std::false_type;
+        const bool partial = nkv > nfull;
+        if (nfull > 0) stage(0, 0); else stage_clamped(0, 0);
+        sync();
+        // tile 0 through the checked code (first-tile rule: a row about to underflow, or to overflow, sets an offset -> verdict "bad")
+        if (nkv > 1) { if (nfull > 1) stage(1, 1); else stage_clamped(1, 1); }
+        if (active) { if (nkv == 1 && partial) tile(B0{}, 0, T1{}, true, F0{}); else tile(B0{}, 0, F0{}, true, F0{}); }
+        const bool bad0 = have_m;
+        sync();
+        int kv = 1;
+        for (; kv + 1 < nfull; kv += 2) {          // kv odd: buffers 1, 0
+            stage(0, kv + 1);
+            if (active) tile(B1{}, kv, F0{}, false, T1{});
+            sync();
+            if (kv + 2 < nfull) stage(1, kv + 2); else if (kv + 2 < nkv) stage_clamped(1, kv + 2);
+            if (active) tile(B0{}, kv + 1, F0{}, false, T1{});
+            sync();
+        }
+        if (kv < nfull) {                           // one more full tile (kv odd -> buffer 1)
+            if (kv + 1 < nkv) stage_clamped(0, kv + 1);
+            if (active) tile(B1{}, kv, F0{}, false, T1{});
+            sync();
+            kv++;
+        }
+        if (kv < nkv && active) {                   // the partial tile
+            if (kv & 1) tile(B1{}, kv, T1{}, false, T1{}); else tile(B0{}, kv, T1{}, false, T1{});
+        }
+        // verdict on the accumulated row sums: every tile's row sum is positive, so l_part <= 2^40 implies that no tile's check would
+        // have fired (stricter than the per-tile rule: a redo costs time, never bits); inf / NaN fail the comparison too
+        const bool bad = bad0 || (active && __any(!(l_part <= 1.0995116e12f)));
+        if (bad && lane == 0) *wg_flag = 1;
+        sync();
+        run_classic = __builtin_amdgcn_readfirstlane(*wg_flag) != 0;
+        if (run_classic) {
+            sync();
+            l_part = 0.f;
+#pragma unroll
+            for (int d = 0; d < 2; d++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) o[d][r] = 0.f;
+        }
+    }
+
     if (run_classic) {
-        if constexpr (PIPE) {      // (re-)establish the classic sweep's state here, so that none of it is live across the pipelined sweep
+        if constexpr (PIPE || OPT) {      // (re-)establish the classic sweep's state here, so that none of it is live across the pipelined sweep
             M = 0.f; have_m = false;
             qn4 = make_uint4(0u, 0u, 0u, 0u); qneg = __builtin_bit_cast(bf16x8, qn4);
             ones4 = make_uint4(hi == 0 ? 0x3F80u : 0u, 0u, 0u, 0u); kones = __builtin_bit_cast(bf16x8, ones4);
@@ -614,21 +675,21 @@ __global__ __launch_bounds__(256, PIPE ? 2 : 3) void attn_fwd_kernel(AttnFwdP p)
         int kv = 0;
         for (; kv + 1 < nfull; kv += 2) {          // two tiles per trip: buffer index is a compile-time constant
             stage(1, kv + 1);
-            if (active) tile(B0{}, kv, std::false_type{}, kv == 0);
+            if (active) tile(B0{}, kv, std::false_type{}, kv == 0, std::false_type{});
             sync();
             if (kv + 2 < nfull) stage(0, kv + 2); else if (kv + 2 < nkv) stage_clamped(0, kv + 2);
-            if (active) tile(B1{}, kv + 1, std::false_type{}, false);
+            if (active) tile(B1{}, kv + 1, std::false_type{}, false, std::false_type{});
             sync();
         }
         // remainder: at most one full tile and/or the partial tile, buffers alternate from (kv & 1)
         if (kv < nfull) {                           // kv even here -> buffer 0
             if (kv + 1 < nkv) stage_clamped(1, kv + 1);          // kv + 1 == nfull: the partial tile
-            if (active) tile(B0{}, kv, std::false_type{}, kv == 0);
+            if (active) tile(B0{}, kv, std::false_type{}, kv == 0, std::false_type{});
             sync();
             kv++;
         }
         if (kv < nkv && active) {
-            if (kv & 1) tile(B1{}, kv, std::true_type{}, false); else tile(B0{}, kv, std::true_type{}, kv == 0);
+            if (kv & 1) tile(B1{}, kv, std::true_type{}, false, std::false_type{}); else tile(B0{}, kv, std::true_type{}, kv == 0, std::false_type{});
         }
     }
     const float l_run = l_part;
@@ -677,6 +738,11 @@ static int attn_fwd_launch(void* stream, const void* q, const void* k, int64_t l
     p.B = (int)B; p.nqb = (int)((T + 127) / 128); p.dbg = g_attn_dbg;
     const int64_t npairs8 = (B * H + 7) / 8;                  // pairs per XCD (rounded up)
     dim3 grid((unsigned)(npairs8 * p.nqb * 8));
+    if (variant == 4 && v_row_major) {
+        hipLaunchKernelGGL((attn_fwd_kernel<true, false, false, true>), grid, dim3(256), 2 * 16384 + 16, (hipStream_t)stream, p);
+        OWL_LAUNCH_CHECK();
+        return 0;
+    }
     OWL_CHECK_ARG(variant >= 0 && variant <= 3 && (variant <= 1 || v_row_major), "owl_attention_fwd: variant must be 0 (default), 1 (classic), 2 / 3 (pipelined; row-major V only)");
     if (variant == 0) variant = ATTN_DEFAULT_VARIANT;
     if (!v_row_major) hipLaunchKernelGGL((attn_fwd_kernel<false>), grid, dim3(256), 2 * 16384, (hipStream_t)stream, p);

@@ -367,7 +367,7 @@ def test_attention_fwd_vrow_matches_vt_variant_bitwise(B, H, T):
     o1 = torch.zeros(ops.pad_rows(M), D, device=DEV, dtype=torch.bfloat16); l1 = torch.zeros(B, H, Tp, device=DEV)
     o2 = torch.zeros_like(o1); l2 = torch.zeros_like(l1)
     ops.attention_fwd(qkv, qkv[:, D:], 3 * D, vt, D * Tp, o1, D, l1, B, H, T, Tp, 0.125)
-    for variant in (0, 1, 2, 3):       # library default, classic sweep, software-pipelined sweep (without / with issue-order hints)
+    for variant in (0, 1, 2, 3, 4):       # library default, classic sweep, software-pipelined sweep (without / with issue-order hints)
         o2.zero_(); l2.zero_()
         ops.attention_fwd_vrow(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, o2, D, l2, B, H, T, Tp, 0.125, variant=variant)
         assert torch.equal(o1, o2) and torch.equal(l1, l2), variant
@@ -385,7 +385,7 @@ def test_attention_fwd_pipelined_sweep_every_tail_shape(T):
     qkv[:M] = torch.randn(M, 3 * D, device=DEV).bfloat16()
     ref = torch.zeros(ops.pad_rows(M), D, device=DEV, dtype=torch.bfloat16); lref = torch.zeros(B, H, Tp, device=DEV)
     ops.attention_fwd_vrow(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, ref, D, lref, B, H, T, Tp, 0.125, variant=1)
-    for variant in (2, 3):
+    for variant in (2, 3, 4):
         out = torch.zeros_like(ref); lse = torch.zeros_like(lref)
         ops.attention_fwd_vrow(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, out, D, lse, B, H, T, Tp, 0.125, variant=variant)
         assert torch.equal(out, ref) and torch.equal(lse, lref), (T, variant)
@@ -408,7 +408,7 @@ def test_attention_fwd_pipelined_sweep_falls_back_on_overflow(spike_key, spike_q
     qkv[:M].view(B, Tp, 3 * D)[:, :T] = x.bfloat16()
     ref = torch.zeros(ops.pad_rows(M), D, device=DEV, dtype=torch.bfloat16); lref = torch.zeros(B, H, Tp, device=DEV)
     ops.attention_fwd_vrow(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, ref, D, lref, B, H, T, Tp, 0.125, variant=1)
-    for variant in (2, 3):
+    for variant in (2, 3, 4):
         out = torch.zeros_like(ref); lse = torch.zeros_like(lref)
         ops.attention_fwd_vrow(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, out, D, lse, B, H, T, Tp, 0.125, variant=variant)
         assert torch.equal(out, ref) and torch.equal(lse, lref), variant
