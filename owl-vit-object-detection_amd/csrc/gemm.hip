@@ -300,13 +300,14 @@ static int launch_cfg(hipStream_t s, GemmP p, int splits) {
 
 int owl_gemm_pp_launch(hipStream_t s, int epi, const GemmP& p, int slots_override, int persistent_on, int nostore);   // gemm_pp.hip
 int owl_gemm_w4_launch(hipStream_t s, int epi, const GemmP& p);                                                       // gemm_w4.hip
+int owl_gemm_pph_launch(hipStream_t s, int epi, const GemmP& p);                                                      // gemm_pph.hip
 
 template <int EPI>
 static int launch(hipStream_t s, const GemmP& p, int splits, int g_force_tile = 0) {
     // 256-wide tiles only when they give the chip enough work items (batch-1 out-proj is 10 x 3 of them: the 128x128
     // kernel's 114 tiles finish sooner)
     const int64_t t256 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-    const bool big = g_force_tile ? (g_force_tile == 256) : (p.M >= 512 && p.N >= 256 && t256 >= 48);
+    const bool big = g_force_tile ? (g_force_tile == 256 || g_force_tile == 8 || g_force_tile == 9) : (p.M >= 512 && p.N >= 256 && t256 >= 48);
     if (big) return launch_cfg<EPI, 256, 256, 128, 64>(s, p, splits);
     return launch_cfg<EPI, 128, 128, 64, 64>(s, p, splits);
 }
@@ -316,7 +317,7 @@ extern "C" int owl_gemm_nt_bf16(void* stream, int epi, const void* A, int64_t ld
                                 const float* resid, void* aux, int64_t ld_aux, int64_t M, int64_t N, int64_t K,
                                 float alpha, int splits, int64_t Tp, int tile) {
     OWL_CHECK_ARG(A && W && out, "owl_gemm_nt_bf16: null pointer");
-    OWL_CHECK_ARG(tile == 0 || tile == 128 || tile == 256 || tile == 8 || tile == 4, "owl_gemm_nt_bf16: tile must be 0 (auto), 128, 256, 8 or 4");
+    OWL_CHECK_ARG(tile == 0 || tile == 128 || tile == 256 || tile == 8 || tile == 9 || tile == 4, "owl_gemm_nt_bf16: tile must be 0 (auto), 128, 256, 8, 9 or 4");
     const int g_force_tile = tile;
     OWL_CHECK_ARG(K > 0 && K % BK == 0, "owl_gemm_nt_bf16: K=%lld must be a positive multiple of 64", (long long)K);
     OWL_CHECK_ARG(M > 0 && N > 0 && N % 8 == 0, "owl_gemm_nt_bf16: bad M=%lld N=%lld (N %% 8 == 0)", (long long)M, (long long)N);
@@ -342,8 +343,39 @@ extern "C" int owl_gemm_nt_bf16(void* stream, int epi, const void* A, int64_t ld
         if (rc <= 0) return rc;
     }
     const bool pp_auto = (g_force_tile == 0 && M >= 512 && N >= 256 && ((M + 255) / 256) * ((N + 255) / 256) >= 48);
-    if ((g_force_tile == 8 || pp_auto) && K >= 128 && (epi != EPI_TRANS_BF16 || (Tp > 0 && Tp % 4 == 0 && N % 64 == 0)) &&
+    if ((g_force_tile == 8 || g_force_tile == 9 || pp_auto) && K >= 128 && (epi != EPI_TRANS_BF16 || (Tp > 0 && Tp % 4 == 0 && N % 64 == 0)) &&
         ((epi != EPI_DQGELU_BF16 && epi != EPI_DGELU_BF16) || aux)) {
+        // Tile quantisation: tm x tn tiles of 256 x 256 on 256 workgroups = full_rounds whole rounds + a remainder round that keeps
+        // only `rem` CUs busy (N = 768: 867 tiles = 3.39 -> 4 rounds).  When the remainder fits one round of HALF-height tiles the
+        // whole rounds go to the 256 x 256 ping-pong kernel and the remaining row tiles to the 128 x 256 variant (gemm_pph.hip):
+        // one round of ~0.56 tile times instead of a whole one.  Same K order and epilogue: bit-identical.
+        // Measured (tools/gemm_remainder_bench.py, same-process A/B at M = 73 984): +3.6 % fc2 (K = 3072), +2.5 % dX (K = 2304), +4.2 % box-head
+        // dense (GELU epilogue), +0.8 % out-proj (K = 768); nothing for wide outputs (QKV N = 2304: -0.1 %, fc1: does not fit one round), where
+        // the half-height tiles -- latency-bound, ~0.85 of a full tile's time, not 0.56 -- only just pay for the second launch.  Hence the
+        // automatic rule: narrow outputs only (N <= 1024); tile = 9 forces the split wherever it fits, tile = 8 never splits.
+        if ((g_force_tile == 9 || (g_force_tile == 0 && N <= 1024)) && epi != EPI_TRANS_BF16 && a_rows >= M) {
+            const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256, items = tm * tn;
+            const int64_t full_rounds = items / 256;
+            const int64_t tm_main = (full_rounds * 256) / tn;
+            const int64_t rem_tiles = (tm - tm_main) * tn;
+            if (full_rounds >= 1 && tm_main >= 1 && rem_tiles > 0 && 2 * rem_tiles <= 256 && items - full_rounds * 256 > 0) {
+                const int64_t M_main = tm_main * 256;
+                GemmP pm = p;
+                pm.M = M_main; pm.a_rows = M_main;
+                int rc = owl_gemm_pp_launch(s, epi, pm, g_debug_slots, g_persistent, g_debug_nostore);
+                if (rc < 0) return rc;
+                if (rc == 0) {
+                    GemmP pr = p;
+                    pr.A = p.A + M_main * lda; pr.a_rows = a_rows - M_main; pr.M = M - M_main;
+                    pr.out = (void*)((bf16_t*)p.out + M_main * ldo);
+                    if (p.aux) pr.aux = (void*)((bf16_t*)p.aux + M_main * ld_aux);
+                    rc = owl_gemm_pph_launch(s, epi, pr);
+                    if (rc <= 0) return rc;
+                    // (epilogue not handled by the half-height kernel: finish the remainder rows with the 256 x 256 kernel)
+                    return owl_gemm_pp_launch(s, epi, pr, g_debug_slots, g_persistent, g_debug_nostore);
+                }
+            }
+        }
         const int rc = owl_gemm_pp_launch(s, epi, p, g_debug_slots, g_persistent, g_debug_nostore);
         if (rc <= 0) return rc;      // 1 = epilogue not handled there: fall through
     }

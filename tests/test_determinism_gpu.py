@@ -55,7 +55,8 @@ def test_gemm_bitwise_repeatable(N, K, epi):
         assert torch.equal(run(), ref)
 
 
-@pytest.mark.parametrize("N,K,epi", [(3072, 768, ops.EPI_QGELU_BF16), (768, 3072, ops.EPI_BIAS_BF16), (768, 128, ops.EPI_BIAS_BF16)])
+@pytest.mark.parametrize("N,K,epi", [(3072, 768, ops.EPI_QGELU_BF16), (768, 3072, ops.EPI_BIAS_BF16), (768, 128, ops.EPI_BIAS_BF16),
+                                     (768, 768, ops.EPI_BIAS_BF16), (2304, 768, ops.EPI_BIAS_BF16), (768, 768, ops.EPI_GELU_BF16)])
 def test_gemm_pingpong_matches_tile256_bitwise(N, K, epi):
     """The ping-pong schedule (counted vmcnt, half-tile early release, two wave groups one barrier apart) must give
     the very bits of the single-phase kernel -- on a persistent launch (more tiles than workgroups, cross-tile
@@ -77,6 +78,11 @@ def test_gemm_pingpong_matches_tile256_bitwise(N, K, epi):
     ref = run(256)
     for _ in range(12):
         assert torch.equal(run(8), ref)
+    # tile = 9: whole rounds on the 256 x 256 ping-pong kernel + the remainder rows on the half-height (128 x 256) variant
+    # where that pays (N = 768: 867 tiles = 3 rounds + 99 tiles -> 198 half tiles), csrc/gemm_pph.hip
+    for _ in range(8):
+        assert torch.equal(run(9), ref)
+    assert torch.equal(run(0), ref)                     # whatever the automatic rule picks
     # the experimental four-wave kernel (csrc/gemm_w4.hip, owl_gemm_set_tile(4): one 128x128 block per wave, fragments
     # software-pipelined inside the wave, LDS-DMA pieces spread over three K-steps) shares the epilogue and the K order
     for _ in range(6):
