@@ -15,20 +15,22 @@
 //   group 0:    LOAD q0(c)    MFMA q0(c)    LOAD q1(c)    MFMA q1(c)
 //   group 1:    MFMA q1(c-1)  LOAD q0(c)    MFMA q0(c)    LOAD q1(c)
 //
-// q0 LOAD reads A (both 32-row tiles, 8 x ds_read_b128) and B(j0) (4); q1 LOAD reads B(j1) (4).  Staging (two stage buffers):
+// q0 LOAD reads A (both 32-row tiles, 8 x ds_read_b128) and B(j0) (4); q1 LOAD reads B(j1) (4).  Staging:
 //   * a group's A rows are read by that group only and staged by that group's own waves, and the q0 LOAD ends with a barrier -> the A
 //     pieces of K-tile c+2 go into the buffer of K-tile c during q1 LOAD of K-tile c (2 pieces per wave);
-//   * the B rows of K-tile c-1's buffer are free once both groups have finished q1 LOAD of K-tile c-1, i.e. when group 0 enters
-//     q0 LOAD of K-tile c -> the B pieces of K-tile c+1 are issued there (4 pieces per wave, + the bias slice with K-tile 0);
-//   * counted wait at the end of q1 LOAD (both groups: group 0 reads K-tile c+1 one barrier after group 1's q1 LOAD): everything but
-//     the newest A pieces has landed before the barrier.
+//   * B has THREE stages: the stage of K-tile c-1 is free once both groups have finished q1 LOAD of K-tile c-1, i.e. when group 0
+//     enters q0 LOAD of K-tile c -> the B pieces of K-tile c+2 are issued there (4 pieces per wave), a whole K-tile of flight time;
+//   * counted wait at the end of q1 LOAD (both groups: group 0 reads K-tile c+1 one barrier after group 1's q1 LOAD): K-tile c+1 has
+//     landed, the six pieces of K-tile c+2 stay in flight across the barrier.
 // One tile per workgroup (the remainder round has fewer tiles than CUs), so no cross-tile streaming.
 #include "gemm_common.h"
 #include <type_traits>
 
 static constexpr int HBM = 128, HBN = 256, HBK = 64;
-static constexpr int H_A_BYTES = HBM * HBK * 2, H_B_BYTES = HBN * HBK * 2, H_STAGE = H_A_BYTES + H_B_BYTES;   // 16 + 32 KiB
-static constexpr int H_BIAS_OFF = 2 * H_STAGE, H_LDS = 2 * H_STAGE + 1024;
+static constexpr int H_A_BYTES = HBM * HBK * 2, H_B_BYTES = HBN * HBK * 2;   // 16 / 32 KiB per stage
+// LDS: two A stages, THREE B stages (B is staged two K-tiles ahead: with two it could only be issued one K-tile ahead -- its rows are
+// shared by both groups and free late -- and the counted wait then stalled on it: the half-height K-tile took as long as a full one)
+static constexpr int H_A_OFF = 0, H_B_OFF = 2 * H_A_BYTES, H_BIAS_OFF = H_B_OFF + 3 * H_B_BYTES, H_LDS = H_BIAS_OFF + 1024;
 
 template <int N> __device__ __forceinline__ void ph_wait() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void ph_wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -80,14 +82,14 @@ __global__ __launch_bounds__(512) void gemm_pph_kernel(GemmP p) {
         b_voff = (unsigned)((n - cn0) * 4);
     }
     auto stage_A = [&](int kt, int buf) {             // 2 pieces
-        unsigned char* base = lds + buf * H_STAGE;
+        unsigned char* base = lds + H_A_OFF + buf * H_A_BYTES;
         const unsigned char* g = (const unsigned char*)(a_base + (int64_t)kt * HBK);
 #pragma unroll
         for (int q = 0; q < 2; q++)
             __builtin_amdgcn_global_load_lds(GPTR(g + a_voff[q]), LPTR(base + ((w * 2 + q) * 8) * 128), 16, 0, 0);
     };
     auto stage_B = [&](int kt, int buf) -> int {      // 4 pieces (+ the bias slice with K-tile 0)
-        unsigned char* base = lds + buf * H_STAGE + H_A_BYTES;
+        unsigned char* base = lds + H_B_OFF + buf * H_B_BYTES;
         const unsigned char* g = (const unsigned char*)(w_base + (int64_t)kt * HBK);
 #pragma unroll
         for (int h = 0; h < 2; h++)
@@ -103,14 +105,15 @@ __global__ __launch_bounds__(512) void gemm_pph_kernel(GemmP p) {
 
     // fragment addresses: A rows grp*64 + t*32 + (lane&31), B rows wc*64 + j*32 + (lane&31); one swizzle per operand
     const int a_row0 = grp * 64 + (lane & 31), b_row0 = wc * 64 + (lane & 31);
-    const int a_base_off = a_row0 * 128, b_base_off = H_A_BYTES + b_row0 * 128;
+    const int a_base_off = a_row0 * 128, b_base_off = b_row0 * 128;
     const int a_swz = (a_row0 >> 1) & 7, b_swz = (b_row0 >> 1) & 7;
 
-    // prologue: A(0), B(0) [+bias], A(1) in flight; retire A(0) and B(0)
+    // prologue: A(0), B(0) [+bias], A(1), B(1); retire A(0) and B(0), K-tile 1 stays in flight
     stage_A(0, 0);
     stage_B(0, 0);
     stage_A(1, 1);
-    ph_wait<2>();
+    stage_B(1, 1);
+    ph_wait<6>();
     ph_bar();
 
     f32x16 acc[2][2];
@@ -121,19 +124,21 @@ __global__ __launch_bounds__(512) void gemm_pph_kernel(GemmP p) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
     if (grp == 1) ph_bar();                           // create the one-barrier offset between the groups
-    int cur = 0;
+    int cur = 0, bcur = 0;                            // A stage (kt & 1), B stage (kt % 3)
     for (int kt = 0; kt < nk; kt++) {
-        const unsigned char* tb = lds + cur * H_STAGE;
+        const unsigned char* ta = lds + H_A_OFF + cur * H_A_BYTES;
+        const unsigned char* tbb = lds + H_B_OFF + bcur * H_B_BYTES;
+        const int bnext2 = bcur >= 1 ? bcur - 1 : 2;  // (kt + 2) % 3
         bf16x8 fa[2][4], fb[2][4];                    // [32-row tile][kc], [j][kc]
         auto ld_a = [&]() {
 #pragma unroll
             for (int t = 0; t < 2; t++)
 #pragma unroll
-                for (int kc = 0; kc < 4; kc++) fa[t][kc] = *(const bf16x8*)(tb + a_base_off + t * 4096 + (((kc * 2 + hi) ^ a_swz) << 4));
+                for (int kc = 0; kc < 4; kc++) fa[t][kc] = *(const bf16x8*)(ta + a_base_off + t * 4096 + (((kc * 2 + hi) ^ a_swz) << 4));
         };
         auto ld_b = [&](int j) {
 #pragma unroll
-            for (int kc = 0; kc < 4; kc++) fb[j][kc] = *(const bf16x8*)(tb + b_base_off + j * 4096 + (((kc * 2 + hi) ^ b_swz) << 4));
+            for (int kc = 0; kc < 4; kc++) fb[j][kc] = *(const bf16x8*)(tbb + b_base_off + j * 4096 + (((kc * 2 + hi) ^ b_swz) << 4));
         };
         auto mma = [&](int j) {
             __builtin_amdgcn_s_setprio(1);
@@ -144,24 +149,25 @@ __global__ __launch_bounds__(512) void gemm_pph_kernel(GemmP p) {
                     acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][kc], fa[t][kc], acc[t][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
         };
-        // ---- q0: the other buffer's B rows are free (both groups are past q1 LOAD of the previous K-tile) ----
+        // ---- q0: the B stage of K-tile kt-1 is free (both groups are past q1 LOAD of that K-tile): it takes K-tile kt+2 ----
         ld_b(0); ld_a();
-        if (kt + 1 < nk) stage_B(kt + 1, cur ^ 1);
+        const bool more = kt + 2 < nk;
+        if (more) stage_B(kt + 2, bnext2);
         ph_wait_lgkm(); ph_bar();
         mma(0);
         ph_bar();
         // ---- q1: this group's A rows of this buffer are free (q0 LOAD ended with a barrier) ----
         ld_b(1);
-        const bool more_a = kt + 2 < nk;
-        if (more_a) stage_A(kt + 2, cur);
+        if (more) stage_A(kt + 2, cur);
         // Counted wait HERE, not one half-slot later: group 0 reads K-tile kt+1 right after the barrier that ends group 1's q1 LOAD, so
         // every wave of BOTH groups must have retired its pieces of K-tile kt+1 before the barrier that ends its own q1 LOAD (the two
         // groups run one barrier apart: "one barrier more", cdna_hip_programming.md).  Only the newest A pieces stay in flight.
-        if (more_a) ph_wait<2>(); else ph_wait<0>();
+        if (more) ph_wait<6>(); else ph_wait<0>();     // K-tile kt+1 has landed; K-tile kt+2 (4 B + 2 A pieces) stays in flight
         ph_bar();
         mma(1);
         ph_bar();
         cur ^= 1;
+        bcur = bcur == 2 ? 0 : bcur + 1;
     }
     if (grp == 0) ph_bar();                           // let group 1 finish its last MFMA half: epilogues run together
 
