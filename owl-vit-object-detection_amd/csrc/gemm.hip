@@ -353,7 +353,7 @@ extern "C" int owl_gemm_nt_bf16(void* stream, int epi, const void* A, int64_t ld
         // dense (GELU epilogue), +0.8 % out-proj (K = 768); nothing for wide outputs (QKV N = 2304: -0.1 %, fc1: does not fit one round), where
         // the half-height tiles -- latency-bound, ~0.85 of a full tile's time, not 0.56 -- only just pay for the second launch.  Hence the
         // automatic rule: narrow outputs only (N <= 1024); tile = 9 forces the split wherever it fits, tile = 8 never splits.
-        if ((g_force_tile == 9 || (g_force_tile == 0 && N <= 1024)) && epi != EPI_TRANS_BF16 && a_rows >= M) {
+        if ((g_force_tile == 9 || (g_force_tile == 0 && N <= 1024)) && epi != EPI_TRANS_BF16 && epi != EPI_F32 && epi != EPI_ACC_F32 && a_rows >= M) {
             const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256, items = tm * tn;
             const int64_t full_rounds = items / 256;
             const int64_t tm_main = (full_rounds * 256) / tn;

@@ -244,6 +244,37 @@ __device__ __forceinline__ void epi_tile_bf16(const GemmP& p, const f32x16& acc,
     chunk1 = make_uint4(x[2], x[3], y[2], y[3]);
 }
 
+// ---- register-resident f32 epilogue of ONE 32x32 accumulator tile (swapped operands: lane owns output row m) ------------
+// out f32 = alpha*acc (+ bias)  [EPI_F32]   |   out f32 += alpha*acc  [EPI_ACC_F32]; four 16-byte accesses per lane and tile at columns
+// n_tile + 8*qd + 4*hi.  Same operations in the same order as epi_quad (alpha, then bias, then the residual): identical bits to the
+// LDS-staged epilogue of the single-phase kernel.
+template <int EPI, bool GUARD>
+__device__ __forceinline__ void epi_tile_f32(const GemmP& p, const f32x16& acc, int64_t m_tile, int64_t n_tile, int lane, const float* lds_bias) {
+    const int hi = lane >> 5;
+    const int64_t m = m_tile + (lane & 31);
+    const bool m_ok = !GUARD || m < p.M;
+    float* orow = (float*)p.out + m * p.ldo + n_tile + 4 * hi;
+    const float* bias_p = lds_bias + 4 * hi;
+#pragma unroll
+    for (int qd = 0; qd < 4; qd++) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = acc[qd * 4 + e] * p.alpha;
+        if (p.bias) {                                  // wave-uniform
+            const f32x4 b4 = lds_read_f4(bias_p + 8 * qd);
+            v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
+        }
+        const bool ok = m_ok && (!GUARD || (n_tile + 8 * qd + 4 * hi) < p.N);
+        if (!ok) continue;
+        if constexpr (EPI == EPI_ACC_F32) {
+            const float4 r4 = *(const float4*)(orow + 8 * qd);
+            *(float4*)(orow + 8 * qd) = make_float4(r4.x + v[0], r4.y + v[1], r4.z + v[2], r4.w + v[3]);
+        } else {
+            *(float4*)(orow + 8 * qd) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
 // issue one 16-byte chunk (c = 0/1 within the tile)
 template <int EPI, bool GUARD>
 __device__ __forceinline__ void epi_store_chunk(const GemmP& p, const uint4& ch, int64_t m_tile, int64_t n_tile, int c, int lane) {

@@ -296,10 +296,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
 #pragma unroll
                     for (int j = 0; j < 2; j++) {
                         const int64_t mt = cm0 + grp * 128 + i * 32, nt = cn0 + wc * 64 + j * 32;
-                        uint4 c0, c1;
-                        epi_tile_bf16<EPI, G>(p, acc[i][j], mt, nt, lane, c0, c1, lbias + j * 32);
-                        epi_store_chunk<EPI, G>(p, c0, mt, nt, 0, lane);
-                        epi_store_chunk<EPI, G>(p, c1, mt, nt, 1, lane);
+                        if constexpr (EPI == EPI_F32 || EPI == EPI_ACC_F32) {
+                            epi_tile_f32<EPI, G>(p, acc[i][j], mt, nt, lane, lbias + j * 32);
+                        } else {
+                            uint4 c0, c1;
+                            epi_tile_bf16<EPI, G>(p, acc[i][j], mt, nt, lane, c0, c1, lbias + j * 32);
+                            epi_store_chunk<EPI, G>(p, c0, mt, nt, 0, lane);
+                            epi_store_chunk<EPI, G>(p, c1, mt, nt, 1, lane);
+                        }
                     }
             };
             if (inner) run(std::false_type{}); else run(std::true_type{});
@@ -359,6 +363,8 @@ int owl_gemm_pp_launch(hipStream_t s, int epi, const GemmP& p, int slots_overrid
         case EPI_DQGELU_BF16: return launch_pp<EPI_DQGELU_BF16>(s, p, slots_override, persistent_on, nostore);
         case EPI_GELU_BF16: return launch_pp<EPI_GELU_BF16>(s, p, slots_override, persistent_on, nostore);
         case EPI_DGELU_BF16: return launch_pp<EPI_DGELU_BF16>(s, p, slots_override, persistent_on, nostore);
+        case EPI_F32: return launch_pp<EPI_F32>(s, p, slots_override, persistent_on, nostore);           // class head e = W feats + b, dfeats
+        case EPI_ACC_F32: return launch_pp<EPI_ACC_F32>(s, p, slots_override, persistent_on, nostore);   // dfeats += (box head)
         default: return 1;
     }
 }

@@ -165,3 +165,26 @@ def test_flat_grad_bitwise_repeatable_after_a_full_step(arch, B):
         assert torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2])
         bad = torch.nonzero(got[0] != ref[0]).flatten()
         assert bad.numel() == 0, f"{bad.numel()} gradient elements differ run to run, first at {int(bad[0])}"
+
+
+@pytest.mark.parametrize("N,K,epi", [(512, 768, ops.EPI_F32), (768, 512, ops.EPI_F32), (768, 768, ops.EPI_ACC_F32)])
+def test_gemm_f32_epilogues_pingpong_matches_tile256_bitwise(N, K, epi):
+    """The f32-output epilogues (class head e = W feats + b, d feats and its accumulation) on the ping-pong schedule give the bits of the
+    single-phase kernel's LDS-staged epilogue, every launch."""
+    torch.manual_seed(11)
+    M = 32 * 2304
+    A = torch.randn(ops.pad_rows(M), K, device=DEV).bfloat16()
+    W = (torch.randn(N, K, device=DEV) * 0.05).bfloat16(); bias = torch.randn(N, device=DEV)
+    base = torch.randn(ops.pad_rows(M), N, device=DEV)
+
+    def run(tile):
+        out = base.clone()
+        ops.gemm(epi, A, W, out, bias=bias if epi == ops.EPI_F32 else None, M=M, tile=tile)
+        torch.cuda.synchronize()
+        return out
+
+    ref = run(256)
+    assert not torch.equal(ref[:M], base[:M])
+    for _ in range(6):
+        assert torch.equal(run(8), ref)
+    assert torch.equal(run(0), ref)
