@@ -75,9 +75,10 @@ int owl_attention_fwd_bf16(void* stream, const void* q, const void* k, int64_t l
 /* Same fused attention forward with V read where the QKV GEMM leaves it: `v` = row-major [B*Tp, ld_qkv] (same row stride as q and k),
  * head h at column h*64 of `v`; the [64 key][64 d] tile is transposed by the LDS hardware (ds_read_b64_tr_b16), so the frozen layers
  * need no V^T copy and run ONE N = 3D QKV GEMM (HF5:437-439).  Bit-identical to owl_attention_fwd_bf16 on the same data.
- * variant (per call, no global state): 0 = the library's default sweep; 1 = classic (QK^T -> softmax -> PV of one tile back to back, 3 waves per
- * SIMD); 2 / 3 = software-pipelined sweep (matrix work of tiles i-1 / i+1 beside the softmax of tile i, 2 waves per SIMD; 3 adds issue-order
- * hints).  All variants compute the same operations in the same order: identical bits. */
+ * variant (per call, no global state): 0 = the library's choice; 1 = plain tiling (tokens 0..T-1 in 64-key tiles / 128-query blocks: the bits
+ * of owl_attention_fwd_bf16); 2 = class token peeled: token 0 enters every other query's online softmax as its initial state and is itself
+ * one VALU-only workgroup per (image, head), the tiles cover tokens 1..T-1 -- needs T - 1 a positive multiple of 64 (else rc != 0);
+ * same values as 1 to bf16 round-off (other summation order), 5.8 % faster at T = 2305.  0 picks 2 wherever it is allowed. */
 int owl_attention_fwd_vrow_bf16(void* stream, const void* q, const void* k, const void* v, int64_t ld_qkv, void* out, int64_t ld_out, float* lse, int64_t B, int64_t H, int64_t T, int64_t Tp, float scale, int variant);
 
 /* backward of the fused attention (layers whose attention runs backward): qkv row-major [B*Tp,3D] (q|k|v), dO / O row-major

@@ -30,13 +30,96 @@ __device__ __forceinline__ int swap23(int m) { return (m & ~12) | ((m & 4) << 1)
 // VROW = false: V arrives per head TRANSPOSED (V^T [B][heads*64][Tp], written by a transposing GEMM epilogue or a token transpose).
 // VROW = true : V is read where the QKV GEMM leaves it (row-major, column 2D + h*64 of the qkv rows); the [64 key][64 d] tile is
 //               staged exactly like the K tile and transposed by the LDS hardware (`ds_read_b64_tr_b16`, two per fragment).
-// PIPE (VROW only): the software-pipelined sweep described at `pipe sweep` below (2 waves per SIMD instead of 3: it keeps the
-//               scores of two tiles and the probabilities of two tiles in registers); SCHED adds explicit issue-order hints.
-// OPT (classic structure): "optimistic" sweep -- tile 0 runs the checked tile code, every further tile runs WITHOUT the per-tile row-sum
-//               check, offset MFMA and rescale branch (5 VALU + ~20 SALU instructions and two branches per tile); the verdict is taken
-//               once, on the accumulated row sums, and a workgroup that fails it redoes its query block with the checked sweep.
-template <bool VROW, bool PIPE = false, bool SCHED = false, bool OPT = false>
-__global__ __launch_bounds__(256, PIPE ? 2 : 3) void attn_fwd_kernel(AttnFwdP p) {
+// PEEL (VROW only): token 0 (the class token) is taken out of the tiling.  T = 1 + 48^2 = 2305 is one more than 36 key tiles / 18 query
+//               blocks: tiled as it is, EVERY query block pays a 37th, masked, one-key tile and every (image, head) a 19th query block
+//               with one live query (5.8 % of the launch, tools/attn_peel.py).  Peeled, key 0 enters as the INITIAL STATE of the online
+//               softmax (p0 = exp2(s0), l = p0, O = p0 v0: one 64-long dot product per query on the VALU), the tiles cover tokens 1..T-1
+//               (36 full tiles, no mask code on the path), and query 0 of every (image, head) is one extra, VALU-only workgroup
+//               (attn_cls_row: 2 T dot products of length 64 -- no MFMA tile with 127 dead columns).
+//               (Two more sweeps were built and measured in round 2 -- software-pipelined across tiles, "optimistic" without per-tile
+//               checks -- and removed again: -5..10 % / +0.5 %, profiles/r02_attn_fwd_experiments.md; the code is in history at 22922f6.)
+
+// Query row 0 of one (image, head) against all T keys, on the VALU.  8 lanes per key row (one 16-byte feature chunk each), so the 256
+// threads form 32 row groups; group g runs an online softmax over rows g, g + 32, ... in ONE pass over K and V (6 rows of each per batch,
+// the next batch's 12 loads issued before the current one is consumed: the workgroup is L2-latency-bound, nothing else), then the 32
+// partial states (m, l, O[64]) are merged through LDS in a fixed order: same bits every launch.
+__device__ __forceinline__ void attn_cls_row(const AttnFwdP& p, int b, int h, unsigned char* lds) {
+    constexpr int U = 6;
+    const int tid = threadIdx.x, sub = tid & 7, grp = tid >> 3;
+    const int T = p.T;
+    const int64_t ld = p.ld_qk;
+    const bf16_t* kb = p.k + (int64_t)b * p.Tp * ld + h * 64 + sub * 8;
+    const bf16_t* vb = p.vt + (int64_t)b * p.Tp * ld + h * 64 + sub * 8;
+    float qv[8];
+    {
+        const uint4 qu = *(const uint4*)(p.q + (int64_t)b * p.Tp * ld + h * 64 + sub * 8);
+        const unsigned u[4] = {qu.x, qu.y, qu.z, qu.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) { qv[2 * e] = __uint_as_float(u[e] << 16) * p.scale_log2e; qv[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u) * p.scale_log2e; }
+    }
+    float m = -1e30f, l = 0.f;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    uint4 kq[2][U], vq[2][U];
+    auto fetch = [&](int set, int j0) {          // rows j0 + 32 u (clamped: a row past T is read, not used)
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            int j = j0 + 32 * u; j = j < T ? j : T - 1;
+            kq[set][u] = *(const uint4*)(kb + (int64_t)j * ld);
+            vq[set][u] = *(const uint4*)(vb + (int64_t)j * ld);
+        }
+    };
+    auto consume = [&](int set, int j0) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const unsigned ku[4] = {kq[set][u].x, kq[set][u].y, kq[set][u].z, kq[set][u].w};
+            const unsigned vu[4] = {vq[set][u].x, vq[set][u].y, vq[set][u].z, vq[set][u].w};
+            float d = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; e++) { d += qv[2 * e] * __uint_as_float(ku[e] << 16); d += qv[2 * e + 1] * __uint_as_float(ku[e] & 0xffff0000u); }
+            d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+            if (j0 + 32 * u >= T) d = -1e30f;                    // (every group's first row is a real one: T >= 65)
+            const float mn = fmaxf(m, d);
+            const float alpha = __builtin_amdgcn_exp2f(m - mn), pj = __builtin_amdgcn_exp2f(d - mn);
+            m = mn;
+            l = l * alpha + pj;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                acc[2 * e] = acc[2 * e] * alpha + pj * __uint_as_float(vu[e] << 16);
+                acc[2 * e + 1] = acc[2 * e + 1] * alpha + pj * __uint_as_float(vu[e] & 0xffff0000u);
+            }
+        }
+    };
+    fetch(0, grp);
+    int j0 = grp;
+    for (; j0 + 32 * U < T; j0 += 64 * U) {      // two batches per trip: the register sets are compile-time
+        fetch(1, j0 + 32 * U);
+        consume(0, j0);
+        if (j0 + 64 * U < T) fetch(0, j0 + 64 * U);
+        consume(1, j0 + 32 * U);
+    }
+    if (j0 < T) consume(0, j0);
+    // merge: red[g] = (m, l, O[0..63]) of row group g
+    float* red = (float*)lds;
+    if (sub == 0) { red[grp * 66] = m; red[grp * 66 + 1] = l; }
+#pragma unroll
+    for (int e = 0; e < 8; e++) red[grp * 66 + 2 + sub * 8 + e] = acc[e];
+    __syncthreads();
+    if (tid < 64) {
+        float mm = red[0];
+        for (int g = 1; g < 32; g++) mm = fmaxf(mm, red[g * 66]);
+        float lt = 0.f, o = 0.f;
+        for (int g = 0; g < 32; g++) {
+            const float sc = __builtin_amdgcn_exp2f(red[g * 66] - mm);
+            lt += red[g * 66 + 1] * sc;
+            o += red[g * 66 + 2 + tid] * sc;
+        }
+        p.out[(int64_t)b * p.Tp * p.ld_out + h * 64 + tid] = f2bf(o / lt);
+        if (p.lse && tid == 0) p.lse[((int64_t)b * p.H + h) * p.Tp] = mm + __builtin_amdgcn_logf(lt);
+    }
+}
+
+template <bool VROW, bool PEEL = false>
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
     // dynamic LDS (one object): with a static array hipcc drains the just-issued LDS-DMA (vmcnt(0)) before the
     // first ds_read of every tile
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -52,20 +135,38 @@ __global__ __launch_bounds__(256, PIPE ? 2 : 3) void attn_fwd_kernel(AttnFwdP p)
     if (pair >= p.B * p.H) return;
     const int qb = idx - (idx / p.nqb) * p.nqb;
     const int b = pair / p.H, h = pair - b * p.H;
+    static_assert(VROW || !PEEL, "the peeled tiling shifts the key rows by one: row-major V only");
+    if constexpr (PEEL) {
+        if (qb == p.nqb - 1) { attn_cls_row(p, b, h, lds); return; }       // workgroup-uniform
+    }
+    // the tiles cover tokens PEEL .. T-1: Tk keys / queries, tile-local index + PEEL = token
+    const int Tk = p.T - (PEEL ? 1 : 0);
     const int q0 = qb * 128 + w * 32;
     const float c = p.scale_log2e;
 
     // ---- Q fragments (B operand of S^T = K Q^T): lane -> query row q0 + (lane&31), 8 d per chunk
     int qrow = q0 + (lane & 31);
-    if (qrow >= p.T) qrow = p.T - 1;
+    if (qrow >= Tk) qrow = Tk - 1;
+    if constexpr (PEEL) qrow += 1;
     const bf16_t* qp = p.q + ((int64_t)b * p.Tp + qrow) * p.ld_qk + h * 64;
     bf16x8 qf[4];
 #pragma unroll
     for (int kc = 0; kc < 4; kc++) qf[kc] = *(const bf16x8*)(qp + kc * 16 + hi * 8);
+    // (peeled) row 0 of K and V, requested together with Q: consumed only after the first tile's staging has been issued
+    uint4 k0u[4];
+    unsigned short v0u[2];
+    if constexpr (PEEL) {
+        const bf16_t* k0p = p.k + (int64_t)b * p.Tp * p.ld_qk + h * 64;
+        const bf16_t* v0p = p.vt + (int64_t)b * p.Tp * p.ld_qk + h * 64;
+#pragma unroll
+        for (int kc = 0; kc < 4; kc++) k0u[kc] = *(const uint4*)(k0p + kc * 16 + hi * 8);      // (one address per half-wave)
+#pragma unroll
+        for (int d = 0; d < 2; d++) v0u[d] = v0p[d * 32 + (lane & 31)];
+    }
 
     // ---- staging sources: wave w stages rows [w*16, w*16+16) of both tiles (2 DMA each) --------
-    const bf16_t* kbase = p.k + (int64_t)b * p.Tp * p.ld_qk + h * 64;
-    const bf16_t* vbase = VROW ? p.vt + (int64_t)b * p.Tp * p.ld_qk + h * 64
+    const bf16_t* kbase = p.k + ((int64_t)b * p.Tp + (PEEL ? 1 : 0)) * p.ld_qk + h * 64;
+    const bf16_t* vbase = VROW ? p.vt + ((int64_t)b * p.Tp + (PEEL ? 1 : 0)) * p.ld_qk + h * 64
                                : p.vt + (int64_t)b * p.vt_img_stride + (int64_t)h * 64 * p.Tp;
     // Per-lane byte offsets of this lane's two DMA rows inside a 64-key tile (K) / inside the head's V^T block; the
     // tile's own offset is wave-uniform and is added on the scalar unit, so staging costs no VALU work per tile
@@ -104,7 +205,7 @@ __global__ __launch_bounds__(256, PIPE ? 2 : 3) void attn_fwd_kernel(AttnFwdP p)
             const int r = r0 + (lane >> 3);
             const int ch = (lane & 7) ^ ((r >> 1) & 7);
             int key = kv * 64 + r;
-            if (key >= p.T) key = p.T - 1;
+            if (key >= Tk) key = Tk - 1;
             // (32-bit buffer offsets: 64-bit per-lane pointers here get hoisted out of the tile loop and spilled across it)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, LPTR(base + r0 * 128), 16, (key * (int)p.ld_qk + ch * 8) * 2, 0, 0, 0);
             if constexpr (VROW)          // same clamp as K: a row past T would be multiplied by P = 0, but must be finite
@@ -112,39 +213,6 @@ __global__ __launch_bounds__(256, PIPE ? 2 : 3) void attn_fwd_kernel(AttnFwdP p)
                                                          (key * (int)p.ld_qk + ((lane & 7) ^ swz_vrow(r)) * 8) * 2, 0, 0, 0);
             else                         // reads past T are finite junk, masked by P = 0
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, LPTR(base + 8192 + r0 * 128), 16, (r * p.Tp + ch * 8) * 2, kv * 128, 0, 0);
-        }
-    };
-
-    // K-only / V-only staging of one tile (pipelined sweep: K runs two tiles ahead of V); `clamp` = the partial last tile
-    auto stage_k = [&](int buf, int kv, bool clamp) {
-        unsigned char* base = lds + buf * 16384;
-#pragma unroll
-        for (int qd = 0; qd < 2; qd++) {
-            const int r0 = w * 8 + qd * 32;
-            if (!clamp) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, LPTR(base + r0 * 128), 16, (int)k_voff, kv * k_tile_bytes + qd * (k_tile_bytes >> 1), 0, 0);
-            } else {
-                const int r = r0 + (lane >> 3);
-                const int ch = (lane & 7) ^ ((r >> 1) & 7);
-                int key = kv * 64 + r;
-                if (key >= p.T) key = p.T - 1;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, LPTR(base + r0 * 128), 16, (key * (int)p.ld_qk + ch * 8) * 2, 0, 0, 0);
-            }
-        }
-    };
-    auto stage_v = [&](int buf, int kv, bool clamp) {          // VROW layout only
-        unsigned char* base = lds + buf * 16384 + 8192;
-#pragma unroll
-        for (int qd = 0; qd < 2; qd++) {
-            const int r0 = w * 8 + qd * 32;
-            if (!clamp) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, LPTR(base + r0 * 128), 16, (int)v_voff, kv * k_tile_bytes + qd * (k_tile_bytes >> 1), 0, 0);
-            } else {
-                const int r = r0 + (lane >> 3);
-                int key = kv * 64 + r;
-                if (key >= p.T) key = p.T - 1;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, LPTR(base + r0 * 128), 16, (key * (int)p.ld_qk + ((lane & 7) ^ swz_vrow(r)) * 8) * 2, 0, 0, 0);
-            }
         }
     };
 
@@ -225,15 +293,14 @@ __global__ __launch_bounds__(256, PIPE ? 2 : 3) void attn_fwd_kernel(AttnFwdP p)
     // one KV tile: S^T = K Q^T (+C), online softmax, O^T += V^T P^T.  BUF is a compile-time buffer index so that the
     // stage offset folds into the ds_read immediate; MASK only for the (peeled) partial last tile; FIRST forces the
     // explicit-maximum path.
-    auto tile = [&](auto buf_tag, int kv, auto mask_tag, bool first, auto opt_tag) {
+    auto tile = [&](auto buf_tag, int kv, auto mask_tag, bool first) {
         constexpr int BUF = decltype(buf_tag)::value;
         constexpr bool MASK = decltype(mask_tag)::value;
-        constexpr bool NOCHECK = decltype(opt_tag)::value;      // optimistic tile: no offset, no row-sum check, no rescale path
         typedef const __attribute__((address_space(3))) bf16x8* frag_ptr;
         f32x16 s[2];
         // the partial last tile often holds very few keys (T = 2305 = 36*64 + 1): when they all sit in its first 32-key
         // half, the second score tile is skipped altogether (its P is 0)
-        const bool half_only = MASK && (p.T - kv * 64 <= 32);
+        const bool half_only = MASK && (Tk - kv * 64 <= 32);
         // the tile's eight K fragments are requested up front: the two score chains then run back to back on counted
         // lgkmcnt waits instead of read -> wait -> MFMA per fragment (and the slow path reuses the registers)
         bf16x8 kfr[2][4];
@@ -260,22 +327,13 @@ __global__ __launch_bounds__(256, PIPE ? 2 : 3) void attn_fwd_kernel(AttnFwdP p)
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
                         const int key = kv * 64 + t * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
-                        if (key >= p.T || (t == 1 && half_only)) s[t][r] = -INFINITY;
+                        if (key >= Tk || (t == 1 && half_only)) s[t][r] = -INFINITY;
                     }
             }
         };
-        bool slow = !NOCHECK && ((p.dbg & 1) || (first && (p.dbg & 4)));    // (bit 2: old behaviour, the first tile always sets the offset)
+        bool slow = (p.dbg & 1) || (first && (p.dbg & 4));    // (bit 2: old behaviour, the first tile always sets the offset)
         float ts = 0.f;
-        if constexpr (NOCHECK) {
-            qk(std::false_type{});
-#pragma unroll
-            for (int t = 0; t < 2; t++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    s[t][r] = __builtin_amdgcn_exp2f(s[t][r]);
-                    ts += s[t][r];
-                }
-        } else if (!slow) {
+        if (!slow) {
             if (have_m) qk(std::true_type{}); else qk(std::false_type{});      // s = score*c - M   (M = 0: no offset MFMA)
 #pragma unroll
             for (int t = 0; t < 2; t++)
@@ -287,7 +345,7 @@ __global__ __launch_bounds__(256, PIPE ? 2 : 3) void attn_fwd_kernel(AttnFwdP p)
             // 2^40: P may have overflowed (or is about to); first tile only: 2^-60, the whole row may be about to underflow
             slow = __any(!(ts <= 1.0995116e12f) || (first && ts < 8.6736174e-19f));
         }
-        if (!NOCHECK && slow) {                                  // wave-uniform
+        if (slow) {                                              // wave-uniform
             qk(std::false_type{});                               // s = score*c
             float mx = s[0][0];
 #pragma unroll
@@ -343,8 +401,8 @@ __global__ __launch_bounds__(256, PIPE ? 2 : 3) void attn_fwd_kernel(AttnFwdP p)
         __builtin_amdgcn_s_setprio(0);
     };
 
-    const int nkv = (p.T + 63) / 64;
-    const int nfull = p.T / 64;          // tiles with no key >= T
+    const int nkv = PEEL ? Tk / 64 : (Tk + 63) / 64;
+    const int nfull = Tk / 64;           // tiles with no key >= Tk
     // Every wave must have its LDS reads RETURNED (lgkmcnt(0)), not merely issued, before the barrier: hipcc may
     // sink the MFMAs that consume the tile's last ds_reads below the barrier, and under a loaded LDS pipeline such a
     // read can still be queued when another wave's post-barrier LDS-DMA (250-400 cycles, L2-warm) lands in the same
@@ -358,338 +416,61 @@ __global__ __launch_bounds__(256, PIPE ? 2 : 3) void attn_fwd_kernel(AttnFwdP p)
     using B1 = std::integral_constant<int, 1>;
     // a wave whose 32 queries all lie beyond T (the last query block of T = 2305 has ONE valid query: three of its four
     // waves) only takes part in the staging and the barriers
-    const bool active = q0 < p.T;
-    bool run_classic = true;
-
-    // ---- pipe sweep -----------------------------------------------------------------------------------------------------
-    // The classic sweep below runs QK^T -> exp -> PV of ONE tile back to back: inside a wave every phase waits for the one
-    // before it, and only the SIMD's other waves fill the gaps (PMC: matrix pipe 54 %, VALU 62 % busy, 39 % of the wave cycles
-    // in issue stalls).  Here the three phases of a tile are spread over three iterations so that the matrix work and the VALU
-    // work inside one iteration are INDEPENDENT of each other:
-    //     iteration i:   matrix pipe:  O += V(i-1)^T P(i-1)^T   and   S(i+1) = K(i+1) Q^T        (16 MFMAs)
-    //                    VALU:         P(i) = exp2(S(i)), row sums, bf16 packing                  (~85 instructions)
-    // K is staged two tiles ahead of V (K(i+2) and V(i) share stage buffer i&1 while iteration i reads buffer (i+1)&1).
-    // The sweep runs WITHOUT a softmax offset (scores of ordinary size: the whole row is exponentiated as it is, exactly the
-    // classic sweep's fast path, same operations in the same order -> same bits).  A row sum that overflows (or a first tile
-    // about to underflow) only raises a flag here; if any wave of the workgroup raised it, the whole workgroup redoes its query
-    // block with the classic sweep, which owns the offset / rescale logic.
-    if constexpr (PIPE) {
-        static_assert(VROW, "the pipelined sweep reads V row-major");
-        typedef const __attribute__((address_space(3))) bf16x8* frag_ptr;
-        volatile int* wg_flag = (volatile int*)(lds + 4 * 16384);
-        if (threadIdx.x == 0) *wg_flag = 0;
-        uint4 pE[4], pO[4];             // packed bf16 probabilities of the even / odd tiles, [16-key chunk]
-        bool bad = false;
-        const int n = nkv;
-        const bool partial = nkv > nfull;
-        const bool half_last = partial && (p.T - nfull * 64 <= 32);    // the partial tile's keys all sit in its first half
-        auto k_read = [&](auto buf_tag, auto t_tag, bf16x8 (&kf)[4]) {          // the four K fragments of 32-key half t
-            constexpr int BUF = decltype(buf_tag)::value, t = decltype(t_tag)::value;
-#pragma unroll
-            for (int kc = 0; kc < 4; kc++) kf[kc] = *(frag_ptr)(uintptr_t)(k_addr[t][kc] + BUF * 16384);
-        };
-        auto qk_mma = [&](f32x16& sc, const bf16x8 (&kf)[4]) {
-#pragma unroll
-            for (int kc = 0; kc < 4; kc++) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kc], qf[kc], kc == 0 ? zero16 : sc, 0, 0, 0);
-        };
-        // V fragments by hand-issued transpose-reads: behind an LDS-DMA hipcc makes every ds_read_tr builtin wait for vmcnt(0), i.e.
-        // for the stage that was issued a few instructions earlier (the classic sweep pays that wait only at the END of a tile).  The
-        // asm loads are invisible to that logic; their completion is waited for by `tr_wait` (lgkmcnt(0) with the destination registers
-        // as read-write operands, so no consumer can be scheduled above it).  c8 = 16-key chunk, two 32-feature blocks each.
-        auto tr_issue = [&](auto buf_tag, auto c8_tag, s16x4_t (&f)[2][2]) {
-            constexpr int OFF = decltype(c8_tag)::value * 2048 + decltype(buf_tag)::value * 16384;
-#pragma unroll
-            for (int d = 0; d < 2; d++) {
-                const unsigned a0 = v_addr[d][0], a1 = v_addr[d][1];
-                s16x4_t lo, hh;
-                asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%4\n\tds_read_b64_tr_b16 %1, %3 offset:%4"
-                             : "=&v"(lo), "=&v"(hh) : "v"(a0), "v"(a1), "i"(OFF));
-                f[d][0] = lo; f[d][1] = hh;
-            }
-        };
-        auto tr_wait = [&](s16x4_t (&f)[2][2], s16x4_t (&g)[2][2]) {
-            s16x4_t a = f[0][0], b = f[0][1], c = f[1][0], d = f[1][1], e = g[0][0], h = g[0][1], i = g[1][0], j = g[1][1];
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(h), "+v"(i), "+v"(j));
-            f[0][0] = a; f[0][1] = b; f[1][0] = c; f[1][1] = d; g[0][0] = e; g[0][1] = h; g[1][0] = i; g[1][1] = j;
-        };
-        auto pv_mma = [&](const uint4& pw, const s16x4_t (&f)[2][2]) {
-            const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
-#pragma unroll
-            for (int d = 0; d < 2; d++) {
-                const bf16x8 vf = __builtin_shufflevector(f[d][0], f[d][1], 0, 1, 2, 3, 4, 5, 6, 7);
-                o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
-            }
-        };
-        using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>;
-        using C2 = std::integral_constant<int, 2>; using C3 = std::integral_constant<int, 3>;
-        // the drain after the last iteration (and nothing else) may skip the second half of a partial tile
-        auto pv = [&](auto buf_tag, const uint4 (&pw)[4], bool skip_t1) {
-            s16x4_t fa[2][2], fb[2][2];
-            tr_issue(buf_tag, C0{}, fa); tr_issue(buf_tag, C1{}, fb);
-            tr_wait(fa, fb);
-            pv_mma(pw[0], fa); pv_mma(pw[1], fb);
-            if (skip_t1) return;
-            tr_issue(buf_tag, C2{}, fa); tr_issue(buf_tag, C3{}, fb);
-            tr_wait(fa, fb);
-            pv_mma(pw[2], fa); pv_mma(pw[3], fb);
-        };
-        // softmax of one quarter of a tile (8 of the lane's 32 keys): exp2, running row sum (same summation order as the classic
-        // sweep: t, then register), bf16 packing -- 8 v_exp + 8 v_add + 4 v_cvt_pk
-        auto sm_part = [&](auto t_tag, auto cc_tag, f32x16 (&sc)[2], uint4 (&pw)[4], float& ts) {
-            constexpr int t = decltype(t_tag)::value, cc = decltype(cc_tag)::value;
-            float e[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                e[j] = __builtin_amdgcn_exp2f(sc[t][cc * 8 + j]);
-                ts += e[j];
-            }
-            pw[t * 2 + cc] = make_uint4(pack_bf2(e[0], e[1]), pack_bf2(e[2], e[3]), pack_bf2(e[4], e[5]), pack_bf2(e[6], e[7]));
-        };
-        // issue-order hint for one segment: four MFMAs, five VALU instructions behind each (a 32x32x16 MFMA occupies the matrix pipe
-        // for 32 cycles, about five single-issue instructions of the same wave -- MI355X_MICROARCH.md)
-        auto seg_hint = [&]() {
-            if constexpr (SCHED) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-                }
-            }
-        };
-        // One iteration = four segments of 4 MFMAs + one softmax quarter (20 VALU) each, hard scheduling boundaries between them (the
-        // compiler interleaves inside a segment).  Carried from iteration to iteration: sc[0] = S(i) half 0 (complete), kp = the K
-        // fragments of S(i) half 1 whose four MFMAs are still PENDING (they only need registers, so they may run after the barrier that
-        // hands the K buffer back to the DMA) -- that way the scores of ONE tile (32 registers) are all that is ever live:
-        //   S0  QK(i) half 1 -> sc[1]             | softmax(i) quarter 0 (sc[0])   | V(i-1) reads c0,c1; K(i+1) half-0 reads
-        //   S1  PV(i-1) chunks 0,1                | softmax(i) quarter 1 (sc[0])   | V(i-1) reads c2,c3; K(i+1) half-1 reads -> kp
-        //   S2  QK(i+1) half 0 -> sc[0] (dead)    | softmax(i) quarter 2 (sc[1])
-        //   S3  PV(i-1) chunks 2,3                | softmax(i) quarter 3 (sc[1]), overflow check
-        auto body = [&](auto rb_tag, f32x16 (&sc)[2], bf16x8 (&kp)[4], uint4 (&p_out)[4], const uint4 (&p_in)[4], auto pv_tag, auto qk_tag,
-                        auto mask_tag, int kv_cur) {
-            constexpr bool PV = decltype(pv_tag)::value, QK = decltype(qk_tag)::value, MASK = decltype(mask_tag)::value;
-            using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-            auto mask_half = [&](int t) {
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int key = kv_cur * 64 + t * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
-                    if (key >= p.T || (t == 1 && half_last)) sc[t][r] = -INFINITY;
-                }
-            };
-            s16x4_t fa[2][2], fb[2][2];
-            bf16x8 k0[4];
-            float ts = 0.f;
-            // S0
-            if constexpr (MASK) mask_half(0);
-            if constexpr (PV) { tr_issue(rb_tag, C0{}, fa); tr_issue(rb_tag, C1{}, fb); }
-            qk_mma(sc[1], kp);
-            if constexpr (QK) k_read(rb_tag, I0{}, k0);
-            sm_part(I0{}, I0{}, sc, p_out, ts);
-            seg_hint();
-            __builtin_amdgcn_sched_barrier(0);
-            // S1
-            if constexpr (PV) {
-                tr_wait(fa, fb);
-                pv_mma(p_in[0], fa); pv_mma(p_in[1], fb);
-                tr_issue(rb_tag, C2{}, fa); tr_issue(rb_tag, C3{}, fb);
-            }
-            if constexpr (QK) k_read(rb_tag, I1{}, kp);
-            sm_part(I0{}, I1{}, sc, p_out, ts);
-            if constexpr (PV) seg_hint();
-            __builtin_amdgcn_sched_barrier(0);
-            // S2
-            if constexpr (MASK) mask_half(1);
-            float ts1 = ts;
-            sm_part(I1{}, I0{}, sc, p_out, ts1);
-            if constexpr (QK) { qk_mma(sc[0], k0); seg_hint(); }
-            __builtin_amdgcn_sched_barrier(0);
-            // S3
-            if constexpr (PV) {
-                tr_wait(fa, fb);
-                pv_mma(p_in[2], fa); pv_mma(p_in[3], fb);
-            }
-            sm_part(I1{}, I1{}, sc, p_out, ts1);
-            if constexpr (PV) seg_hint();
-            // the classic sweep's check: 2^40 (P may have overflowed); first tile only: 2^-60 (the row may be about to underflow)
-            bad |= (bool)__any(!(ts1 <= 1.0995116e12f) || (kv_cur == 0 && ts1 < 8.6736174e-19f));
-            l_part += ts1;
-        };
-        using T1 = std::true_type;
-        using F0 = std::false_type;
-        using B2 = std::integral_constant<int, 2>;
-        using B3 = std::integral_constant<int, 3>;
-        // Stage ring of FOUR buffers: slot j&3 holds K(j) and V(j-2).  Iteration i reads slot (i+1)&3 and issues K(i+3), V(i+1) into
-        // slot (i+3)&3 (last read two iterations ago), so every LDS-DMA piece has two iterations to land and the end-of-iteration wait
-        // is a COUNTED vmcnt(4): this iteration's four pieces stay in flight across the barrier.
-        auto stage_for = [&](int i) -> int {     // returns the number of pieces issued by this wave
-            int np = 0;
-            if (i + 3 < n) { stage_k((i + 3) & 3, i + 3, i + 3 >= nfull); np += 2; }
-            if (i + 1 < n) { stage_v((i + 3) & 3, i + 1, i + 1 >= nfull); np += 2; }
-            return np;
-        };
-        auto sync_keep4 = [&]() {                // steady state: everything but the newest four pieces has landed
-            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-        };
-        // dispatch on the (runtime) iteration index to the compile-time (slot, parity) instance: slot read = (i+1)&3, odd i writes pO
-        auto run_body = [&](int i, f32x16 (&sc_)[2], bf16x8 (&kp_)[4], auto pv_tag, auto qk_tag, auto mask_tag) {
-            switch ((i + 1) & 3) {
-                case 0: body(B0{}, sc_, kp_, pO, pE, pv_tag, qk_tag, mask_tag, i); break;       // i = 3 (mod 4)
-                case 1: body(B1{}, sc_, kp_, pE, pO, pv_tag, qk_tag, mask_tag, i); break;       // i = 0
-                case 2: body(B2{}, sc_, kp_, pO, pE, pv_tag, qk_tag, mask_tag, i); break;       // i = 1
-                default: body(B3{}, sc_, kp_, pE, pO, pv_tag, qk_tag, mask_tag, i); break;      // i = 2
-            }
-        };
-        f32x16 sc[2];
-        bf16x8 kp[4];
-        // prologue: K(0) -> slot 0, K(1) -> slot 1, K(2) + V(0) -> slot 2; S(0) half 0, half-1 fragments pending
-        stage_k(0, 0, nfull < 1);
-        if (n > 1) stage_k(1, 1, nfull < 2);
-        if (n > 2) stage_k(2, 2, nfull < 3);
-        stage_v(2, 0, nfull < 1);
-        sync();
-        {
-            bf16x8 k0[4];
-            k_read(B0{}, std::integral_constant<int, 0>{}, k0);
-            k_read(B0{}, std::integral_constant<int, 1>{}, kp);
-            if (active) qk_mma(sc[0], k0);
-        }
-        // iteration 0: no PV yet
-        stage_for(0);
-        if (active) {
-            if (n == 1) {
-                if (partial) run_body(0, sc, kp, F0{}, F0{}, T1{});
-                else run_body(0, sc, kp, F0{}, F0{}, F0{});
-            } else {
-                run_body(0, sc, kp, F0{}, T1{}, F0{});
-            }
-        }
-        sync();
-        int i = 1;
-        // steady state, four iterations per trip (i = 1 mod 4): every tile touched is a full one -> branch-free staging, compile-time
-        // slots, counted waits
-        for (; i + 6 < nfull; i += 4) {
-            stage_k(0, i + 3, false); stage_v(0, i + 1, false);
-            if (active) body(B2{}, sc, kp, pO, pE, T1{}, T1{}, F0{}, i);
-            sync_keep4();
-            stage_k(1, i + 4, false); stage_v(1, i + 2, false);
-            if (active) body(B3{}, sc, kp, pE, pO, T1{}, T1{}, F0{}, i + 1);
-            sync_keep4();
-            stage_k(2, i + 5, false); stage_v(2, i + 3, false);
-            if (active) body(B0{}, sc, kp, pO, pE, T1{}, T1{}, F0{}, i + 2);
-            sync_keep4();
-            stage_k(3, i + 6, false); stage_v(3, i + 4, false);
-            if (active) body(B1{}, sc, kp, pE, pO, T1{}, T1{}, F0{}, i + 3);
-            sync_keep4();
-        }
-        for (; i + 1 < n; i++) {                 // the last few iterations before the final one: clamped staging, plain waits
-            stage_for(i);
-            if (active) run_body(i, sc, kp, T1{}, T1{}, F0{});
-            sync();
-        }
-        if (n >= 2) {                            // final iteration (i == n-1): PV(n-2), softmax(n-1) (masked if partial), no QK
+    const bool active = q0 < Tk;
+    {
+        // (peeled: the host only selects it when Tk is a multiple of 64 -- no partial tile, no clamped staging, no mask code)
+        if (PEEL || nfull > 0) stage(0, 0); else stage_clamped(0, 0);
+        if constexpr (PEEL) {
+            // Key 0 as the initial state, on the matrix pipe (the kernel is VALU-bound: as VALU dot products this cost two tiles' worth of
+            // VALU issue per wave).  s0: four MFMAs against a K fragment whose only non-zero row is row 0 = k0 -> register 0 of the lanes
+            // with hi == 0.  Ordinary scores (|s0| <= 40) leave the offset at 0 like the first tile's fast path; anything else (or inf /
+            // NaN) makes s0 the offset -- what the slow path of a first tile would do with a one-key tile.  O = v0 p0: two MFMAs with
+            // contraction slot 0 (= key 0) the only live one.
             if (active) {
-                if (partial) run_body(i, sc, kp, T1{}, F0{}, T1{});
-                else run_body(i, sc, kp, T1{}, F0{}, F0{});
+                const bool row0 = (lane & 31) == 0;
+                f32x16 s0t = zero16;
+#pragma unroll
+                for (int kc = 0; kc < 4; kc++) {
+                    const uint4 kz = row0 ? k0u[kc] : make_uint4(0u, 0u, 0u, 0u);
+                    s0t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kz), qf[kc], s0t, 0, 0, 0);
+                }
+                const float s0 = __shfl(s0t[0], lane & 31, 64);   // both half-waves carry the same offset
+                if (__any(!(fabsf(s0) <= 40.f)) || (p.dbg & 5)) {
+                    M = bf2f(f2bf(s0));
+                    have_m = true;
+                    qn4.x = hi == 0 ? (unsigned)f2bf(-M) : 0u;
+                    qneg = __builtin_bit_cast(bf16x8, qn4);
+                }
+                const float p0 = __builtin_amdgcn_exp2f(s0 - M);
+                l_part = hi == 0 ? p0 : 0.f;                      // the two half-waves' sums are added in the epilogue
+                const uint4 pz = make_uint4(hi == 0 ? (unsigned)f2bf(p0) : 0u, 0u, 0u, 0u);
+#pragma unroll
+                for (int d = 0; d < 2; d++) {
+                    const uint4 vz = make_uint4(hi == 0 ? (unsigned)v0u[d] : 0u, 0u, 0u, 0u);
+                    o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vz), __builtin_bit_cast(bf16x8, pz), zero16, 0, 0, 0);
+                }
             }
-            sync();
         }
-        if (active) {                            // drain: PV(n-1), V(n-1) sits in slot (n+1)&3
-            switch ((n + 1) & 3) {
-                case 0: pv(B0{}, ((n - 1) & 1) ? pO : pE, half_last); break;
-                case 1: pv(B1{}, ((n - 1) & 1) ? pO : pE, half_last); break;
-                case 2: pv(B2{}, ((n - 1) & 1) ? pO : pE, half_last); break;
-                default: pv(B3{}, ((n - 1) & 1) ? pO : pE, half_last); break;
-            }
-        }
-        // workgroup-uniform verdict (one LDS word behind the stage buffers)
-        if (bad && lane == 0) *wg_flag = 1;
-        sync();
-        run_classic = __builtin_amdgcn_readfirstlane(*wg_flag) != 0;
-        if (run_classic) {                       // redo the whole query block with the offset-capable sweep
-            sync();
-            l_part = 0.f;
-#pragma unroll
-            for (int d = 0; d < 2; d++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) o[d][r] = 0.f;
-        }
-    }
-
-    // ---- optimistic sweep (classic structure, 3 waves per SIMD) -------------------------------------------------------------
-    if constexpr (OPT && !PIPE) {
-        volatile int* wg_flag = (volatile int*)(lds + 2 * 16384);
-        if (threadIdx.x == 0) *wg_flag = 0;
-        using T1 = std::true_type;
-        using F0 = std::false_type;
-        const bool partial = nkv > nfull;
-        if (nfull > 0) stage(0, 0); else stage_clamped(0, 0);
-        sync();
-        // tile 0 through the checked code (first-tile rule: a row about to underflow, or to overflow, sets an offset -> verdict "bad")
-        if (nkv > 1) { if (nfull > 1) stage(1, 1); else stage_clamped(1, 1); }
-        if (active) { if (nkv == 1 && partial) tile(B0{}, 0, T1{}, true, F0{}); else tile(B0{}, 0, F0{}, true, F0{}); }
-        const bool bad0 = have_m;
-        sync();
-        int kv = 1;
-        for (; kv + 1 < nfull; kv += 2) {          // kv odd: buffers 1, 0
-            stage(0, kv + 1);
-            if (active) tile(B1{}, kv, F0{}, false, T1{});
-            sync();
-            if (kv + 2 < nfull) stage(1, kv + 2); else if (kv + 2 < nkv) stage_clamped(1, kv + 2);
-            if (active) tile(B0{}, kv + 1, F0{}, false, T1{});
-            sync();
-        }
-        if (kv < nfull) {                           // one more full tile (kv odd -> buffer 1)
-            if (kv + 1 < nkv) stage_clamped(0, kv + 1);
-            if (active) tile(B1{}, kv, F0{}, false, T1{});
-            sync();
-            kv++;
-        }
-        if (kv < nkv && active) {                   // the partial tile
-            if (kv & 1) tile(B1{}, kv, T1{}, false, T1{}); else tile(B0{}, kv, T1{}, false, T1{});
-        }
-        // verdict on the accumulated row sums: every tile's row sum is positive, so l_part <= 2^40 implies that no tile's check would
-        // have fired (stricter than the per-tile rule: a redo costs time, never bits); inf / NaN fail the comparison too
-        const bool bad = bad0 || (active && __any(!(l_part <= 1.0995116e12f)));
-        if (bad && lane == 0) *wg_flag = 1;
-        sync();
-        run_classic = __builtin_amdgcn_readfirstlane(*wg_flag) != 0;
-        if (run_classic) {
-            sync();
-            l_part = 0.f;
-#pragma unroll
-            for (int d = 0; d < 2; d++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) o[d][r] = 0.f;
-        }
-    }
-
-    if (run_classic) {
-        if constexpr (PIPE || OPT) {      // (re-)establish the classic sweep's state here, so that none of it is live across the pipelined sweep
-            M = 0.f; have_m = false;
-            qn4 = make_uint4(0u, 0u, 0u, 0u); qneg = __builtin_bit_cast(bf16x8, qn4);
-            ones4 = make_uint4(hi == 0 ? 0x3F80u : 0u, 0u, 0u, 0u); kones = __builtin_bit_cast(bf16x8, ones4);
-        }
-        if (nfull > 0) stage(0, 0); else stage_clamped(0, 0);
         sync();
         int kv = 0;
         for (; kv + 1 < nfull; kv += 2) {          // two tiles per trip: buffer index is a compile-time constant
             stage(1, kv + 1);
-            if (active) tile(B0{}, kv, std::false_type{}, kv == 0, std::false_type{});
+            if (active) tile(B0{}, kv, std::false_type{}, !PEEL && kv == 0);
             sync();
-            if (kv + 2 < nfull) stage(0, kv + 2); else if (kv + 2 < nkv) stage_clamped(0, kv + 2);
-            if (active) tile(B1{}, kv + 1, std::false_type{}, false, std::false_type{});
+            if (kv + 2 < nfull) stage(0, kv + 2);
+            else if (!PEEL && kv + 2 < nkv) stage_clamped(0, kv + 2);
+            if (active) tile(B1{}, kv + 1, std::false_type{}, false);
             sync();
         }
         // remainder: at most one full tile and/or the partial tile, buffers alternate from (kv & 1)
         if (kv < nfull) {                           // kv even here -> buffer 0
-            if (kv + 1 < nkv) stage_clamped(1, kv + 1);          // kv + 1 == nfull: the partial tile
-            if (active) tile(B0{}, kv, std::false_type{}, kv == 0, std::false_type{});
+            if (!PEEL && kv + 1 < nkv) stage_clamped(1, kv + 1);          // kv + 1 == nfull: the partial tile
+            if (active) tile(B0{}, kv, std::false_type{}, !PEEL && kv == 0);
             sync();
             kv++;
         }
-        if (kv < nkv && active) {
-            if (kv & 1) tile(B1{}, kv, std::true_type{}, false, std::false_type{}); else tile(B0{}, kv, std::true_type{}, kv == 0, std::false_type{});
+        if (!PEEL && kv < nkv && active) {
+            if (kv & 1) tile(B1{}, kv, std::true_type{}, false); else tile(B0{}, kv, std::true_type{}, !PEEL && kv == 0);
         }
     }
     const float l_run = l_part;
@@ -702,7 +483,7 @@ __global__ __launch_bounds__(256, PIPE ? 2 : 3) void attn_fwd_kernel(AttnFwdP p)
     // 30 MB of scratch written and read back per launch (PMC: WRITE_SIZE 143 MB for 114 MB of output).
     int q0e = q0, be = b, he = h;
     asm volatile("" : "+s"(q0e), "+s"(be), "+s"(he));
-    const int qr = q0e + (lane & 31);
+    const int qr = q0e + (lane & 31) + (PEEL ? 1 : 0);        // token
     uint4 st[2][2];
     pack_token_rows(o, inv, st);                    // 16-byte stores (common.h)
     if (qr < p.T) {
@@ -722,40 +503,28 @@ extern "C" int owl_attention_debug(int flags) { g_attn_dbg = flags; return 0; }
 static constexpr int g_attn_dbg = 0;
 #endif
 
-static constexpr int ATTN_DEFAULT_VARIANT = 1;      // what variant 0 resolves to for row-major V (1 classic, 2 pipelined, 3 pipelined + issue-order hints)
-
+// variant: 0 = the library's choice (peeled wherever it can be), 1 = plain tiling, 2 = peeled (row-major V, T - 1 a positive multiple of 64)
 static int attn_fwd_launch(void* stream, const void* q, const void* k, int64_t ld_qk, const void* v, int v_row_major,
                            int64_t vt_img_stride, void* out, int64_t ld_out, float* lse, int64_t B, int64_t H, int64_t T,
                            int64_t Tp, float scale, int variant) {
     OWL_CHECK_ARG(q && k && v && out, "owl_attention_fwd_bf16: null pointer");
     OWL_CHECK_ARG(ld_qk % 8 == 0 && ld_out % 8 == 0 && Tp % 8 == 0 && T > 0 && T <= Tp, "owl_attention_fwd_bf16: bad strides (ld_qk %% 8, ld_out %% 8, Tp %% 8)");
+    OWL_CHECK_ARG(variant >= 0 && variant <= 2 && (variant <= 1 || v_row_major), "owl_attention_fwd: variant must be 0 (default), 1 (plain tiling) or 2 (class token peeled; row-major V only)");
+    const bool can_peel = v_row_major && T >= 65 && (T - 1) % 64 == 0;
+    OWL_CHECK_ARG(variant != 2 || can_peel, "owl_attention_fwd: variant 2 (peeled) needs row-major V and T - 1 a positive multiple of 64");
+    const bool peel = variant == 2 || (variant == 0 && can_peel);
     AttnFwdP p{};
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.ld_qk = ld_qk;
     p.vt = (const bf16_t*)v; p.vt_img_stride = vt_img_stride;
     p.out = (bf16_t*)out; p.ld_out = ld_out; p.lse = lse;
     p.T = (int)T; p.Tp = (int)Tp; p.H = (int)H;
     p.scale_log2e = scale * 1.4426950408889634f;
-    p.B = (int)B; p.nqb = (int)((T + 127) / 128); p.dbg = g_attn_dbg;
+    p.B = (int)B; p.dbg = g_attn_dbg;
+    p.nqb = peel ? (int)((T - 1 + 127) / 128) + 1 : (int)((T + 127) / 128);      // peeled: the last "block" is the class-token row
     const int64_t npairs8 = (B * H + 7) / 8;                  // pairs per XCD (rounded up)
     dim3 grid((unsigned)(npairs8 * p.nqb * 8));
-    if (variant == 4 && v_row_major) {
-        hipLaunchKernelGGL((attn_fwd_kernel<true, false, false, true>), grid, dim3(256), 2 * 16384 + 16, (hipStream_t)stream, p);
-        OWL_LAUNCH_CHECK();
-        return 0;
-    }
-    OWL_CHECK_ARG(variant >= 0 && variant <= 3 && (variant <= 1 || v_row_major), "owl_attention_fwd: variant must be 0 (default), 1 (classic), 2 / 3 (pipelined; row-major V only)");
-    if (variant == 0) variant = ATTN_DEFAULT_VARIANT;
     if (!v_row_major) hipLaunchKernelGGL((attn_fwd_kernel<false>), grid, dim3(256), 2 * 16384, (hipStream_t)stream, p);
-    else if (variant == 2 || variant == 3) {
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16384 + 16);
-            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16384 + 16);
-            attr_done = true;
-        }
-        if (variant == 2) hipLaunchKernelGGL((attn_fwd_kernel<true, true, false>), grid, dim3(256), 4 * 16384 + 16, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((attn_fwd_kernel<true, true, true>), grid, dim3(256), 4 * 16384 + 16, (hipStream_t)stream, p);
-    }
+    else if (peel) hipLaunchKernelGGL((attn_fwd_kernel<true, true>), grid, dim3(256), 2 * 16384, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((attn_fwd_kernel<true>), grid, dim3(256), 2 * 16384, (hipStream_t)stream, p);
     OWL_LAUNCH_CHECK();
     return 0;

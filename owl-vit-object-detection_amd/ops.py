@@ -11,7 +11,7 @@ EPI_BIAS_BF16, EPI_QGELU_BF16, EPI_GELU_BF16, EPI_RESID_F32, EPI_F32, EPI_ATOMIC
 EPI_TRANS_BF16, EPI_PATCH_F32, EPI_DQGELU_BF16, EPI_DGELU_BF16, EPI_ACC_F32, EPI_SLAB_F32 = 6, 7, 8, 9, 10, 11
 
 ROW_PAD = 128
-ATTN_VARIANT = 0   # default `variant` of attention_fwd_vrow(): 0 = the library's choice; 1 classic, 2 / 3 pipelined (tests / tools)
+ATTN_VARIANT = 0   # default `variant` of attention_fwd_vrow(): 0 = the library's choice; 1 plain tiling, 2 class token peeled (tests / tools)
 GEMM_TILE = 0      # default `tile` argument of gemm(): 0 = automatic kernel choice; tests / tools pin one kernel (128 | 256 | 8 | 4)
 
 

@@ -129,10 +129,11 @@ def test_attention_fwd_vrow_bitwise_repeatable():
         ops.attention_fwd_vrow(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, out, D, lse, B, H, T, Tp, 0.125, variant=variant)
         return out, lse
 
-    ref = run(1)
-    for it in range(40):
-        got = run(it % 4)            # default / classic / pipelined / pipelined + hints: one result, every launch
-        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), it
+    for variant in (1, 2):           # plain tiling / class token peeled (= the default at this T): each repeats its own bits
+        ref = run(variant)
+        for it in range(20):
+            got = run(variant if it % 2 else (0 if variant == 2 else 1))
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (variant, it)
 
 
 @pytest.mark.parametrize("arch,B", [("owlvit-base-patch16", 4), ("tiny-l14", 3)])
