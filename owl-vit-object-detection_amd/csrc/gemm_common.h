@@ -166,9 +166,25 @@ __device__ __forceinline__ void epi_pass(const GemmP& p, const f32x16& t0, const
 //       n_tile + 16*c + 8*hi + {0..7}
 //   TRANS (natural operands): lane owns output column n = n_tile + (lane&31); chunk c covers token rows
 //       m_tile + 16*c + 8*hi + {0..7}
+//
+// EPI_DQGELU / EPI_DGELU read the saved pre-activation tile (p.aux).  epi_aux_load fetches it in the STORE layout (two 16-byte loads per
+// lane and tile instead of four 8-byte ones at a row stride) so that a caller can have the loads of all its tiles in flight before the
+// first one is consumed; epi_tile_bf16 then undoes the lane pairing with the same v_permlane32_swap (it is its own inverse).
+template <bool GUARD>
+__device__ __forceinline__ void epi_aux_load(const GemmP& p, int64_t m_tile, int64_t n_tile, int lane, uint4 (&a)[2]) {
+    const int hi = lane >> 5;
+    const int64_t m = m_tile + (lane & 31);
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int64_t n = n_tile + 16 * c + 8 * hi;
+        a[c] = make_uint4(0u, 0u, 0u, 0u);
+        if (!GUARD || (m < p.M && n < p.N)) a[c] = *(const uint4*)((const bf16_t*)p.aux + m * p.ld_aux + n);
+    }
+}
+
 template <int EPI, bool GUARD>
 __device__ __forceinline__ void epi_tile_bf16(const GemmP& p, const f32x16& acc, int64_t m_tile, int64_t n_tile, int lane,
-                                              uint4& chunk0, uint4& chunk1, const float* lds_bias) {
+                                              uint4& chunk0, uint4& chunk1, const float* lds_bias, const uint4* aux_pre = nullptr) {
     constexpr bool TRANS = (EPI == EPI_TRANS_BF16);
     const int hi = lane >> 5;
     unsigned w[8];   // packed words, quad qd -> w[2*qd], w[2*qd+1]
@@ -186,6 +202,18 @@ __device__ __forceinline__ void epi_tile_bf16(const GemmP& p, const f32x16& acc,
         const bool m_ok = !GUARD || m < p.M;
         const bf16_t* aux_row = (const bf16_t*)p.aux + m * p.ld_aux + n_tile + 4 * hi;
         const float* bias_p = lds_bias + 4 * hi;           // this tile's bias slice, staged in LDS
+        unsigned aw[8] = {};                               // preloaded pre-activations, back in the accumulator's quad layout
+        if constexpr (EPI == EPI_DQGELU_BF16 || EPI == EPI_DGELU_BF16) {
+            if (aux_pre) {
+                unsigned ax[4] = {aux_pre[0].x, aux_pre[0].y, aux_pre[1].x, aux_pre[1].y}, ay[4] = {aux_pre[0].z, aux_pre[0].w, aux_pre[1].z, aux_pre[1].w};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    auto r = __builtin_amdgcn_permlane32_swap(ax[k], ay[k], false, false);
+                    ax[k] = r[0]; ay[k] = r[1];
+                }
+                aw[0] = ax[0]; aw[1] = ax[1]; aw[2] = ay[0]; aw[3] = ay[1]; aw[4] = ax[2]; aw[5] = ax[3]; aw[6] = ay[2]; aw[7] = ay[3];
+            }
+        }
 #pragma unroll
         for (int qd = 0; qd < 4; qd++) {
             float v[4];
@@ -223,7 +251,8 @@ __device__ __forceinline__ void epi_tile_bf16(const GemmP& p, const f32x16& acc,
                 }
             } else if constexpr (EPI == EPI_DQGELU_BF16 || EPI == EPI_DGELU_BF16) {
                 uint2 a = make_uint2(0u, 0u);
-                if (ok) a = *(const uint2*)(aux_row + 8 * qd);
+                if (aux_pre) a = make_uint2(aw[2 * qd], aw[2 * qd + 1]);
+                else if (ok) a = *(const uint2*)(aux_row + 8 * qd);
                 const float u[4] = {bf2f(a.x & 0xffff), bf2f(a.x >> 16), bf2f(a.y & 0xffff), bf2f(a.y >> 16)};
 #pragma unroll
                 for (int e = 0; e < 4; e++) v[e] *= (EPI == EPI_DQGELU_BF16) ? dqgelu_f(u[e]) : dgelu_f(u[e]);

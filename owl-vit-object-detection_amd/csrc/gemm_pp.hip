@@ -291,6 +291,16 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
             const float* lbias = (const float*)(lds + P_BIAS_OFF + tile_parity * 1024) + wc * 64;
             auto run = [&](auto guard_tag) {
                 constexpr bool G = decltype(guard_tag)::value;
+                constexpr bool AUX_IN = (EPI == EPI_DQGELU_BF16);     // (the erf-GELU derivative needs the registers itself: per-tile loads there)
+                // the saved pre-activations of all eight 32x32 tiles are requested up front (64 registers: the K loop's fragments are
+                // dead here): one HBM latency per 256x256 tile instead of one per 32x32 tile -- no load is ordered behind a store
+                uint4 auxr[AUX_IN ? 4 : 1][2][2];
+                if constexpr (AUX_IN) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+#pragma unroll
+                        for (int j = 0; j < 2; j++) epi_aux_load<G>(p, cm0 + grp * 128 + i * 32, cn0 + wc * 64 + j * 32, lane, auxr[i][j]);
+                }
 #pragma unroll
                 for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -300,7 +310,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
                             epi_tile_f32<EPI, G>(p, acc[i][j], mt, nt, lane, lbias + j * 32);
                         } else {
                             uint4 c0, c1;
-                            epi_tile_bf16<EPI, G>(p, acc[i][j], mt, nt, lane, c0, c1, lbias + j * 32);
+                            epi_tile_bf16<EPI, G>(p, acc[i][j], mt, nt, lane, c0, c1, lbias + j * 32, AUX_IN ? auxr[AUX_IN ? i : 0][j] : nullptr);
                             epi_store_chunk<EPI, G>(p, c0, mt, nt, 0, lane);
                             epi_store_chunk<EPI, G>(p, c1, mt, nt, 1, lane);
                         }
