@@ -64,7 +64,7 @@ def _flat_order(cfg: OwlConfig):
 class OwlViT(nn.Module):
     """Vision-only OWL-ViT with a learnable query bank (ref src/models.py:41-119)."""
 
-    def __init__(self, cfg: OwlConfig, state: "dict[str, np.ndarray]", device="cuda", bf16_stream: bool = False):
+    def __init__(self, cfg: OwlConfig, state: "dict[str, np.ndarray]", device="cuda", bf16_stream: bool = False, encoder_streams: int = 2):
         super().__init__()
         self.cfg = cfg
         self.device_ = torch.device(device)
@@ -138,6 +138,8 @@ class OwlViT(nn.Module):
         # Experiment only, measured and rejected: residual stream of the frozen prefix in bf16.  +1 % step rate
         # for twice the forward error (boxes 1.9e-3 -> 3.9e-3 / 4.5e-3) -- tools/bf16_stream_study.py reproduces both numbers.
         self._bf16_stream = bool(bf16_stream)
+        self.encoder_streams = int(encoder_streams)     # sub-batches of the encoder forward, one HIP stream each (see _forward_impl); 1 = off
+        self._streams, self._join, self._fork_ev = [], {}, None
         self._param_event = None           # ddp.DataParallel(overlap=True): the deferred all-reduce + AdamW of the previous step
         self._grad_clean = False           # ... which also left flat_grad zeroed for this step
         self._trainable = frozenset(order)
@@ -255,6 +257,80 @@ class OwlViT(nn.Module):
                     "exactly the reference's trainable set (layers.11 / box / post_layernorm / class_predictor / queries, ref "
                     "src/models.py:173-184); freezing or unfreezing individual tensors is not supported")
 
+    # -- encoder schedule --------------------------------------------------------------------------------
+    def _encoder_chunks(self, B: int):
+        """[(first image, images)] of the sub-batches the encoder runs on separate streams.  Small batches stay whole: below ~4 images per
+        sub-batch the GEMMs no longer fill the chip on their own."""
+        n = self.encoder_streams if B >= 8 else 1
+        if n <= 1:
+            return [(0, B)]
+        base, extra = divmod(B, n)
+        out, b0 = [], 0
+        for c in range(n):
+            nb = base + (1 if c < extra else 0)
+            out.append((b0, nb)); b0 += nb
+        return out
+
+    def _side_stream(self, c: int):
+        while len(self._streams) < c:
+            self._streams.append(torch.cuda.Stream(device=self.device_))
+            self._join[len(self._streams)] = torch.cuda.Event()
+        return self._streams[c - 1]
+
+    def _encoder_layer(self, i: int, ws, B: int, save: bool, st):
+        """Encoder layer i (HF5:478-511) for the sub-batch `st` (images [b0, b0 + nb) = rows [b0 Tp, (b0 + nb) Tp) of every buffer), on the
+        current stream.  st carries the sub-batch's residual stream and the not-yet-added branch outputs from layer to layer."""
+        cfg = self.cfg
+        D, I, H, Tp, T = cfg.hidden, cfg.mlp, cfg.heads, cfg.tokens_padded, cfg.tokens
+        b0, nb = st["b0"], st["nb"]
+        r0, M = b0 * Tp, nb * Tp
+        R = lambda t: t[r0:r0 + M]
+        tl = cfg.trainable_layer()
+        scale = cfg.head_dim ** -0.5
+        xs, pending, pending1 = st["xs"], st["pending"], st["pending1"]
+        d1, d2 = R(ws["d1"]), R(ws["d2"])
+        lw = self._layer_weights(i)
+        sv = save and i >= tl          # the backward passes through this layer: keep its activations
+        full = sv and i == tl          # ... and, for the trainable layer, the dW operands too
+        Ls = self._layer_ws(B, i) if sv else None
+        st1 = R(Ls["st1"]) if sv else None
+        h = R(Ls["h1"]) if full else R(ws["h"])
+        # Residual adds (HF5:500,507) live in the LayerNorm kernels: the GEMM in front of each emits a bf16
+        # delta through the fast wide-store epilogue, and LN does x += delta while it normalises.
+        x_cur = R(Ls["x_in"]) if sv else xs
+        if self._bf16_stream and not sv and pending is not None:
+            x_cur = R(ws["xb"]) if i < cfg.layers - 1 else R(ws["x"])     # (the final merge-LN reads f32)  experiment: bf16 residual stream of the frozen prefix (DESIGN.md section 9, item 7b)
+        if pending is None:
+            if sv:
+                x_cur.copy_(xs)
+            ops.layernorm(x_cur, lw["g1"], lw["be1"], h, M, D, st1, cfg.ln_eps)
+        else:
+            if pending1 is None:
+                ops.layernorm(xs, lw["g1"], lw["be1"], h, M, D, st1, cfg.ln_eps, delta=pending, x_out=x_cur)
+            else:       # (xs + delta1) + delta2, same operands and order as the two separate adds
+                ops.layernorm(xs, lw["g1"], lw["be1"], h, M, D, st1, cfg.ln_eps, delta=pending1, delta2=pending, x_out=x_cur)
+        # ONE row-major QKV GEMM per layer.  The attention kernels (forward and backward) read every transposed MFMA operand
+        # (V^T; Q^T, K^T, dO^T) out of the row-major tiles with the LDS hardware transpose (ds_read_b64_tr_b16): no transposed
+        # copy of anything exists in HBM.
+        qkv_l = R(Ls["qkv"]) if sv else R(ws["qkv"])
+        ops.gemm(ops.EPI_BIAS_BF16, h, lw["wqkv"], qkv_l, bias=lw["bqkv"], M=M, N=3 * D, K=D, ldo=3 * D)
+        att_l = R(Ls["att"]) if sv else R(ws["att"])
+        ops.attention_fwd_vrow(qkv_l, qkv_l[:, D:], qkv_l[:, 2 * D:], 3 * D, att_l, D, Ls["lse"][b0:b0 + nb] if sv else None, nb, H, T, Tp, scale)
+        ops.gemm(ops.EPI_BIAS_BF16, att_l, lw["wo"], d1, bias=lw["bo"], M=M, N=D, K=D)
+        x_mid = R(Ls["x_mid"]) if sv else x_cur
+        h2 = R(Ls["h2"]) if full else R(ws["h"])
+        # A frozen layer's x + delta1 is read by nobody but the next LayerNorm: it is not stored (4 bytes per element), that
+        # LayerNorm adds both branch outputs instead (2 more bytes read).  Layers whose activations are kept, and the last one
+        # (the merge kernel takes a single delta), store it.
+        defer = (not sv) and (i + 1 < cfg.layers)
+        ops.layernorm(x_cur, lw["g2"], lw["be2"], h2, M, D, R(Ls["st2"]) if sv else None, cfg.ln_eps, delta=d1, x_out=x_mid,
+                      store_x=not defer)
+        g_l = R(Ls["g"]) if full else R(ws["g"])
+        ops.gemm(ops.EPI_QGELU_BF16, h2, lw["w1"], g_l, bias=lw["b1"], aux=R(Ls["u"]) if sv else None, M=M, N=I, K=D)
+        ops.gemm(ops.EPI_BIAS_BF16, g_l, lw["w2"], d2, bias=lw["b2"], M=M, N=D, K=I)
+        st["pending"], st["xs"] = d2, x_mid
+        st["pending1"] = d1 if defer else None
+
     # -- forward ---------------------------------------------------------------------------------------
     def _forward_impl(self, image: torch.Tensor, save: bool):
         cfg = self.cfg
@@ -284,57 +360,43 @@ class OwlViT(nn.Module):
         ops.cls_rows(x, P_["backbone.embeddings.class_embedding"], P_["backbone.embeddings.position_embedding.weight"], B, Tp, D)
         ops.layernorm(x, P_["backbone.pre_layernorm.weight"], P_["backbone.pre_layernorm.bias"], x, M, D, eps=cfg.ln_eps)
 
-        scale = cfg.head_dim ** -0.5
-        qkv, att, g = ws["qkv"], ws["att"], ws["g"]
-        d1, d2 = ws["d1"], ws["d2"]
-        xs = x                  # residual stream BEFORE the pending MLP-branch delta is added
-        pending = None          # bf16 output of the previous layer's fc2, not yet added to the residual stream
-        pending1 = None         # ... and of its out-proj, when that layer's second LayerNorm did not store x + delta1 (frozen layers)
+        # ---- encoder.  No kernel of it couples images, so the batch is run as `encoder_streams` sub-batches (contiguous row ranges of the
+        #      same buffers), each on its own HIP stream, layer by layer: the idle CUs of one sub-batch's last GEMM round / attention tail
+        #      run the other sub-batch's next kernel (a 256 x 256 GEMM workgroup owns its CU's registers and LDS, so the overlap is at CU
+        #      granularity).  Measured on the forward: -3.7 % at B/16 batch 32, -2.9 % at L/14 batch 16 (two streams; three or four lose --
+        #      profiles/r02_encoder_streams.md).  Every kernel is batch-invariant: same bits as the single-stream schedule.
         tl = cfg.trainable_layer()
+        param_event, self._param_event = self._param_event, None
+        chunks = self._encoder_chunks(B)
+        main = torch.cuda.current_stream()
+        if save:        # first use allocates (and zero-fills, on THIS stream) the kept activations: before any other stream may write them
+            for i in range(tl, cfg.layers):
+                self._layer_ws(B, i)
+        if len(chunks) > 1:
+            if self._fork_ev is None:
+                self._fork_ev = torch.cuda.Event()
+            self._fork_ev.record(main)
+        states = []
+        for c, (b0, nb) in enumerate(chunks):
+            st = dict(b0=b0, nb=nb, stream=main if c == 0 else self._side_stream(c), xs=x[b0 * Tp:(b0 + nb) * Tp], pending=None, pending1=None)
+            if c > 0:
+                st["stream"].wait_event(self._fork_ev)
+            states.append(st)
         for i in range(cfg.layers):
-            if i == tl:
-                self._wait_params()        # everything above ran on frozen weights only
-            lw = self._layer_weights(i)
-            sv = save and i >= tl          # the backward passes through this layer: keep its activations
-            full = sv and i == tl          # ... and, for the trainable layer, the dW operands too
-            Ls = self._layer_ws(B, i) if sv else None
-            h = Ls["h1"] if full else ws["h"]
-            # Residual adds (HF5:500,507) live in the LayerNorm kernels: the GEMM in front of each emits a bf16
-            # delta through the fast wide-store epilogue, and LN does x += delta while it normalises.
-            x_cur = Ls["x_in"] if sv else xs
-            if self._bf16_stream and not sv and pending is not None:
-                x_cur = ws["xb"] if i < cfg.layers - 1 else ws["x"]     # (the final merge-LN reads f32)  experiment: bf16 residual stream of the frozen prefix
-            if pending is None:
-                if sv:
-                    x_cur.copy_(xs)
-                ops.layernorm(x_cur, lw["g1"], lw["be1"], h, M, D, Ls["st1"] if sv else None, cfg.ln_eps)
-            else:
-                if pending1 is None:
-                    ops.layernorm(xs, lw["g1"], lw["be1"], h, M, D, Ls["st1"] if sv else None, cfg.ln_eps, delta=pending, x_out=x_cur)
-                else:       # (xs + delta1) + delta2, same operands and order as the two separate adds
-                    ops.layernorm(xs, lw["g1"], lw["be1"], h, M, D, Ls["st1"] if sv else None, cfg.ln_eps, delta=pending1, delta2=pending,
-                                  x_out=x_cur)
-            # ONE row-major QKV GEMM per layer.  The attention kernels (forward and backward) read every transposed MFMA operand
-            # (V^T; Q^T, K^T, dO^T) out of the row-major tiles with the LDS hardware transpose (ds_read_b64_tr_b16): no transposed
-            # copy of anything exists in HBM.
-            qkv_l = Ls["qkv"] if sv else qkv
-            ops.gemm(ops.EPI_BIAS_BF16, h, lw["wqkv"], qkv_l, bias=lw["bqkv"], M=M, N=3 * D, K=D, ldo=3 * D)
-            att_l = Ls["att"] if sv else att
-            ops.attention_fwd_vrow(qkv_l, qkv_l[:, D:], qkv_l[:, 2 * D:], 3 * D, att_l, D, Ls["lse"] if sv else None, B, H, T, Tp, scale)
-            ops.gemm(ops.EPI_BIAS_BF16, att_l, lw["wo"], d1, bias=lw["bo"], M=M, N=D, K=D)
-            x_mid = Ls["x_mid"] if sv else x_cur
-            h2 = Ls["h2"] if full else ws["h"]
-            # A frozen layer's x + delta1 is read by nobody but the next LayerNorm: it is not stored (4 bytes per element), that
-            # LayerNorm adds both branch outputs instead (2 more bytes read).  Layers whose activations are kept, and the last one
-            # (the merge kernel takes a single delta), store it.
-            defer = (not sv) and (i + 1 < cfg.layers)
-            ops.layernorm(x_cur, lw["g2"], lw["be2"], h2, M, D, Ls["st2"] if sv else None, cfg.ln_eps, delta=d1, x_out=x_mid,
-                          store_x=not defer)
-            g_l = Ls["g"] if full else g
-            ops.gemm(ops.EPI_QGELU_BF16, h2, lw["w1"], g_l, bias=lw["b1"], aux=Ls["u"] if sv else None, M=M, N=I, K=D)
-            ops.gemm(ops.EPI_BIAS_BF16, g_l, lw["w2"], d2, bias=lw["b2"], M=M, N=D, K=I)
-            pending, xs = d2, x_mid
-            pending1 = d1 if defer else None
+            for st in states:
+                with torch.cuda.stream(st["stream"]):
+                    if i == tl and param_event is not None:
+                        st["stream"].wait_event(param_event)    # everything above ran on frozen weights only (ddp overlap schedule)
+                    self._encoder_layer(i, ws, B, save, st)
+        for c, st in enumerate(states):
+            if c > 0:
+                self._join[c].record(st["stream"])
+                main.wait_event(self._join[c])
+        # the sub-batches' residual streams / deferred MLP-branch outputs are row ranges of ONE buffer each: the merge kernel takes the batch
+        last = cfg.layers - 1
+        xs = self._layer_ws(B, last)["x_mid"] if (save and last >= tl) else x
+        assert all(st["xs"].data_ptr() == xs.data_ptr() + st["b0"] * Tp * D * 4 for st in states)
+        pending = ws["d2"]
 
         # ---- final residual add + post_layernorm (all tokens) * class token -> post_post_layernorm
         #      (ref src/models.py:80-86); the final residual stream is materialised in `x` for the backward

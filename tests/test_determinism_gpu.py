@@ -189,3 +189,36 @@ def test_gemm_f32_epilogues_pingpong_matches_tile256_bitwise(N, K, epi):
     for _ in range(6):
         assert torch.equal(run(8), ref)
     assert torch.equal(run(0), ref)
+
+
+@pytest.mark.parametrize("arch,B", [("owlvit-base-patch16", 8), ("tiny-l14", 9)])
+def test_encoder_sub_batch_streams_give_the_single_stream_bits(arch, B):
+    """The encoder forward runs as two sub-batches on two HIP streams (models.OwlViT.encoder_streams): outputs, losses and the whole
+    gradient bucket must be the bits of the single-stream schedule, step after step (kept activations are allocated before the fork;
+    every buffer a sub-batch touches is its own row range)."""
+    from owl_vit_object_detection_amd import synth, weights
+    from owl_vit_object_detection_amd.config import get_config
+    from owl_vit_object_detection_amd.losses import PushPullLoss
+    from owl_vit_object_detection_amd.models import OwlViT
+    cfg = get_config(arch)
+    Wnp = weights.make_weights(cfg)
+    imgs = torch.from_numpy(synth.make_images(cfg, B)).to(DEV)
+    labels, boxes = synth.make_targets(cfg, B, max_boxes=8)
+    crit = PushPullLoss(cfg.n_classes, synth.class_scales(cfg, labels))
+    res = []
+    for n in (1, 2):
+        model = OwlViT(cfg, Wnp, DEV, encoder_streams=n)
+        assert len(model._encoder_chunks(B)) == n
+        runs = []
+        for it in range(3):
+            model.flat_grad.zero_()
+            pb, _, ps, _ = model(imgs)
+            losses = crit(ps, [torch.from_numpy(l).to(DEV) for l in labels], pb, [torch.from_numpy(b).to(DEV) for b in boxes])
+            (losses["loss_ce"] + losses["loss_bg"] + losses["loss_bbox"] + losses["loss_giou"]).backward()
+            runs.append((pb.detach().clone(), ps.detach().clone(), model.flat_grad.clone()))
+        with torch.no_grad():
+            eb, _, es, _ = model.eval()(imgs)
+        runs.append((eb.clone(), es.clone(), model.flat_grad.clone()))
+        res.append(runs)
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
