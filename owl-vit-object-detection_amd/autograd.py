@@ -183,21 +183,41 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
     scale = cfg.head_dim ** -0.5
     dxb_fresh = False        # bw["dxb"] already holds the bf16 copy of bw["dx"] (written by the last LayerNorm backward)
     # ---- frozen layers ABOVE the trainable one (literal "layers.11" rule on a deeper model): dX only ----------
-    for i in range(cfg.layers - 1, cfg.trainable_layer(), -1):
-        Ls, fz = model._layer_ws(B, i), model._fz
-        pre = f"backbone.encoder.layers.{i}."
+    # Like the encoder forward (models.OwlViT._forward_impl), this chain couples no two images: it runs as sub-batches (row ranges of the
+    # same buffers) on the model's streams, layer by layer.
+    upper = range(cfg.layers - 1, cfg.trainable_layer(), -1)
+    if len(upper) > 0:
         if not dxb_fresh:
             ops.cast_bf16(bw["dx"], bw["dxb"])
-        ops.gemm(ops.EPI_DQGELU_BF16, bw["dxb"], fz[f"{i}.w2T"], bw["du"], aux=Ls["u"], M=M, N=I, K=D)
-        ops.gemm(ops.EPI_BIAS_BF16, bw["du"], fz[f"{i}.w1T"], bw["dh"], M=M, N=D, K=I)
-        # (the LayerNorm backward also writes the bf16 copy of its dx: the operand of the next dX GEMM, no separate cast pass)
-        ops.layernorm_bwd(bw["dh"], Ls["x_mid"], Ls["st2"], P_[pre + "layer_norm2.weight"], bw["dx"], bw["dxm"], None, None, M, D,
-                          dx_bf16=bw["dxb"])
-        ops.gemm(ops.EPI_BIAS_BF16, bw["dxb"], fz[f"{i}.woT"], bw["datt"], M=M, N=D, K=D)
-        ops.attention_bwd(Ls["qkv"], bw["datt"], Ls["att"], Ls["lse"], bw["dvec"], bw["dqkv"], B, H, T, Tp, scale)
-        ops.gemm(ops.EPI_BIAS_BF16, bw["dqkv"], fz[f"{i}.wqkvT"], bw["dh"], M=M, N=D, K=3 * D)
-        ops.layernorm_bwd(bw["dh"], Ls["x_in"], Ls["st1"], P_[pre + "layer_norm1.weight"], bw["dxm"], bw["dx"], None, None, M, D,
-                          dx_bf16=bw["dxb"])
+        chunks = model._encoder_chunks(B)
+        main = torch.cuda.current_stream()
+        streams = [main] + [model._side_stream(c) for c in range(1, len(chunks))]
+        if len(chunks) > 1:
+            model._fork_ev.record(main)
+            for s_ in streams[1:]:
+                s_.wait_event(model._fork_ev)
+        for i in upper:
+            Ls, fz = model._layer_ws(B, i), model._fz
+            pre = f"backbone.encoder.layers.{i}."
+            for (b0, nb), s_ in zip(chunks, streams):
+                r0, Mc = b0 * Tp, nb * Tp
+                R = lambda t: t[r0:r0 + Mc]
+                with torch.cuda.stream(s_):
+                    ops.gemm(ops.EPI_DQGELU_BF16, R(bw["dxb"]), fz[f"{i}.w2T"], R(bw["du"]), aux=R(Ls["u"]), M=Mc, N=I, K=D)
+                    ops.gemm(ops.EPI_BIAS_BF16, R(bw["du"]), fz[f"{i}.w1T"], R(bw["dh"]), M=Mc, N=D, K=I)
+                    # (the LayerNorm backward also writes the bf16 copy of its dx: the operand of the next dX GEMM, no separate cast pass)
+                    ops.layernorm_bwd(R(bw["dh"]), R(Ls["x_mid"]), R(Ls["st2"]), P_[pre + "layer_norm2.weight"], R(bw["dx"]), R(bw["dxm"]), None, None,
+                                      Mc, D, dx_bf16=R(bw["dxb"]))
+                    ops.gemm(ops.EPI_BIAS_BF16, R(bw["dxb"]), fz[f"{i}.woT"], R(bw["datt"]), M=Mc, N=D, K=D)
+                    ops.attention_bwd(R(Ls["qkv"]), R(bw["datt"]), R(Ls["att"]), Ls["lse"][b0:b0 + nb], bw["dvec"][b0:b0 + nb], R(bw["dqkv"]),
+                                      nb, H, T, Tp, scale)
+                    ops.gemm(ops.EPI_BIAS_BF16, R(bw["dqkv"]), fz[f"{i}.wqkvT"], R(bw["dh"]), M=Mc, N=D, K=3 * D)
+                    ops.layernorm_bwd(R(bw["dh"]), R(Ls["x_in"]), R(Ls["st1"]), P_[pre + "layer_norm1.weight"], R(bw["dxm"]), R(bw["dx"]), None, None,
+                                      Mc, D, dx_bf16=R(bw["dxb"]))
+        for c, s_ in enumerate(streams):
+            if c > 0:
+                model._join[c].record(s_)
+                main.wait_event(model._join[c])
         dxb_fresh = True
     Lt = model._layer_ws(B, cfg.trainable_layer())
     # ---- trainable encoder layer: MLP ---------------------------------------------------------------------
