@@ -87,6 +87,8 @@ def _bws(model, B):
         # partial sums of the deterministic row reductions (bias / LayerNorm-affine gradients): written by one kernel, added in a
         # fixed order by the next -- no f32 atomics into the gradient bucket
         part=ops.rowreduce_workspace(B, Tp, max(3 * D, I, Dt), dev),
+        part2=ops.rowreduce_workspace(B, Tp, max(3 * D, I, Dt), dev),      # ... of the weight-gradient stream (see backward_impl)
+        dxb2=z(M, D, bf, dev),                                              # second bf16 dx of the trainable layer (the first one is still being read)
         # transposed-operand scratch for the dW GEMMs; token-row and head-row users get their own buffers so
         # that the zero pad columns [rows, rows_pad) of each are never dirtied by the other row count
         # (only the shapes the TN kernel does not take need them: feature counts that are not multiples of 256 -- the
@@ -138,14 +140,14 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
         ops.transpose_bf16(tv(name), out, rows, cols)
         return out
 
-    def dW(dy, x, grad_w, n_out, n_in, rows, rows_pad, grad_b=None, accumulate=1):
+    def dW(dy, x, grad_w, n_out, n_in, rows, rows_pad, grad_b=None, accumulate=1, part="part"):
         """grad_w[n_out, n_in] (+)= dy[rows, n_out]^T x[rows, n_in];  grad_b += colsum(dy).
         Token-major operand copies (transposes) -> split-K GEMM into f32 slabs -> deterministic slab reduction.
         Pad columns [rows, rows_pad) of the scratch stay zero: never written, buffers start zeroed."""
         if n_out % 256 == 0 and n_in % 256 == 0:
             # TN kernel: reads dy / x where they lie (LDS transpose-reads), no token-major copies
             if grad_b is not None:
-                ops.colsum_bf16(dy, grad_b, rows, n_out, partials=bw["part"])
+                ops.colsum_bf16(dy, grad_b, rows, n_out, partials=bw[part])
             tiles = (n_out // 256) * (n_in // 256)
             ns = ops.gemm_tn_slab(dy, x, bw["slab"], rows, n_out, n_in, max(1, 256 // tiles))
             _lib.call("owl_slab_reduce", ops.stream(), bw["slab"], grad_w, n_out * n_in, n_out * n_in, ns, accumulate)
@@ -153,7 +155,7 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
         tA, tB = (bw["tAh"], bw["tBh"]) if rows == Mh else (bw["tA"], bw["tB"])
         ld = tA.shape[1]
         assert ld == rows_pad
-        ops.transpose_colsum(dy, tA, grad_b, rows, n_out, ld_in=dy.shape[-1], ld_out=ld, partials=bw["part"])
+        ops.transpose_colsum(dy, tA, grad_b, rows, n_out, ld_in=dy.shape[-1], ld_out=ld, partials=bw[part])
         ops.transpose_colsum(x, tB, None, rows, n_in, ld_in=x.shape[-1], ld_out=ld)
         want = _split_k(n_out, n_in, rows_pad)
         ns = _lib.load().owl_gemm_effective_splits(rows_pad, want)
@@ -220,28 +222,47 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
                 main.wait_event(model._join[c])
         dxb_fresh = True
     Lt = model._layer_ws(B, cfg.trainable_layer())
-    # ---- trainable encoder layer: MLP ---------------------------------------------------------------------
+    # ---- trainable encoder layer ------------------------------------------------------------------------------
+    # Two chains: dX (this stream) and the four weight gradients.  A weight gradient feeds nothing downstream -- it only has to be in the
+    # bucket when backward() returns -- so the dW GEMMs (+ their bias column sums and slab reductions) run on the model's side stream, each
+    # behind the event of the dX-chain kernel that produces its operand: its workgroups fill the CUs the dX kernels' last rounds leave
+    # idle, and vice versa.  Same kernels on the same operands: same bits.  The side stream owns the split-K slab from here on and has its
+    # own reduction scratch; the second bf16 dx goes to its own buffer because dW(fc2) may still be reading the first.
+    main = torch.cuda.current_stream()
+    side = model._side_stream(1) if model.encoder_streams > 1 else main
+    evs = model._dw_events
+
+    def on_side(k, fn):
+        if side is main:
+            fn()
+            return
+        evs[k].record(main)
+        side.wait_event(evs[k])
+        with torch.cuda.stream(side):
+            fn()
+
     if not dxb_fresh:
         ops.cast_bf16(bw["dx"], bw["dxb"])
+    # MLP
     ops.colsum_f32(bw["dx"], G(tl + "mlp.fc2.bias"), M, D, partials=bw["part"])
-    dW(bw["dxb"], Lt["g"], G(tl + "mlp.fc2.weight"), D, I, M, Mp)
+    on_side(0, lambda: dW(bw["dxb"], Lt["g"], G(tl + "mlp.fc2.weight"), D, I, M, Mp, part="part2"))
     ops.gemm(ops.EPI_DQGELU_BF16, bw["dxb"], wT(tl + "mlp.fc2.weight", D, I), bw["du"], aux=Lt["u"], M=M, N=I, K=D)
-    dW(bw["du"], Lt["h2"], G(tl + "mlp.fc1.weight"), I, D, M, Mp, G(tl + "mlp.fc1.bias"))
+    on_side(1, lambda: dW(bw["du"], Lt["h2"], G(tl + "mlp.fc1.weight"), I, D, M, Mp, G(tl + "mlp.fc1.bias"), part="part2"))
     ops.gemm(ops.EPI_BIAS_BF16, bw["du"], wT(tl + "mlp.fc1.weight", I, D), bw["dh"], M=M, N=D, K=I)
     ops.layernorm_bwd(bw["dh"], Lt["x_mid"], Lt["st2"], P_[tl + "layer_norm2.weight"], bw["dx"], bw["dxm"],
-                      G(tl + "layer_norm2.weight"), G(tl + "layer_norm2.bias"), M, D, dx_bf16=bw["dxb"], partials=bw["part"])
-    # ---- trainable encoder layer: attention -----------------------------------------------------------------
+                      G(tl + "layer_norm2.weight"), G(tl + "layer_norm2.bias"), M, D, dx_bf16=bw["dxb2"], partials=bw["part"])
+    # attention
     ops.colsum_f32(bw["dxm"], G(tl + "self_attn.out_proj.bias"), M, D, partials=bw["part"])
-    dW(bw["dxb"], Lt["att"], G(tl + "self_attn.out_proj.weight"), D, D, M, Mp)
+    on_side(2, lambda: dW(bw["dxb2"], Lt["att"], G(tl + "self_attn.out_proj.weight"), D, D, M, Mp, part="part2"))
     woT = wT(tl + "self_attn.out_proj.weight", D, D)
-    ops.gemm(ops.EPI_BIAS_BF16, bw["dxb"], woT, bw["datt"], M=M, N=D, K=D)
+    ops.gemm(ops.EPI_BIAS_BF16, bw["dxb2"], woT, bw["datt"], M=M, N=D, K=D)
     ops.attention_bwd(Lt["qkv"], bw["datt"], Lt["att"], Lt["lse"], bw["dvec"], bw["dqkv"], B, H, T, Tp,
                       cfg.head_dim ** -0.5)
     o = model.flat_offsets[tl + "self_attn.q_proj.weight"]
     g_wqkv = model.flat_grad[o: o + 3 * D * D].view(3 * D, D)
     ob = model.flat_offsets[tl + "self_attn.q_proj.bias"]
     g_bqkv = model.flat_grad[ob: ob + 3 * D]
-    dW(bw["dqkv"], Lt["h1"], g_wqkv, 3 * D, D, M, Mp, g_bqkv)
+    on_side(3, lambda: dW(bw["dqkv"], Lt["h1"], g_wqkv, 3 * D, D, M, Mp, g_bqkv, part="part2"))
     wqkv = model.flat_bf16[o: o + 3 * D * D].view(3 * D, D)
     wqkvT = bw["wT"][: 3 * D * D].view(D, 3 * D)
     ops.transpose_bf16(wqkv, wqkvT, 3 * D, D)
@@ -249,3 +270,6 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
     # everything below layer_norm1 is frozen: only its affine parameters need gradients
     ops.layernorm_bwd(bw["dh"], Lt["x_in"], Lt["st1"], P_[tl + "layer_norm1.weight"], None, None,
                       G(tl + "layer_norm1.weight"), G(tl + "layer_norm1.bias"), M, D, partials=bw["part"])
+    if side is not main:
+        evs[4].record(side)
+        main.wait_event(evs[4])

@@ -140,6 +140,7 @@ class OwlViT(nn.Module):
         self._bf16_stream = bool(bf16_stream)
         self.encoder_streams = int(encoder_streams)     # sub-batches of the encoder forward, one HIP stream each (see _forward_impl); 1 = off
         self._streams, self._join, self._fork_ev = [], {}, None
+        self._dw_events_ = None
         self._param_event = None           # ddp.DataParallel(overlap=True): the deferred all-reduce + AdamW of the previous step
         self._grad_clean = False           # ... which also left flat_grad zeroed for this step
         self._trainable = frozenset(order)
@@ -270,6 +271,13 @@ class OwlViT(nn.Module):
             nb = base + (1 if c < extra else 0)
             out.append((b0, nb)); b0 += nb
         return out
+
+    @property
+    def _dw_events(self):
+        """Events of the backward's weight-gradient stream (autograd.backward_impl): four operand-ready events + the final join."""
+        if self._dw_events_ is None:
+            self._dw_events_ = [torch.cuda.Event() for _ in range(5)]
+        return self._dw_events_
 
     def _side_stream(self, c: int):
         while len(self._streams) < c:
