@@ -69,6 +69,9 @@ def parse():
     ap.add_argument("--no-compare", action="store_true", help="skip the second (other --targets mode) measurement")
     ap.add_argument("--overlap", action="store_true", help="all-reduce + AdamW on a side stream under the next step's frozen prefix")
     ap.add_argument("--no-kernel-events", action="store_true", help="no HIP events around the GEMM / attention launches (overhead A/B)")
+    ap.add_argument("--encoder-streams", type=int, default=2,
+                    help="sub-batches of the encoder forward / dX-only backward, one HIP stream each (OwlViT(encoder_streams=...)); 1 = one stream "
+                         "(what the rocprofv3 profiles are taken with: kernel durations are then exclusive)")
     return ap.parse_args()
 
 
@@ -153,6 +156,9 @@ def cpu_baseline(cfg, steps):
                       "better of the two; the reference itself: 0.32 img/s on 8 vCPUs (BASELINE.md section 2)"}
 
 
+EVENT_EVERY = 5
+
+
 class KernelTimer:
     """HIP events around selected launches on the launch stream (= torch's current stream, which the ops enqueue on)."""
 
@@ -211,7 +217,7 @@ def main():
     cfg = get_config(args.arch)
     B = args.batch
 
-    model = OwlViT(cfg, weights.make_weights(cfg), dev)           # identical weights on every rank (seeded)
+    model = OwlViT(cfg, weights.make_weights(cfg), dev, encoder_streams=args.encoder_streams)    # identical weights on every rank (seeded)
     batches = synth_batches(cfg, B, dev, rank)
     scales = synth.class_scales(cfg, [l for l in batches[0]["labels_np"]])
     crit = PushPullLoss(cfg.n_classes, scales)
@@ -275,10 +281,14 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
-            # kernel events on every 4th timed step only: an event pair around each of a step's ~70 GEMM / attention launches costs
-            # ~1.2 % of the step (measured A/B, --no-kernel-events), a quarter of the steps keeps that under 0.3 %
-            kt.on = record and (i % 4 == 0)
+            # Kernel events on every EVENT_EVERY-th timed step only: an event pair around each of a step's ~70 GEMM / attention launches
+            # costs ~1.2 % of the step (measured A/B, --no-kernel-events).  Those steps also run the ONE-stream schedule (same kernels,
+            # same bits, ~3 % slower): with two sub-batches in flight a launch shares the chip with the other stream's kernel and its
+            # event-to-event time is not the kernel's own duration.
+            kt.on = record and (i % EVENT_EVERY == 0)
+            model.encoder_streams = 1 if kt.on else args.encoder_streams
             step(warmup + i, mode)
+        model.encoder_streams = args.encoder_streams
         dp.finish()
         torch.cuda.synchronize()
         if world > 1:
@@ -312,6 +322,7 @@ def main():
                                    + (f", DDP over {world} GPUs, one RCCL all-reduce of the flat grad bucket/step" if world > 1 else ""),
                        "global_batch": B * world, "tokens": cfg.tokens, "parallelism": f"dp{world}",
                        "targets": args.targets + (" (per-image label/box lists through PushPullLoss.__call__, ref main.py:77-83)" if args.targets == "lists" else " (pre-padded)"),
+                       "encoder_streams": args.encoder_streams,
                        "optimizer_schedule": "side-stream all-reduce + AdamW under the next step's frozen prefix" if dp.overlap else "in-line",
                        "gflop_per_image": round(flops_img / 1e9, 1),
                        "step_mfma_frac": round(flops_img * value / world / 1e12 / PEAK_BF16_TFLOPS, 4)},
@@ -328,7 +339,9 @@ def main():
             r = kt.summary(label)
             if r is None:
                 continue
-            r["ms_total_per_step"] = round(r["ms_per_launch"] * r["launches_timed"] / len(range(0, args.steps, 4)), 3)
+            r["ms_total_per_step"] = round(r["ms_per_launch"] * r["launches_timed"] / len(range(0, args.steps, EVENT_EVERY)), 3)
+            r["measured_on"] = (f"every {EVENT_EVERY}th timed step, which runs the one-stream schedule (whole-batch launches, the kernel alone on the chip); "
+                                f"the other steps run {args.encoder_streams} sub-batch streams")
             if main_r is None:
                 main_r = r
             else:

@@ -1,17 +1,21 @@
 #!/bin/bash
 # Round-2 profile set, run on the GPU box through gpurun (outputs under gpurun_out/, summaries copied to profiles/ afterwards):
-#   1. rocprofv3 --kernel-trace --stats over the default bench (B/16, batch 32)          -> r2_prof_b16/
+# Every pass runs the ONE-stream schedule (--encoder-streams 1): with two sub-batch streams (the default) kernels overlap and a kernel's
+# traced duration is not its own.  The default-schedule bench line is taken separately (pass 0).
+#   0. python bench.py (default schedule)                                                   -> r2_bench_default.log
+#   1. rocprofv3 --kernel-trace --stats over the bench (B/16, batch 32)          -> r2_prof_b16/
 #   2. the same for L/14 840x840 batch 16                                                -> r2_prof_l14/
 #   3. HBM traffic: two --pmc passes (FETCH_SIZE, WRITE_SIZE -- each alone: together they exceed the TCC counter slots) over a
 #      short bench run, --kernel-trace only, every pass under its own timeout             -> r2_pmc_fetch/, r2_pmc_write/
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r2_prof_b16 -o rf -- python $R/bench.py --no-cpu-baseline --no-compare > $R/gpurun_out/r2_prof_b16.log 2>&1
-timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r2_prof_l14 -o rf -- python $R/bench.py --no-cpu-baseline --no-compare --arch owlvit-large-patch14 --batch 16 --steps 4 --warmup 2 > $R/gpurun_out/r2_prof_l14.log 2>&1
-timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/r2_pmc_fetch -o p -f csv -- python $R/bench.py --no-cpu-baseline --no-compare --no-kernel-events --steps 2 --warmup 1 > $R/gpurun_out/r2_pmc_fetch.log 2>&1
-timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/r2_pmc_write -o p -f csv -- python $R/bench.py --no-cpu-baseline --no-compare --no-kernel-events --steps 2 --warmup 1 > $R/gpurun_out/r2_pmc_write.log 2>&1
+python $R/bench.py --no-compare > $R/gpurun_out/r2_bench_default.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r2_prof_b16 -o rf -- python $R/bench.py --no-cpu-baseline --no-compare --encoder-streams 1 > $R/gpurun_out/r2_prof_b16.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r2_prof_l14 -o rf -- python $R/bench.py --no-cpu-baseline --no-compare --encoder-streams 1 --arch owlvit-large-patch14 --batch 16 --steps 4 --warmup 2 > $R/gpurun_out/r2_prof_l14.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/r2_pmc_fetch -o p -f csv -- python $R/bench.py --no-cpu-baseline --no-compare --no-kernel-events --encoder-streams 1 --steps 2 --warmup 1 > $R/gpurun_out/r2_pmc_fetch.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/r2_pmc_write -o p -f csv -- python $R/bench.py --no-cpu-baseline --no-compare --no-kernel-events --encoder-streams 1 --steps 2 --warmup 1 > $R/gpurun_out/r2_pmc_write.log 2>&1
 cd $R
 python tools/prof_summary.py $(ls gpurun_out/r2_prof_b16/*.db | head -1) 60 > gpurun_out/r2_prof_b16_summary.md
 python tools/prof_summary.py $(ls gpurun_out/r2_prof_l14/*.db | head -1) 40 > gpurun_out/r2_prof_l14_summary.md
 python tools/pmc_traffic.py gpurun_out/r2_pmc_fetch gpurun_out/r2_pmc_write --json gpurun_out/r2_traffic.json > gpurun_out/r2_hbm_traffic.md
-tail -1 gpurun_out/r2_prof_b16.log | cut -c1-300; tail -1 gpurun_out/r2_prof_l14.log | cut -c1-300; head -12 gpurun_out/r2_hbm_traffic.md; cat gpurun_out/r2_traffic.json
+tail -1 gpurun_out/r2_bench_default.log | cut -c1-300; grep -h '"metric"' gpurun_out/r2_prof_b16.log | cut -c1-300; grep -h '"metric"' gpurun_out/r2_prof_l14.log | cut -c1-300; head -12 gpurun_out/r2_hbm_traffic.md; cat gpurun_out/r2_traffic.json
