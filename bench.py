@@ -67,7 +67,9 @@ def parse():
                     help="lists = per-image label/box lists through PushPullLoss.__call__ as ref main.py:77-83 (headline); "
                          "packed = targets padded once outside the timed region (diagnostic)")
     ap.add_argument("--no-compare", action="store_true", help="skip the second (other --targets mode) measurement")
-    ap.add_argument("--overlap", action="store_true", help="all-reduce + AdamW on a side stream under the next step's frozen prefix")
+    ap.add_argument("--overlap", action="store_true", help="all-reduce + AdamW on a side stream under the next step's frozen prefix "
+                                                           "(default with more than one rank: it hides the ring time; bitwise the in-line result)")
+    ap.add_argument("--no-overlap", action="store_true", help="in-line all-reduce + AdamW even with more than one rank")
     ap.add_argument("--no-kernel-events", action="store_true", help="no HIP events around the GEMM / attention launches (overhead A/B)")
     ap.add_argument("--encoder-streams", type=int, default=2,
                     help="sub-batches of the encoder forward / dX-only backward, one HIP stream each (OwlViT(encoder_streams=...)); 1 = one stream "
@@ -222,7 +224,7 @@ def main():
     scales = synth.class_scales(cfg, [l for l in batches[0]["labels_np"]])
     crit = PushPullLoss(cfg.n_classes, scales)
     opt = FusedAdamW(model, lr=3e-6, weight_decay=0.1)            # ref config.yaml:10,12
-    dp = ddp.DataParallel(model, opt, overlap=args.overlap)
+    dp = ddp.DataParallel(model, opt, overlap=(args.overlap or world > 1) and not args.no_overlap)
     dp.check_equal_batches(B)
 
     # ---- kernel timing: HIP events around the GEMM (bf16-output epilogues) and fused-attention-forward launches -------

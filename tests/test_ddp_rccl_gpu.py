@@ -45,13 +45,20 @@ def test_bench_refuses_more_gpus_than_visible():
 
 
 @pytest.mark.timeout(900)
-def test_bench_single_forced_rccl_rank_reports_the_collective():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--arch", "small",
-                        "--batch", "4", "--no-cpu-baseline"], capture_output=True, text=True, env=_env(OWL_FORCE_DIST="1"), timeout=800)
+@pytest.mark.parametrize("schedule", ["in-line", "overlap"])
+def test_bench_single_forced_rccl_rank_reports_the_collective(schedule):
+    """One forced rank over the real RCCL backend, both optimizer schedules (with more than one rank the bench defaults to the overlapped
+    one: RCCL + AdamW on a side stream while the next step's sub-batch streams already run the frozen prefix); batch 8 so that the
+    encoder runs its two sub-batch streams beside them."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "1", "--arch", "small",
+                        "--batch", "8", "--no-cpu-baseline"] + (["--overlap"] if schedule == "overlap" else []),
+                       capture_output=True, text=True, env=_env(OWL_FORCE_DIST="1"), timeout=800)
     assert r.returncode == 0, r.stderr[-3000:]
     out = _last_json(r.stdout)
     assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and out["backend"].startswith("nccl")
     assert out["allreduce_ms"] > 0 and out["allreduce_bytes"] > 0 and out["value"] > 0
+    assert out["config"]["optimizer_schedule"].startswith("side-stream" if schedule == "overlap" else "in-line")
+    assert out["config"]["encoder_streams"] == 2
 
 
 def _free_port():
