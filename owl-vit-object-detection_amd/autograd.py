@@ -181,16 +181,14 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
     ops.merge_ln_bwd(bw["dfeats"], ws["x"], ws["cls_ln"], ws["st_post"], ws["st_pp"], P_["backbone.post_layernorm.weight"],
                      P_["backbone.post_layernorm.bias"], P_["post_post_layernorm.weight"], bw["dx"], bw["dcls"],
                      G("backbone.post_layernorm.weight"), G("backbone.post_layernorm.bias"), G("post_post_layernorm.weight"),
-                     G("post_post_layernorm.bias"), B, P, Tp, D, partials=bw["part"])
+                     G("post_post_layernorm.bias"), B, P, Tp, D, partials=bw["part"], dx_bf16=bw["dxb"])
     scale = cfg.head_dim ** -0.5
-    dxb_fresh = False        # bw["dxb"] already holds the bf16 copy of bw["dx"] (written by the last LayerNorm backward)
+    # (bw["dxb"] always holds the bf16 copy of bw["dx"]: every kernel that writes dx writes it too -- no separate cast pass)
     # ---- frozen layers ABOVE the trainable one (literal "layers.11" rule on a deeper model): dX only ----------
     # Like the encoder forward (models.OwlViT._forward_impl), this chain couples no two images: it runs as sub-batches (row ranges of the
     # same buffers) on the model's streams, layer by layer.
     upper = range(cfg.layers - 1, cfg.trainable_layer(), -1)
     if len(upper) > 0:
-        if not dxb_fresh:
-            ops.cast_bf16(bw["dx"], bw["dxb"])
         chunks = model._encoder_chunks(B)
         main = torch.cuda.current_stream()
         streams = [main] + [model._side_stream(c) for c in range(1, len(chunks))]
@@ -220,7 +218,6 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
             if c > 0:
                 model._join[c].record(s_)
                 main.wait_event(model._join[c])
-        dxb_fresh = True
     Lt = model._layer_ws(B, cfg.trainable_layer())
     # ---- trainable encoder layer ------------------------------------------------------------------------------
     # Two chains: dX (this stream) and the four weight gradients.  A weight gradient feeds nothing downstream -- it only has to be in the
@@ -241,8 +238,6 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
         with torch.cuda.stream(side):
             fn()
 
-    if not dxb_fresh:
-        ops.cast_bf16(bw["dx"], bw["dxb"])
     # MLP
     ops.colsum_f32(bw["dx"], G(tl + "mlp.fc2.bias"), M, D, partials=bw["part"])
     on_side(0, lambda: dW(bw["dxb"], Lt["g"], G(tl + "mlp.fc2.weight"), D, I, M, Mp, part="part2"))
@@ -250,9 +245,9 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
     on_side(1, lambda: dW(bw["du"], Lt["h2"], G(tl + "mlp.fc1.weight"), I, D, M, Mp, G(tl + "mlp.fc1.bias"), part="part2"))
     ops.gemm(ops.EPI_BIAS_BF16, bw["du"], wT(tl + "mlp.fc1.weight", I, D), bw["dh"], M=M, N=D, K=I)
     ops.layernorm_bwd(bw["dh"], Lt["x_mid"], Lt["st2"], P_[tl + "layer_norm2.weight"], bw["dx"], bw["dxm"],
-                      G(tl + "layer_norm2.weight"), G(tl + "layer_norm2.bias"), M, D, dx_bf16=bw["dxb2"], partials=bw["part"])
+                      G(tl + "layer_norm2.weight"), G(tl + "layer_norm2.bias"), M, D, dx_bf16=bw["dxb2"], partials=bw["part"],
+                      dx_colsum=G(tl + "self_attn.out_proj.bias"))     # (dx here = d(x + out-proj output): its column sums are that bias's gradient)
     # attention
-    ops.colsum_f32(bw["dxm"], G(tl + "self_attn.out_proj.bias"), M, D, partials=bw["part"])
     on_side(2, lambda: dW(bw["dxb2"], Lt["att"], G(tl + "self_attn.out_proj.weight"), D, D, M, Mp, part="part2"))
     woT = wT(tl + "self_attn.out_proj.weight", D, D)
     ops.gemm(ops.EPI_BIAS_BF16, bw["dxb2"], woT, bw["datt"], M=M, N=D, K=D)

@@ -60,18 +60,20 @@ extern "C" int owl_rowreduce_workspace_bytes(int64_t groups, int64_t rows_per_gr
 // ---------------------------------------------------------------------------------------------------
 // LayerNorm backward: dx = (dres) + rstd * (g*dy - mean(g*dy) - xhat*mean(g*dy*xhat));  dgamma += dy*xhat,
 // dbeta += dy.  dy is bf16 (GEMM output) or f32; one wave per row, RPB rows per workgroup.
+// DXSUM: also the column sums of dx (= the bias gradient of the linear layer whose output this residual position is: saves that
+// layer's separate column-sum pass over the f32 dx).
 // ---------------------------------------------------------------------------------------------------
-template <bool DY_BF16>
+template <bool DY_BF16, bool DXSUM = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy_, const float* __restrict__ x,
                                                      const float2* __restrict__ stats, const float* __restrict__ gamma,
                                                      const float* dres, float* dx, float* part, int64_t rows,
                                                      int D, int rows_per_block, bf16_t* dx_bf16) {
-    __shared__ float red[2][4][LN_MAXV * 256 + 4];
+    __shared__ float red[DXSUM ? 3 : 2][4][LN_MAXV * 256 + 4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nvec = D >> 2;
-    float4 ag[LN_MAXV], ab[LN_MAXV];
+    float4 ag[LN_MAXV], ab[LN_MAXV], ad[DXSUM ? LN_MAXV : 1];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; i++) { ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0); }
+    for (int i = 0; i < LN_MAXV; i++) { ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0); if (DXSUM) ad[DXSUM ? i : 0] = make_float4(0, 0, 0, 0); }
     const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r_end = min(rows, r_begin + rows_per_block);
     for (int64_t row = r_begin + w; row < r_end; row += 4) {
@@ -112,6 +114,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                         o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
                     }
                     ((float4*)(dx + row * D))[idx] = o;
+                    if constexpr (DXSUM) { float4& a = ad[DXSUM ? i : 0]; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
                     if (dx_bf16) {                          // the bf16 copy the next dX GEMM reads (saves a separate cast pass)
                         uint2 ob; ob.x = pack_bf2(o.x, o.y); ob.y = pack_bf2(o.z, o.w);
                         ((uint2*)(dx_bf16 + row * D))[idx] = ob;
@@ -125,19 +128,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
 #pragma unroll
     for (int i = 0; i < LN_MAXV; i++) {
         const int idx = lane + i * 64;
-        if (idx < nvec) { *(float4*)&red[0][w][idx * 4] = ag[i]; *(float4*)&red[1][w][idx * 4] = ab[i]; }
+        if (idx < nvec) {
+            *(float4*)&red[0][w][idx * 4] = ag[i]; *(float4*)&red[1][w][idx * 4] = ab[i];
+            if constexpr (DXSUM) *(float4*)&red[2][w][idx * 4] = ad[DXSUM ? i : 0];
+        }
     }
     __syncthreads();
-    float* mine = part + (int64_t)blockIdx.x * 2 * D;
+    constexpr int NS = DXSUM ? 3 : 2;
+    float* mine = part + (int64_t)blockIdx.x * NS * D;
     for (int c = threadIdx.x; c < D; c += 256) {
-        mine[c] = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
-        mine[D + c] = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+#pragma unroll
+        for (int k = 0; k < NS; k++) mine[k * D + c] = red[k][0][c] + red[k][1][c] + red[k][2][c] + red[k][3][c];
     }
 }
 
 extern "C" int owl_layernorm_bwd(void* stream, const void* dy, int dy_bf16, const float* x, const float* stats, const float* gamma,
                                  const float* dres, float* dx, float* dgamma, float* dbeta, int64_t rows, int64_t D, void* dx_bf16,
-                                 float* partials, int64_t partials_floats) {
+                                 float* partials, int64_t partials_floats, float* dx_colsum) {
     OWL_CHECK_ARG(dy && x && stats && gamma, "owl_layernorm_bwd: null pointer");
     OWL_CHECK_ARG(D % 4 == 0 && D <= 256 * LN_MAXV, "owl_layernorm_bwd: D must be a multiple of 4 and <= 1024");
     OWL_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "owl_layernorm_bwd: dgamma/dbeta both or neither");
@@ -146,18 +153,22 @@ extern "C" int owl_layernorm_bwd(void* stream, const void* dy, int dy_bf16, cons
     const int nblk = (int)((rows + rpb - 1) / rpb);
     dim3 grid((unsigned)nblk);
     float* part = nullptr;
+    OWL_CHECK_ARG(!dx_colsum || (dgamma && dx && dy_bf16), "owl_layernorm_bwd: dx_colsum comes with dgamma / dbeta, dx and a bf16 dy");
+    const int ns = dx_colsum ? 3 : 2;
     if (dgamma) {
-        OWL_CHECK_ARG(partials && partials_floats >= (int64_t)nblk * 2 * D, "owl_layernorm_bwd: parameter gradients need %lld floats of partial-sum scratch (owl_rowreduce_workspace_bytes)", (long long)nblk * 2 * D);
+        OWL_CHECK_ARG(partials && partials_floats >= (int64_t)nblk * ns * D, "owl_layernorm_bwd: parameter gradients need %lld floats of partial-sum scratch (owl_rowreduce_workspace_bytes)", (long long)nblk * ns * D);
         part = partials;
     }
-    if (dy_bf16)
+    if (dx_colsum)
+        hipLaunchKernelGGL((ln_bwd_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, dy, x, (const float2*)stats, gamma, dres, dx, part, rows, (int)D, rpb, (bf16_t*)dx_bf16);
+    else if (dy_bf16)
         hipLaunchKernelGGL(ln_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dy, x, (const float2*)stats, gamma, dres, dx, part, rows, (int)D, rpb, (bf16_t*)dx_bf16);
     else
         hipLaunchKernelGGL(ln_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dy, x, (const float2*)stats, gamma, dres, dx, part, rows, (int)D, rpb, (bf16_t*)dx_bf16);
     OWL_LAUNCH_CHECK();
     if (!part) return 0;
-    ReduceOuts outs{}; outs.o[0] = dgamma; outs.o[1] = dbeta;
-    return partials_reduce((hipStream_t)stream, part, outs, 2, (int)D, 2 * D, nblk, 1, 0, 0, 1);
+    ReduceOuts outs{}; outs.o[0] = dgamma; outs.o[1] = dbeta; outs.o[2] = dx_colsum;
+    return partials_reduce((hipStream_t)stream, part, outs, ns, (int)D, (int64_t)ns * D, nblk, 1, 0, 0, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -169,7 +180,7 @@ __global__ __launch_bounds__(256) void merge_ln_bwd_kernel(const float* __restri
                                                            const float* __restrict__ cls_ln, const float2* __restrict__ stats1,
                                                            const float2* __restrict__ stats2, const float* __restrict__ g1,
                                                            const float* __restrict__ b1, const float* __restrict__ g2, float* dx,
-                                                           float* part, int64_t P, int64_t Tp, int D, int rows_per_block) {
+                                                           float* part, int64_t P, int64_t Tp, int D, int rows_per_block, bf16_t* dx_bf16) {
     __shared__ float red[4][LN_MAXV * 256 + 4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t b = blockIdx.y;
@@ -226,9 +237,15 @@ __global__ __launch_bounds__(256) void merge_ln_bwd_kernel(const float* __restri
 #pragma unroll
         for (int i = 0; i < LN_MAXV; i++) {
             const int idx = lane + i * 64;
-            if (idx < nvec)
-                ((float4*)(dx + xrow * D))[idx] = make_float4(s1.y * (gd[i].x - n1 - xh[i].x * n2), s1.y * (gd[i].y - n1 - xh[i].y * n2),
-                                                              s1.y * (gd[i].z - n1 - xh[i].z * n2), s1.y * (gd[i].w - n1 - xh[i].w * n2));
+            if (idx < nvec) {
+                const float4 o = make_float4(s1.y * (gd[i].x - n1 - xh[i].x * n2), s1.y * (gd[i].y - n1 - xh[i].y * n2),
+                                             s1.y * (gd[i].z - n1 - xh[i].z * n2), s1.y * (gd[i].w - n1 - xh[i].w * n2));
+                ((float4*)(dx + xrow * D))[idx] = o;
+                if (dx_bf16) {                              // the bf16 copy the first dX GEMM reads (saves a separate cast pass)
+                    uint2 ob; ob.x = pack_bf2(o.x, o.y); ob.y = pack_bf2(o.z, o.w);
+                    ((uint2*)(dx_bf16 + xrow * D))[idx] = ob;
+                }
+            }
         }
     }
     // five column reductions: 4 waves -> LDS -> this workgroup's slab part[b][blockIdx.x][{dcls, dg1, db1, dg2, db2}][D]
@@ -250,7 +267,7 @@ __global__ __launch_bounds__(256) void merge_ln_bwd_kernel(const float* __restri
 // cls rows: dy0 = dcls[b,:] -> LN1 backward on token 0 of image b
 __global__ __launch_bounds__(64) void cls_ln_bwd_kernel(const float* __restrict__ dcls, const float* __restrict__ x,
                                                         const float2* __restrict__ stats1, const float* __restrict__ g1, float* dx,
-                                                        float* part, int64_t Tp, int D) {
+                                                        float* part, int64_t Tp, int D, bf16_t* dx_bf16) {
     const int lane = threadIdx.x;
     const int64_t b = blockIdx.x, row = b * Tp;
     const int nvec = D >> 2;
@@ -275,16 +292,22 @@ __global__ __launch_bounds__(64) void cls_ln_bwd_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < LN_MAXV; i++) {
         const int idx = lane + i * 64;
-        if (idx < nvec)
-            ((float4*)(dx + row * D))[idx] = make_float4(st.y * (gd[i].x - s1 - xh[i].x * s2), st.y * (gd[i].y - s1 - xh[i].y * s2),
-                                                         st.y * (gd[i].z - s1 - xh[i].z * s2), st.y * (gd[i].w - s1 - xh[i].w * s2));
+        if (idx < nvec) {
+            const float4 o = make_float4(st.y * (gd[i].x - s1 - xh[i].x * s2), st.y * (gd[i].y - s1 - xh[i].y * s2),
+                                         st.y * (gd[i].z - s1 - xh[i].z * s2), st.y * (gd[i].w - s1 - xh[i].w * s2));
+            ((float4*)(dx + row * D))[idx] = o;
+            if (dx_bf16) {
+                uint2 ob; ob.x = pack_bf2(o.x, o.y); ob.y = pack_bf2(o.z, o.w);
+                ((uint2*)(dx_bf16 + row * D))[idx] = ob;
+            }
+        }
     }
 }
 
 extern "C" int owl_merge_ln_bwd(void* stream, const float* dfeats, const float* x, const float* cls_ln, const float* stats1,
                                 const float* stats2, const float* g1, const float* b1, const float* g2, float* dx, float* dcls_ws,
                                 float* dg1, float* db1, float* dg2, float* db2, int64_t B, int64_t P, int64_t Tp, int64_t D,
-                                float* partials, int64_t partials_floats) {
+                                float* partials, int64_t partials_floats, void* dx_bf16) {
     OWL_CHECK_ARG(dfeats && x && cls_ln && stats1 && stats2 && g1 && b1 && g2 && dx && dcls_ws && dg1 && db1 && dg2 && db2 && partials, "owl_merge_ln_bwd: null pointer");
     OWL_CHECK_ARG(D % 4 == 0 && D <= 256 * LN_MAXV, "owl_merge_ln_bwd: D must be a multiple of 4 and <= 1024");
     hipStream_t s = (hipStream_t)stream;
@@ -292,7 +315,7 @@ extern "C" int owl_merge_ln_bwd(void* stream, const float* dfeats, const float* 
     const int nbx = (int)((P + rpb - 1) / rpb);
     OWL_CHECK_ARG(partials_floats >= B * nbx * 5 * D, "owl_merge_ln_bwd: needs %lld floats of partial-sum scratch (owl_rowreduce_workspace_bytes)", (long long)(B * nbx * 5 * D));
     hipLaunchKernelGGL(merge_ln_bwd_kernel, dim3((unsigned)nbx, (unsigned)B), dim3(256), 0, s, dfeats, x, cls_ln,
-                       (const float2*)stats1, (const float2*)stats2, g1, b1, g2, dx, partials, P, Tp, (int)D, rpb);
+                       (const float2*)stats1, (const float2*)stats2, g1, b1, g2, dx, partials, P, Tp, (int)D, rpb, (bf16_t*)dx_bf16);
     OWL_LAUNCH_CHECK();
     // d(cls_ln)[b] = sum over the image's row blocks (per-image groups); the four LN parameter gradients += sum over all slabs
     ReduceOuts oc{}; oc.o[0] = dcls_ws;
@@ -302,7 +325,7 @@ extern "C" int owl_merge_ln_bwd(void* stream, const float* dfeats, const float* 
     rc = partials_reduce(s, partials + D, op, 4, (int)D, 5 * D, (int)(B * nbx), 1, 0, 0, 1);
     if (rc) return rc;
     // class-token rows: the slabs above have been consumed (stream order), so the scratch is reused for part[b][{dg1, db1}][D]
-    hipLaunchKernelGGL(cls_ln_bwd_kernel, dim3((unsigned)B), dim3(64), 0, s, dcls_ws, x, (const float2*)stats1, g1, dx, partials, Tp, (int)D);
+    hipLaunchKernelGGL(cls_ln_bwd_kernel, dim3((unsigned)B), dim3(64), 0, s, dcls_ws, x, (const float2*)stats1, g1, dx, partials, Tp, (int)D, (bf16_t*)dx_bf16);
     OWL_LAUNCH_CHECK();
     ReduceOuts o2{}; o2.o[0] = dg1; o2.o[1] = db1;
     return partials_reduce(s, partials, o2, 2, (int)D, 2 * D, (int)B, 1, 0, 0, 1);

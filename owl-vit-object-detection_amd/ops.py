@@ -154,18 +154,20 @@ def _part(partials, rows, C, device):
     return buf
 
 
-def layernorm_bwd(dy, x, stats, gamma, dres, dx, dgamma, dbeta, rows, D, dx_bf16=None, partials=None):
-    """dx (f32) = LN backward (+ dres); optionally also its bf16 copy `dx_bf16` (the operand of the next dX GEMM)."""
-    _chk(dx_bf16, torch.bfloat16, "dx_bf16")
+def layernorm_bwd(dy, x, stats, gamma, dres, dx, dgamma, dbeta, rows, D, dx_bf16=None, partials=None, dx_colsum=None):
+    """dx (f32) = LN backward (+ dres); optionally also its bf16 copy `dx_bf16` (the operand of the next dX GEMM) and `dx_colsum` +=
+    the column sums of dx (the bias gradient of the linear layer in front of this residual position)."""
+    _chk(dx_bf16, torch.bfloat16, "dx_bf16"); _chk(dx_colsum, torch.float32, "dx_colsum")
     part = _part(partials, rows, D, x.device) if dgamma is not None else None
     _lib.call("owl_layernorm_bwd", stream(), dy, 1 if dy.dtype == torch.bfloat16 else 0, x, stats, gamma, dres, dx,
-              dgamma, dbeta, rows, D, dx_bf16, part, part.numel() if part is not None else 0)
+              dgamma, dbeta, rows, D, dx_bf16, part, part.numel() if part is not None else 0, dx_colsum)
 
 
-def merge_ln_bwd(dfeats, x, cls_ln, st1, st2, g1, b1, g2, dx, dcls_ws, dg1, db1, dg2, db2, B, P, Tp, D, partials=None):
+def merge_ln_bwd(dfeats, x, cls_ln, st1, st2, g1, b1, g2, dx, dcls_ws, dg1, db1, dg2, db2, B, P, Tp, D, partials=None, dx_bf16=None):
     part = partials if partials is not None else _part(None, B * ((P + 63) // 64) * 64, D, x.device)
+    _chk(dx_bf16, torch.bfloat16, "dx_bf16")
     _lib.call("owl_merge_ln_bwd", stream(), dfeats, x, cls_ln, st1, st2, g1, b1, g2, dx, dcls_ws, dg1, db1, dg2, db2, B, P, Tp, D,
-              part, part.numel())
+              part, part.numel(), dx_bf16)
 
 
 def class_sims_bwd(dsims, sims, argmax, inv_norm, e, qhat32, de, g32, e_bf16, rows, Dt, C):

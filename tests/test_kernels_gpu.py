@@ -474,3 +474,38 @@ def test_attention_bwd_matches_torch_autograd(B, H, T):
         d = (got[:, :, i].permute(0, 2, 1, 3) - g).abs().max().item()
         assert d < 2e-2 * max(g.abs().max().item(), 1e-3), (i, d, g.abs().max().item())
     assert float(dqkv[:M].view(B, Tp, 3 * D)[:, T:].abs().max()) == 0.0 if Tp > T else True      # pad tokens get no gradient
+
+
+@pytest.mark.parametrize("rows,D,bf16_dy", [(1000, 768, True), (333, 1024, True), (257, 128, False)])
+def test_layernorm_bwd_matches_torch_autograd(rows, D, bf16_dy):
+    """owl_layernorm_bwd vs torch autograd of F.layer_norm: dx (+ residual gradient), its bf16 copy, dgamma / dbeta (accumulated into the
+    caller's buffers through fixed-order partial sums) and -- fused for the trainable layer's LN2 -- the column sums of dx."""
+    torch.manual_seed(rows)
+    x = torch.randn(ops.pad_rows(rows), D, device=DEV) * 2 + 0.3
+    gamma = torch.randn(D, device=DEV); beta = torch.randn(D, device=DEV)
+    dy = torch.randn(ops.pad_rows(rows), D, device=DEV) * 0.1
+    if bf16_dy:
+        dy = dy.bfloat16()
+    dres = torch.randn(ops.pad_rows(rows), D, device=DEV) * 0.05
+    h = torch.zeros(ops.pad_rows(rows), D, device=DEV, dtype=torch.bfloat16); stats = torch.zeros(ops.pad_rows(rows), 2, device=DEV)
+    ops.layernorm(x, gamma, beta, h, rows, D, stats)
+    xr = x[:rows].clone().requires_grad_(True); gr = gamma.clone().requires_grad_(True); br = beta.clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-5).backward(dy[:rows].float())
+    want_dx = xr.grad + dres[:rows]
+    for fused in (False, True) if bf16_dy else (False,):
+        dx = torch.zeros_like(x); dxb = torch.zeros_like(h)
+        dg = torch.full((D,), 0.25, device=DEV); db = torch.full((D,), -0.5, device=DEV); dcs = torch.full((D,), 2.0, device=DEV)
+        ops.layernorm_bwd(dy, x, stats, gamma, dres, dx, dg, db, rows, D, dx_bf16=dxb, dx_colsum=dcs if fused else None)
+        report("ln_bwd dx", dx[:rows], want_dx, 1e-4, 1e-4)
+        assert torch.equal(dxb[:rows], dx[:rows].bfloat16())
+        report("ln_bwd dgamma", dg - 0.25, gr.grad, 2e-3, 1e-3)
+        report("ln_bwd dbeta", db + 0.5, br.grad, 2e-3, 1e-3)
+        if fused:
+            report("ln_bwd colsum(dx)", dcs - 2.0, dx[:rows].double().sum(0).float(), 2e-3, 1e-4)
+            dcs2 = torch.full((D,), 2.0, device=DEV); dg2 = torch.full((D,), 0.25, device=DEV); db2 = torch.full((D,), -0.5, device=DEV)
+            ops.layernorm_bwd(dy, x, stats, gamma, dres, dx, dg2, db2, rows, D, dx_bf16=dxb, dx_colsum=dcs2)
+            assert torch.equal(dcs, dcs2) and torch.equal(dg, dg2) and torch.equal(db, db2)        # fixed-order reduction: repeatable bits
+    # dx-only form (frozen layers): no parameter gradients, no scratch
+    dx = torch.zeros_like(x)
+    ops.layernorm_bwd(dy, x, stats, gamma, None, dx, None, None, rows, D)
+    report("ln_bwd dx only", dx[:rows], xr.grad, 1e-4, 1e-4)
