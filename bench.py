@@ -158,7 +158,7 @@ def cpu_baseline(cfg, steps):
                       "better of the two; the reference itself: 0.32 img/s on 8 vCPUs (BASELINE.md section 2)"}
 
 
-EVENT_EVERY = 5
+EVENT_EVERY = 10
 
 
 class KernelTimer:
