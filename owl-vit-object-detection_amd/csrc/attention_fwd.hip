@@ -496,372 +496,6 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// Ping-pong attention forward: 8 waves = 256 query rows of one (image, head), two groups of four waves, every SIMD hosting one wave
-// of each.  A wave's work per 64-key tile is two PHASES of about equal length,
-//     V(j): softmax of tile j on the VALU (exp2, row sums, bf16 packing)   + the K fragment reads of tile j+1 + this wave's two LDS-DMA
-//           pieces of tile j+4
-//     M(j): the 16 MFMAs  S(j+1) = K(j+1) Q^T  and  O += V(j)^T P(j)^T      + the V fragment transpose-reads between the MFMAs
-// and the two groups run ONE PHASE APART (every phase ends in a workgroup barrier): while group 0 exponentiates, group 1 owns the matrix
-// pipe, and vice versa.  The free-running kernel above leaves it to three waves per SIMD to drift into complementary phases (PMC: matrix
-// pipe 54 % busy, VALU 62 %, both at once 27 %); here the complement is enforced, as in the ping-pong GEMM (gemm_pp.hip) and as
-// MI355X_MICROARCH.md describes for a tuned 8-wave attention loop.  Per query it also issues half the LDS-DMA pieces (a K / V tile now
-// serves 256 queries) -- the data-movement skeleton was half of the free-running kernel (profiles/r02_attn_fwd_experiments.md).
-// Same MFMA chains and the same summation order per query as the kernel above: identical bits.
-// K / V tiles travel through a ring of six 16-KiB stages (tile i+4 is requested in V(i): >= 5 phases ahead of its first read, the
-// slot's previous tile i-2 was last read two barriers earlier); waits are counted (two pieces per wave and tile).
-// Only whole tiles: Tk = T - PEEL must be a multiple of 64 (the host falls back to the kernel above otherwise).
-// ---------------------------------------------------------------------------------------------------------------------------
-static constexpr int APP_RING = 6;
-template <int N> __device__ __forceinline__ void app_wait() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
-template <int N> __device__ __forceinline__ void app_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-__device__ __forceinline__ void app_bar() {
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-template <bool PEEL>
-__global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnFwdP p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int hi = lane >> 5;
-    const int grp = (p.dbg & 256) ? (w & 1) : (p.dbg & 512) ? ((w >> 1) & 1) : (w >> 2);
-    int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int pair = (idx / p.nqb) * 8 + xcd;
-    if (pair >= p.B * p.H) return;
-    const int qb = idx - (idx / p.nqb) * p.nqb;
-    const int b = pair / p.H, h = pair - b * p.H;
-    if constexpr (PEEL) {
-        if (qb == p.nqb - 1) {                        // the class-token row: the first four waves run the same code as in the kernel above
-            if (threadIdx.x < 256) attn_cls_row(p, b, h, lds);
-            return;
-        }
-    }
-    const int Tk = p.T - (PEEL ? 1 : 0);
-    const int q0 = qb * 256 + w * 32;
-    const float c = p.scale_log2e;
-    const bool active = q0 < Tk;
-    const int n = Tk / 64;                             // whole tiles only (host-checked)
-
-    int qrow = q0 + (lane & 31);
-    if (qrow >= Tk) qrow = Tk - 1;
-    if constexpr (PEEL) qrow += 1;
-    const bf16_t* qp = p.q + ((int64_t)b * p.Tp + qrow) * p.ld_qk + h * 64;
-    bf16x8 qf[4];
-#pragma unroll
-    for (int kc = 0; kc < 4; kc++) qf[kc] = *(const bf16x8*)(qp + kc * 16 + hi * 8);
-    uint4 k0u[4];
-    unsigned short v0u[2];
-    if constexpr (PEEL) {
-        const bf16_t* k0p = p.k + (int64_t)b * p.Tp * p.ld_qk + h * 64;
-        const bf16_t* v0p = p.vt + (int64_t)b * p.Tp * p.ld_qk + h * 64;
-#pragma unroll
-        for (int kc = 0; kc < 4; kc++) k0u[kc] = *(const uint4*)(k0p + kc * 16 + hi * 8);
-#pragma unroll
-        for (int d = 0; d < 2; d++) v0u[d] = v0p[d * 32 + (lane & 31)];
-    }
-    // ---- staging: wave w owns rows [w*8, w*8+8) of every K and V tile: one 1-KiB LDS-DMA piece each ------------------------
-    const bf16_t* kbase = p.k + ((int64_t)b * p.Tp + (PEEL ? 1 : 0)) * p.ld_qk + h * 64;
-    const bf16_t* vbase = p.vt + ((int64_t)b * p.Tp + (PEEL ? 1 : 0)) * p.ld_qk + h * 64;
-    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, 0x7fffffff, 0x00020000);
-    unsigned k_voff, v_voff;
-    {
-        const int r = w * 8 + (lane >> 3);
-        k_voff = (unsigned)((r * p.ld_qk + ((lane & 7) ^ ((r >> 1) & 7)) * 8) * 2);
-        v_voff = (unsigned)((r * p.ld_qk + ((lane & 7) ^ swz_vrow(r)) * 8) * 2);
-    }
-    const int k_tile_bytes = (int)(64 * p.ld_qk * 2);
-    auto stage = [&](int kv) {
-        unsigned char* base = lds + (kv % APP_RING) * 16384 + w * 1024;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, LPTR(base), 16, (int)k_voff, kv * k_tile_bytes, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, LPTR(base + 8192), 16, (int)v_voff, kv * k_tile_bytes, 0, 0);
-    };
-
-    f32x16 o[2];
-#pragma unroll
-    for (int d = 0; d < 2; d++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) o[d][r] = 0.f;
-#pragma unroll
-    for (int kc = 0; kc < 4; kc++) {                   // Q scaled by scale*log2(e) once (see the kernel above)
-        unsigned wq[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const unsigned u = ((const unsigned*)&qf[kc])[e];
-            wq[e] = pack_bf2(__uint_as_float(u << 16) * c, __uint_as_float(u & 0xffff0000u) * c);
-        }
-        qf[kc] = __builtin_bit_cast(bf16x8, make_uint4(wq[0], wq[1], wq[2], wq[3]));
-    }
-    float M = 0.f;
-    bool have_m = false;
-    const bf16x8 kones = __builtin_bit_cast(bf16x8, make_uint4(hi == 0 ? 0x3F80u : 0u, 0u, 0u, 0u));
-    uint4 qn4 = make_uint4(0u, 0u, 0u, 0u);
-    bf16x8 qneg = __builtin_bit_cast(bf16x8, qn4);
-    const unsigned lds0 = (unsigned)(uintptr_t)LPTR(lds);
-    unsigned k_addr[2][4], v_addr[2][2];
-#pragma unroll
-    for (int t = 0; t < 2; t++) {
-        const int rk = t * 32 + swap23(lane & 31);
-#pragma unroll
-        for (int kc = 0; kc < 4; kc++) k_addr[t][kc] = lds0 + rk * 128 + (((kc * 2 + hi) ^ ((rk >> 1) & 7)) << 4);
-#pragma unroll
-        for (int h2 = 0; h2 < 2; h2++) v_addr[t][h2] = lds0 + 8192 + tr_lane_off(lane, t, h2);
-    }
-    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float l_part = 0.f;
-    typedef const __attribute__((address_space(3))) bf16x8* frag_ptr;
-
-    f32x16 s[2];                                       // scores of the tile whose softmax comes next
-    bf16x8 kfr[2][4];                                  // K fragments of the tile whose QK^T comes next
-    uint4 pw[4];                                       // packed bf16 probabilities of the tile whose PV comes next, [t*2 + cc]
-    // Every LDS fragment read of the loop is hand-issued (asm) and waited for with explicit lgkmcnt counts: the K fragments of tile j+1 are
-    // requested as the LAST instructions of V(j) and are NOT waited for before the barrier (the stage they come from is not rewritten for
-    // another six phases), they return under the barrier and under the transpose-reads that open M(j).  `ka` = their addresses, formed in
-    // the M phase before (the VALU is idle there).
-    unsigned ka[4];                                    // (the second 32-key half is 4096 bytes further: the swizzle has a period of 16 rows)
-    auto k_addr_for = [&](int kv) {
-        const unsigned so = (unsigned)((kv % APP_RING) * 16384);
-#pragma unroll
-        for (int kc = 0; kc < 4; kc++) ka[kc] = k_addr[0][kc] + so;
-    };
-    auto k_issue = [&]() {
-        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7"
-                     : "=&v"(kfr[0][0]), "=&v"(kfr[0][1]), "=&v"(kfr[0][2]), "=&v"(kfr[0][3])
-                     : "v"(ka[0]), "v"(ka[1]), "v"(ka[2]), "v"(ka[3]));
-        asm volatile("ds_read_b128 %0, %4 offset:4096\n\tds_read_b128 %1, %5 offset:4096\n\tds_read_b128 %2, %6 offset:4096\n\tds_read_b128 %3, %7 offset:4096"
-                     : "=&v"(kfr[1][0]), "=&v"(kfr[1][1]), "=&v"(kfr[1][2]), "=&v"(kfr[1][3])
-                     : "v"(ka[0]), "v"(ka[1]), "v"(ka[2]), "v"(ka[3]));
-    };
-    auto k_wait = [&]() {                              // the K fragments have returned (no consumer may be scheduled above this)
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(kfr[0][0]), "+v"(kfr[0][1]), "+v"(kfr[0][2]), "+v"(kfr[0][3]), "+v"(kfr[1][0]), "+v"(kfr[1][1]), "+v"(kfr[1][2]), "+v"(kfr[1][3]));
-    };
-    auto qk = [&](bool sub_max) {                      // s = K Q^T (- M): the chains of the kernel above, fragment by fragment
-#pragma unroll
-        for (int t = 0; t < 2; t++) {
-            if (sub_max) s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kones, qneg, zero16, 0, 0, 0);
-#pragma unroll
-            for (int kc = 0; kc < 4; kc++)
-                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[t][kc], qf[kc], (kc == 0 && !sub_max) ? zero16 : s[t], 0, 0, 0);
-        }
-    };
-    // softmax of the tile in s[] (its K tile is tile kv): exactly the checked tile code of the kernel above
-    auto softmax = [&](int kv, bool first) {
-        bool slow = (p.dbg & 1) || (first && (p.dbg & 4));
-        float ts = 0.f;
-        if (!slow) {
-#pragma unroll
-            for (int t = 0; t < 2; t++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    s[t][r] = __builtin_amdgcn_exp2f(s[t][r]);
-                    ts += s[t][r];
-                }
-            slow = __any(!(ts <= 1.0995116e12f) || (first && ts < 8.6736174e-19f));
-        }
-        if (slow) {                                    // wave-uniform, rare: recompute s = score*c from the tile's own K fragments
-            const unsigned so = (unsigned)((kv % APP_RING) * 16384);
-#pragma unroll
-            for (int t = 0; t < 2; t++)
-#pragma unroll
-                for (int kc = 0; kc < 4; kc++) {
-                    const bf16x8 kf = *(frag_ptr)(uintptr_t)(k_addr[t][kc] + so);
-                    s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kc], kc == 0 ? zero16 : s[t], 0, 0, 0);
-                }
-            float mx = s[0][0];
-#pragma unroll
-            for (int t = 0; t < 2; t++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[t][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float M_new = bf2f(f2bf(first ? mx : fmaxf(M, mx)));
-            const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(M - M_new);
-            M = M_new;
-            have_m = true;
-            l_part *= alpha;
-#pragma unroll
-            for (int d = 0; d < 2; d++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) o[d][r] *= alpha;
-            qn4.x = hi == 0 ? (unsigned)f2bf(-M) : 0u;
-            qneg = __builtin_bit_cast(bf16x8, qn4);
-            ts = 0.f;
-#pragma unroll
-            for (int t = 0; t < 2; t++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    s[t][r] = __builtin_amdgcn_exp2f(s[t][r] - M);
-                    ts += s[t][r];
-                }
-        }
-        l_part += ts;
-#pragma unroll
-        for (int t = 0; t < 2; t++)
-#pragma unroll
-            for (int cc = 0; cc < 2; cc++)
-                pw[t * 2 + cc] = make_uint4(pack_bf2(s[t][cc * 8 + 0], s[t][cc * 8 + 1]), pack_bf2(s[t][cc * 8 + 2], s[t][cc * 8 + 3]),
-                                            pack_bf2(s[t][cc * 8 + 4], s[t][cc * 8 + 5]), pack_bf2(s[t][cc * 8 + 6], s[t][cc * 8 + 7]));
-    };
-    // M phase of tile kv: S(kv+1) (if there is one; its offset state is the one softmax(kv) left) and O += V(kv)^T P(kv)^T.
-    // The V fragments come from hand-issued transpose-reads: behind an LDS-DMA hipcc puts a vmcnt(0) in front of every ds_read_tr BUILTIN,
-    // i.e. the phase would wait for the pieces requested one phase earlier (they have five phases to land).  The asm reads are invisible to
-    // that logic; `tr_wait` (lgkmcnt(0) with the destination registers as read-write operands) keeps their consumers behind their return.
-    // All sixteen are requested before the first QK^T MFMA and return under those.
-    unsigned long long tr_ts[12] = {};
-    const bool tr_on = (p.dbg & 1024) && blockIdx.x == 0 && (w == 0 || w == 4);
-    auto stamp = [&](int kv, int i) {
-        if (tr_on && kv == 8) tr_ts[i] = __builtin_amdgcn_s_memtime();
-    };
-    auto m_phase = [&](int kv, bool has_next) {
-        const unsigned so = (unsigned)((kv % APP_RING) * 16384);
-        stamp(kv, 3);
-        s16x4_t vlo[4][2], vhi[4][2];                  // [16-key chunk][d-block], two halves of the 8-key fragment
-        const unsigned va[2][2] = {{v_addr[0][0] + so, v_addr[0][1] + so}, {v_addr[1][0] + so, v_addr[1][1] + so}};
-        if (has_next) k_wait();      // requested before the barrier: back by now
-        stamp(kv, 4);
-        __builtin_amdgcn_s_setprio(1);
-        // Issue order: one MFMA, then two transpose-reads in its shadow (a 32x32x16 MFMA holds the matrix pipe for 32 cycles; an LDS read
-        // costs ~10 cycles of issue).  The scheduling barriers pin that order; without a next tile the reads go out back to back.
-        const bool sub = have_m;
-        if (has_next && sub) {
-#pragma unroll
-            for (int t = 0; t < 2; t++) s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kones, qneg, zero16, 0, 0, 0);
-        }
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int t = k & 1, kc = k >> 1, c8 = k >> 1, d = k & 1;
-            if (has_next) s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[t][kc], qf[kc], (kc == 0 && !sub) ? zero16 : s[t], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            switch (c8) {                              // (the chunk offset must be an immediate)
-                case 0: asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3" : "=&v"(vlo[0][d]), "=&v"(vhi[0][d]) : "v"(va[d][0]), "v"(va[d][1])); break;
-                case 1: asm volatile("ds_read_b64_tr_b16 %0, %2 offset:2048\n\tds_read_b64_tr_b16 %1, %3 offset:2048" : "=&v"(vlo[1][d]), "=&v"(vhi[1][d]) : "v"(va[d][0]), "v"(va[d][1])); break;
-                case 2: asm volatile("ds_read_b64_tr_b16 %0, %2 offset:4096\n\tds_read_b64_tr_b16 %1, %3 offset:4096" : "=&v"(vlo[2][d]), "=&v"(vhi[2][d]) : "v"(va[d][0]), "v"(va[d][1])); break;
-                default: asm volatile("ds_read_b64_tr_b16 %0, %2 offset:6144\n\tds_read_b64_tr_b16 %1, %3 offset:6144" : "=&v"(vlo[3][d]), "=&v"(vhi[3][d]) : "v"(va[d][0]), "v"(va[d][1])); break;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        stamp(kv, 6);
-        if (kv + 2 < n) k_addr_for(kv + 2);
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(vlo[0][0]), "+v"(vhi[0][0]), "+v"(vlo[0][1]), "+v"(vhi[0][1]), "+v"(vlo[1][0]), "+v"(vhi[1][0]), "+v"(vlo[1][1]), "+v"(vhi[1][1]),
-                       "+v"(vlo[2][0]), "+v"(vhi[2][0]), "+v"(vlo[2][1]), "+v"(vhi[2][1]), "+v"(vlo[3][0]), "+v"(vhi[3][0]), "+v"(vlo[3][1]), "+v"(vhi[3][1]));
-        stamp(kv, 7);
-        const bool dma = kv + 4 < n && !(p.dbg & 64);
-#pragma unroll
-        for (int c8 = 0; c8 < 4; c8++) {
-            const bf16x8 pf = __builtin_bit_cast(bf16x8, pw[c8]);
-#pragma unroll
-            for (int d = 0; d < 2; d++) {
-                const bf16x8 vf = __builtin_shufflevector(vlo[c8][d], vhi[c8][d], 0, 1, 2, 3, 4, 5, 6, 7);
-                o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
-            }
-            if (c8 == 0) {                             // this wave's two pieces of tile kv+4, in the shadow of the MFMAs just issued
-                __builtin_amdgcn_sched_barrier(0);
-                if (dma) stage(kv + 4);
-                __builtin_amdgcn_sched_barrier(0);
-                stamp(kv, 8);
-            }
-        }
-        stamp(kv, 9);
-        __builtin_amdgcn_s_setprio(0);
-    };
-    // End of a phase of iteration i (i = -1: the prologue).  Tile i+2's K fragments are requested at the end of V(i+1) -- of group 0 one barrier
-    // after this one at the earliest -- so before this barrier every wave's own pieces of tile i+2 must have landed.  The newest tile this wave
-    // has requested is i+4 after an M phase (the request sits in M(i)) and i+3 after a V phase; two pieces per tile, in-order completion.
-    auto phase_end = [&](int i, bool m_phase_end) {
-        const int d = min(n - 1, i + (m_phase_end ? 4 : 3)) - (i + 2);
-        if (m_phase_end) { if (d >= 2) app_wait<4>(); else if (d == 1) app_wait<2>(); else app_wait<0>(); }     // (+ the phase's LDS reads)
-        else { if (d >= 1) app_vm<2>(); else app_vm<0>(); }          // the K fragment requests just issued stay in flight across the barrier
-        app_bar();
-    };
-
-    // ---- prologue: tiles 0..3 requested, tile 0 landed ---------------------------------------------------------------------
-#pragma unroll
-    for (int t = 0; t < 4; t++)
-        if (t < n) stage(t);
-    if (n >= 4) app_wait<6>(); else if (n == 3) app_wait<4>(); else if (n == 2) app_wait<2>(); else app_wait<0>();
-    app_bar();
-    if (grp == 1 && !(p.dbg & 32)) app_bar();          // group 1 runs one phase behind
-    // P0: S(0) (and the peeled key's initial state)
-    if (active) {
-        k_addr_for(0);
-        k_issue();
-        if (n > 1) k_addr_for(1);
-        k_wait();
-        if constexpr (PEEL) {
-            const bool row0 = (lane & 31) == 0;
-            f32x16 s0t = zero16;
-#pragma unroll
-            for (int kc = 0; kc < 4; kc++) {
-                const uint4 kz = row0 ? k0u[kc] : make_uint4(0u, 0u, 0u, 0u);
-                s0t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kz), qf[kc], s0t, 0, 0, 0);
-            }
-            const float s0 = __shfl(s0t[0], lane & 31, 64);
-            if (__any(!(fabsf(s0) <= 40.f)) || (p.dbg & 5)) {
-                M = bf2f(f2bf(s0));
-                have_m = true;
-                qn4.x = hi == 0 ? (unsigned)f2bf(-M) : 0u;
-                qneg = __builtin_bit_cast(bf16x8, qn4);
-            }
-            const float p0 = __builtin_amdgcn_exp2f(s0 - M);
-            l_part = hi == 0 ? p0 : 0.f;
-            const uint4 pz = make_uint4(hi == 0 ? (unsigned)f2bf(p0) : 0u, 0u, 0u, 0u);
-#pragma unroll
-            for (int d = 0; d < 2; d++) {
-                const uint4 vz = make_uint4(hi == 0 ? (unsigned)v0u[d] : 0u, 0u, 0u, 0u);
-                o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vz), __builtin_bit_cast(bf16x8, pz), zero16, 0, 0, 0);
-            }
-        }
-        if (have_m) qk(true); else qk(false);
-    }
-    phase_end(-1, true);
-    for (int j = 0; j < n; j++) {
-        // ---- V(j): the softmax, then the K fragment requests of tile j+1 (returning under the barrier) ----
-        stamp(j, 0);
-        if (active) {
-            if (!(p.dbg & 8)) softmax(j, !PEEL && j == 0);
-            __builtin_amdgcn_sched_barrier(0);
-            stamp(j, 1);
-            if (j + 1 < n) k_issue();
-        }
-        stamp(j, 2);
-        phase_end(j, false);
-        // ---- M(j) ----
-        if (active && !(p.dbg & 16)) m_phase(j, j + 1 < n);
-        else if (j + 4 < n && !(p.dbg & 64)) stage(j + 4);          // a wave without live queries still stages its rows
-        stamp(j, 10);
-        phase_end(j, true);
-        stamp(j, 11);
-        if (tr_on && j == 8) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0)
-                for (int i = 0; i < 12; i++) ((unsigned*)(p.out + (int64_t)p.T * p.ld_out))[(w >> 2) * 16 + i] = (unsigned)tr_ts[i];     // pad row T of image 0
-        }
-    }
-    if (grp == 0 && !(p.dbg & 32)) app_bar();
-
-    // ---- epilogue (as above) ----
-    const float l_tot = l_part + __shfl_xor(l_part, 32, 64);
-    const float inv = 1.0f / l_tot;
-    int q0e = q0, be = b, he = h;
-    asm volatile("" : "+s"(q0e), "+s"(be), "+s"(he));
-    const int qr = q0e + (lane & 31) + (PEEL ? 1 : 0);
-    uint4 st[2][2];
-    pack_token_rows(o, inv, st);
-    if (active && qr < p.T) {
-        bf16_t* op = p.out + ((int64_t)be * p.Tp + qr) * p.ld_out + he * 64;
-#pragma unroll
-        for (int d = 0; d < 2; d++)
-#pragma unroll
-            for (int pr = 0; pr < 2; pr++) *(uint4*)(op + d * 32 + 16 * pr + 8 * hi) = st[d][pr];
-        if (p.lse && hi == 0) p.lse[((int64_t)be * p.H + he) * p.Tp + qr] = M + __builtin_amdgcn_logf(l_tot);
-    }
-}
-
 #ifdef OWL_TUNING   // tuning / race-hunting switches exist only in an OWL_TUNING build (include/owl_hip_tuning.h)
 static int g_attn_dbg = 0;
 extern "C" int owl_attention_debug(int flags) { g_attn_dbg = flags; return 0; }
@@ -869,20 +503,16 @@ extern "C" int owl_attention_debug(int flags) { g_attn_dbg = flags; return 0; }
 static constexpr int g_attn_dbg = 0;
 #endif
 
-// variant: 0 = the library's choice (ping-pong wherever it can be, peeled wherever it can be), 1 = plain tiling, 2 = peeled (row-major V, T - 1 a positive
-// multiple of 64), both on the free-running kernel; 3 = ping-pong kernel (row-major V; T a multiple of 64: plain tiling, T - 1 a multiple of 64: peeled)
+// variant: 0 = the library's choice (peeled wherever it can be), 1 = plain tiling, 2 = peeled (row-major V, T - 1 a positive multiple of 64)
 static int attn_fwd_launch(void* stream, const void* q, const void* k, int64_t ld_qk, const void* v, int v_row_major,
                            int64_t vt_img_stride, void* out, int64_t ld_out, float* lse, int64_t B, int64_t H, int64_t T,
                            int64_t Tp, float scale, int variant) {
     OWL_CHECK_ARG(q && k && v && out, "owl_attention_fwd_bf16: null pointer");
     OWL_CHECK_ARG(ld_qk % 8 == 0 && ld_out % 8 == 0 && Tp % 8 == 0 && T > 0 && T <= Tp, "owl_attention_fwd_bf16: bad strides (ld_qk %% 8, ld_out %% 8, Tp %% 8)");
-    OWL_CHECK_ARG(variant >= 0 && variant <= 3 && (variant <= 1 || v_row_major), "owl_attention_fwd: variant must be 0 (default), 1 (plain tiling), 2 (class token peeled) or 3 (ping-pong kernel); 2 / 3 need row-major V");
+    OWL_CHECK_ARG(variant >= 0 && variant <= 2 && (variant <= 1 || v_row_major), "owl_attention_fwd: variant must be 0 (default), 1 (plain tiling) or 2 (class token peeled; row-major V only)");
     const bool can_peel = v_row_major && T >= 65 && (T - 1) % 64 == 0;
     OWL_CHECK_ARG(variant != 2 || can_peel, "owl_attention_fwd: variant 2 (peeled) needs row-major V and T - 1 a positive multiple of 64");
-    const bool can_pp = v_row_major && (can_peel || (T >= 64 && T % 64 == 0));
-    OWL_CHECK_ARG(variant != 3 || can_pp, "owl_attention_fwd: variant 3 (ping-pong) needs row-major V and T or T - 1 a positive multiple of 64");
-    const bool pp = variant == 3 || (variant == 0 && can_pp);
-    const bool peel = variant == 2 || ((variant == 0 || variant == 3) && can_peel);
+    const bool peel = variant == 2 || (variant == 0 && can_peel);
     AttnFwdP p{};
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.ld_qk = ld_qk;
     p.vt = (const bf16_t*)v; p.vt_img_stride = vt_img_stride;
@@ -890,22 +520,9 @@ static int attn_fwd_launch(void* stream, const void* q, const void* k, int64_t l
     p.T = (int)T; p.Tp = (int)Tp; p.H = (int)H;
     p.scale_log2e = scale * 1.4426950408889634f;
     p.B = (int)B; p.dbg = g_attn_dbg;
-    const int qblk = pp ? 256 : 128;                                               // query rows per workgroup
-    p.nqb = peel ? (int)((T - 1 + qblk - 1) / qblk) + 1 : (int)((T + qblk - 1) / qblk);      // peeled: the last "block" is the class-token row
+    p.nqb = peel ? (int)((T - 1 + 127) / 128) + 1 : (int)((T + 127) / 128);      // peeled: the last "block" is the class-token row
     const int64_t npairs8 = (B * H + 7) / 8;                  // pairs per XCD (rounded up)
     dim3 grid((unsigned)(npairs8 * p.nqb * 8));
-    if (pp) {
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, APP_RING * 16384);
-            (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, APP_RING * 16384);
-            attr_done = true;
-        }
-        if (peel) hipLaunchKernelGGL((attn_fwd_pp_kernel<true>), grid, dim3(512), APP_RING * 16384, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((attn_fwd_pp_kernel<false>), grid, dim3(512), APP_RING * 16384, (hipStream_t)stream, p);
-        OWL_LAUNCH_CHECK();
-        return 0;
-    }
     if (!v_row_major) hipLaunchKernelGGL((attn_fwd_kernel<false>), grid, dim3(256), 2 * 16384, (hipStream_t)stream, p);
     else if (peel) hipLaunchKernelGGL((attn_fwd_kernel<true, true>), grid, dim3(256), 2 * 16384, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((attn_fwd_kernel<true>), grid, dim3(256), 2 * 16384, (hipStream_t)stream, p);

@@ -12,7 +12,7 @@ def case(B, H, T, rounds=7, iters=20):
     qkv = torch.zeros(ops.pad_rows(M), 3 * D, device=DEV, dtype=torch.bfloat16)
     qkv[:M] = torch.randn(M, 3 * D, device=DEV).bfloat16()
     outs = {}
-    for v in (1, 2, 3):
+    for v in (1, 2):
         o = torch.zeros(ops.pad_rows(M), D, device=DEV, dtype=torch.bfloat16)
         ops.attention_fwd_vrow(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, o, D, None, B, H, T, Tp, 0.125, variant=v)
         outs[v] = o
@@ -20,9 +20,9 @@ def case(B, H, T, rounds=7, iters=20):
     q, k, vv = (x[:, :, i].permute(0, 2, 1, 3) for i in range(3))
     want = (torch.softmax(q @ k.transpose(2, 3) * 0.125, -1) @ vv).permute(0, 2, 1, 3).reshape(T, D)
     e = {v: (outs[v][:Tp][:T].float() - want).abs().max().item() for v in (1, 2)}
-    print(f"B={B} H={H} T={T}: ping-pong == peeled bits: {torch.equal(outs[2], outs[3])}; max|plain - peeled| {(outs[1].float() - outs[2].float()).abs().max().item():.2e}; vs f32 softmax (image 0): plain {e[1]:.2e}, peeled {e[2]:.2e}", flush=True)
+    print(f"B={B} H={H} T={T}: max|plain - peeled| {(outs[1].float() - outs[2].float()).abs().max().item():.2e}; vs f32 softmax (image 0): plain {e[1]:.2e}, peeled {e[2]:.2e}", flush=True)
     o = outs[1]
-    runs = {"plain": (T, 1), "peeled": (T, 2), "ping-pong": (T, 3), "plain, T-1": (T - 1, 1)}
+    runs = {"plain": (T, 1), "peeled": (T, 2), "plain, T-1": (T - 1, 1)}
     times = {n: [] for n in runs}
     for _ in range(3):
         for n, (t, v) in runs.items():
