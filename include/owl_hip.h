@@ -64,9 +64,8 @@ int owl_cls_rows(void* stream, float* x, const float* cls, const float* pos, int
 /* ---- LayerNorm (HF5:484-486, 721-723; eps 1e-5).  out bf16 or f32 (may alias x); stats = (mean,rstd) */
 int owl_layernorm_fwd(void* stream, const float* x, const float* gamma, const float* beta, void* out, int out_bf16, float* stats, int64_t rows, int64_t D, float eps);
 /* fused residual add: x_out = x + delta (bf16 output of the previous branch's GEMM, HF5:500,507 `residual + hidden_states`),
- * out = LN(x_out).  x_out may alias x.
- * x_flags (experimental bf16 residual stream of the frozen prefix): bit 0 = x is bf16, bit 1 = x_out is bf16; 0 = f32 stream.                */
-int owl_add_layernorm_fwd(void* stream, const void* x, const void* delta_bf16, void* x_out, const float* gamma, const float* beta, void* out, int out_bf16, float* stats, int64_t rows, int64_t D, float eps, const void* delta2_bf16, int x_flags);
+ * out = LN(x_out).  x_out may alias x.                                                                              */
+int owl_add_layernorm_fwd(void* stream, const float* x, const void* delta_bf16, float* x_out, const float* gamma, const float* beta, void* out, int out_bf16, float* stats, int64_t rows, int64_t D, float eps, const void* delta2_bf16);
 
 /* ---- fused self-attention forward (HF5:377-402): softmax(Q K^T * scale) V, dh = 64 -----------------
  * q, k row-major [B*Tp, ld_qk] (head h at column h*64); vt = V^T per head [B][..][64][Tp] as written

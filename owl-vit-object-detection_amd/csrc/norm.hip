@@ -26,29 +26,20 @@ __device__ __forceinline__ void row_stats(const float4 (&v)[NV], int nvec, int l
 // With `delta` (bf16 GEMM output of the previous residual branch) the residual add is fused here:
 // x_new = x + delta is written to x_out (f32, may alias x) -- the GEMM epilogue then stores 2 bytes per
 // element instead of reading and writing 4 (the f32 residual epilogue was HBM/issue-bound).
-// XIN_BF16 / XOUT_BF16 (experiment): the residual stream of the frozen prefix kept in bf16 -- 16 instead of 22
-// bytes per element and layer through these kernels, at the price of rounding the stream itself twice per layer.
-template <bool OUT_BF16, bool XIN_BF16 = false, bool XOUT_BF16 = false>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const void* x_, const bf16_t* __restrict__ delta, void* x_out_,
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* x, const bf16_t* __restrict__ delta, float* x_out,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta, void* out,
                                                      float2* stats, int64_t rows, int D, float eps, const bf16_t* __restrict__ delta2) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int nvec = D >> 2;
-    const float* x = (const float*)x_;
-    float* x_out = (float*)x_out_;
     const float4* xr = (const float4*)(x + row * D);
     float4 v[LN_MAXV];
 #pragma unroll
     for (int i = 0; i < LN_MAXV; i++)
         if (lane + i * 64 < nvec) {
-            if constexpr (XIN_BF16) {
-                const uint2 ux = ((const uint2*)((const bf16_t*)x_ + row * D))[lane + i * 64];
-                v[i] = make_float4(bf2f(ux.x & 0xffff), bf2f(ux.x >> 16), bf2f(ux.y & 0xffff), bf2f(ux.y >> 16));
-            } else {
-                v[i] = xr[lane + i * 64];
-            }
+            v[i] = xr[lane + i * 64];
             if (delta) {
                 const uint2 u = ((const uint2*)(delta + row * D))[lane + i * 64];
                 v[i].x += bf2f(u.x & 0xffff); v[i].y += bf2f(u.x >> 16); v[i].z += bf2f(u.y & 0xffff); v[i].w += bf2f(u.y >> 16);
@@ -56,16 +47,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* x_, const bf16_
                     const uint2 u2 = ((const uint2*)(delta2 + row * D))[lane + i * 64];
                     v[i].x += bf2f(u2.x & 0xffff); v[i].y += bf2f(u2.x >> 16); v[i].z += bf2f(u2.y & 0xffff); v[i].w += bf2f(u2.y >> 16);
                 }
-                if (x_out) {
-                    if constexpr (XOUT_BF16) {
-                        uint2 o; o.x = pack_bf2(v[i].x, v[i].y); o.y = pack_bf2(v[i].z, v[i].w);
-                        ((uint2*)((bf16_t*)x_out_ + row * D))[lane + i * 64] = o;
-                        // the stream IS the rounded value from here on: normalise what the next kernel will read
-                        v[i] = make_float4(bf2f(o.x & 0xffff), bf2f(o.x >> 16), bf2f(o.y & 0xffff), bf2f(o.y >> 16));
-                    } else {
-                        ((float4*)(x_out + row * D))[lane + i * 64] = v[i];
-                    }
-                }
+                if (x_out) ((float4*)(x_out + row * D))[lane + i * 64] = v[i];
             }
         }
     float mean, rstd;
@@ -88,20 +70,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* x_, const bf16_
     }
 }
 
-static int ln_launch(void* stream, const void* x, const void* delta, void* x_out, const float* gamma, const float* beta, void* out,
-                     int out_bf16, float* stats, int64_t rows, int64_t D, float eps, const void* delta2 = nullptr, int x_flags = 0) {
+static int ln_launch(void* stream, const float* x, const void* delta, float* x_out, const float* gamma, const float* beta, void* out,
+                     int out_bf16, float* stats, int64_t rows, int64_t D, float eps, const void* delta2 = nullptr) {
     OWL_CHECK_ARG(x && gamma && beta && out, "owl_layernorm_fwd: null pointer");
     OWL_CHECK_ARG(D % 4 == 0 && D <= 256 * LN_MAXV, "owl_layernorm_fwd: D=%lld must be a multiple of 4 and <= 1024", (long long)D);
     OWL_CHECK_ARG(delta || !delta2, "owl_add_layernorm_fwd: delta2 without delta");
     dim3 grid((unsigned)((rows + 3) / 4));
-    if (x_flags) {         // bf16 residual stream (bit 0: x is bf16, bit 1: x_out is bf16); LN output bf16 only
-        OWL_CHECK_ARG(out_bf16 && x_flags >= 1 && x_flags <= 3, "owl_add_layernorm_fwd: x_flags needs the bf16 LN output");
-        if (x_flags == 1) hipLaunchKernelGGL((ln_fwd_kernel<true, true, false>), grid, dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)delta, x_out, gamma, beta, out, (float2*)stats, rows, (int)D, eps, (const bf16_t*)delta2);
-        else if (x_flags == 2) hipLaunchKernelGGL((ln_fwd_kernel<true, false, true>), grid, dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)delta, x_out, gamma, beta, out, (float2*)stats, rows, (int)D, eps, (const bf16_t*)delta2);
-        else hipLaunchKernelGGL((ln_fwd_kernel<true, true, true>), grid, dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)delta, x_out, gamma, beta, out, (float2*)stats, rows, (int)D, eps, (const bf16_t*)delta2);
-        OWL_LAUNCH_CHECK();
-        return 0;
-    }
     if (out_bf16)
         hipLaunchKernelGGL(ln_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)delta, x_out, gamma, beta, out, (float2*)stats, rows, (int)D, eps, (const bf16_t*)delta2);
     else
@@ -117,11 +91,11 @@ extern "C" int owl_layernorm_fwd(void* stream, const float* x, const float* gamm
 
 // s = x + delta (+ delta2), bf16 branch outputs;  out = LN(s);  x_out = s unless x_out is null (the sum is then re-formed, from the
 // same operands in the same order, by the next call -- saves writing 4 bytes per element where nobody else reads the sum)
-extern "C" int owl_add_layernorm_fwd(void* stream, const void* x, const void* delta_bf16, void* x_out, const float* gamma,
+extern "C" int owl_add_layernorm_fwd(void* stream, const float* x, const void* delta_bf16, float* x_out, const float* gamma,
                                      const float* beta, void* out, int out_bf16, float* stats, int64_t rows, int64_t D, float eps,
-                                     const void* delta2_bf16, int x_flags) {
+                                     const void* delta2_bf16) {
     OWL_CHECK_ARG(delta_bf16, "owl_add_layernorm_fwd: null delta");
-    return ln_launch(stream, x, delta_bf16, x_out, gamma, beta, out, out_bf16, stats, rows, D, eps, delta2_bf16, x_flags);
+    return ln_launch(stream, x, delta_bf16, x_out, gamma, beta, out, out_bf16, stats, rows, D, eps, delta2_bf16);
 }
 
 // Class-token rows: X[b*Tp + 0, :] = class_embedding + pos[0]   (HF5:338-343)

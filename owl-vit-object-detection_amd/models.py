@@ -64,7 +64,7 @@ def _flat_order(cfg: OwlConfig):
 class OwlViT(nn.Module):
     """Vision-only OWL-ViT with a learnable query bank (ref src/models.py:41-119)."""
 
-    def __init__(self, cfg: OwlConfig, state: "dict[str, np.ndarray]", device="cuda", bf16_stream: bool = False, encoder_streams: int = 2):
+    def __init__(self, cfg: OwlConfig, state: "dict[str, np.ndarray]", device="cuda", encoder_streams: int = 2):
         super().__init__()
         self.cfg = cfg
         self.device_ = torch.device(device)
@@ -135,9 +135,6 @@ class OwlViT(nn.Module):
         self._ws = {}
         self._saved = None
         self._bf16_version = None          # flat_param._version the bf16 compute copy was cast from
-        # Experiment only, measured and rejected: residual stream of the frozen prefix in bf16.  +1 % step rate
-        # for twice the forward error (boxes 1.9e-3 -> 3.9e-3 / 4.5e-3) -- tools/bf16_stream_study.py reproduces both numbers.
-        self._bf16_stream = bool(bf16_stream)
         self.encoder_streams = int(encoder_streams)     # sub-batches of the encoder forward, one HIP stream each (see _forward_impl); 1 = off
         self._streams, self._join, self._fork_ev = [], {}, None
         self._dw_events_ = None
@@ -207,7 +204,6 @@ class OwlViT(nn.Module):
             qhat=torch.zeros(32, Dt, device=dev), qnorm=torch.zeros(32, device=dev),
             argmax=torch.zeros(Mh, C, dtype=torch.uint8, device=dev), inv_norm=torch.zeros(Mh, device=dev),
             img=torch.zeros(B, 3, cfg.image_size, cfg.image_size, dtype=bf, device=dev),
-            xb=z(M, D, bf, dev) if self._bf16_stream else None,
             gen=0,
         )
         self._ws[key] = ws
@@ -306,8 +302,6 @@ class OwlViT(nn.Module):
         # Residual adds (HF5:500,507) live in the LayerNorm kernels: the GEMM in front of each emits a bf16
         # delta through the fast wide-store epilogue, and LN does x += delta while it normalises.
         x_cur = R(Ls["x_in"]) if sv else xs
-        if self._bf16_stream and not sv and pending is not None:
-            x_cur = R(ws["xb"]) if i < cfg.layers - 1 else R(ws["x"])     # (the final merge-LN reads f32)  experiment: bf16 residual stream of the frozen prefix
         if pending is None:
             if sv:
                 x_cur.copy_(xs)

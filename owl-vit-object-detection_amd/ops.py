@@ -71,16 +71,14 @@ def cls_rows(x, cls, pos, B, Tp, D):
 def layernorm(x, gamma, beta, out, rows, D, stats=None, eps=1e-5, delta=None, x_out=None, delta2=None, store_x=True):
     """out = LN(x) -- or, with `delta` (bf16; optionally a second one), s = x + delta (+ delta2), out = LN(s) and
     x_out = s in one pass; `store_x=False` skips the write of s (the caller re-forms it later from the same operands)."""
-    _chk(gamma, torch.float32, "gamma"); _chk(beta, torch.float32, "beta")
+    _chk(x, torch.float32, "x"); _chk(gamma, torch.float32, "gamma"); _chk(beta, torch.float32, "beta")
     ob = 1 if out.dtype == torch.bfloat16 else 0
     if delta is None:
-        _chk(x, torch.float32, "x")
         _lib.call("owl_layernorm_fwd", stream(), x, gamma, beta, out, ob, stats, rows, D, float(eps))
     else:
         _chk(delta, torch.bfloat16, "delta"); _chk(delta2, torch.bfloat16, "delta2")
         xo = (x_out if x_out is not None else x) if store_x else None
-        flags = (1 if x.dtype == torch.bfloat16 else 0) | (2 if (xo is not None and xo.dtype == torch.bfloat16) else 0)
-        _lib.call("owl_add_layernorm_fwd", stream(), x, delta, xo, gamma, beta, out, ob, stats, rows, D, float(eps), delta2, flags)
+        _lib.call("owl_add_layernorm_fwd", stream(), x, delta, xo, gamma, beta, out, ob, stats, rows, D, float(eps), delta2)
     return out
 
 
