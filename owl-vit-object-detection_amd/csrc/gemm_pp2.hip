@@ -1,0 +1,232 @@
+// Two-phase ping-pong variant of the 256x256x64 bf16 GEMM (bias / quick-GELU epilogues): same tile, same LDS image, same epilogues and the
+// same accumulation order as gemm_pp.hip (identical bits) -- a different split of the K-tile into phases.
+//
+// gemm_pp.hip runs a K-tile as FOUR quadrant phases of 8 MFMAs on TWO accumulator tiles: two dependent chains, which one wave issues at
+// ~36 cycles per MFMA instead of 32 (a chain's next MFMA needs the previous one's result: `s_memtime` traces, tools/probe), and eight
+// barriers per K-tile.  Here a K-tile is TWO phases of 16 MFMAs on FOUR accumulator tiles (four independent chains, four deep):
+//     phase A: rows i0,i1 x columns j0,j1     LOAD A: A(i0,i1) + B(j0) + B(j1) fragments (16 ds_read_b128) + this wave's 4 A pieces
+//     phase B: rows i2,i3 x columns j0,j1     LOAD B: A(i2,i3) fragments (8; B stays in registers)           + this wave's 4 B pieces
+// The two groups (waves 0-3 / 4-7 = output rows 0-127 / 128-255, one wave of each per SIMD) run one barrier apart, as there.
+// LDS lifetime: a buffer's B rows are free once both groups have run LOAD A, its A rows once both have run LOAD B.  So the B pieces run TWO
+// K-tiles ahead (requested in LOAD B of K-tile c into the buffer c is being computed from) and the A pieces ONE K-tile ahead (requested in
+// LOAD A of K-tile c into the other buffer, whose A rows K-tile c-1 released one barrier earlier): two independent DMA cursors that cross
+// tile boundaries of the persistent loop.  One counted wait per K-tile, at the end of LOAD B: everything but the B pieces just requested has
+// landed -- that is K-tile c+1 complete, for both groups, before the first barrier after which anybody reads it.
+// (A second version gave every group its own A rows to stage -- rows i0,i1 two K-tiles ahead, rows i2,i3 one ahead, two counted waits per
+// K-tile, five to six half-slots of flight for every piece instead of two for the A pieces -- and measured 4-5 % slower than this one on the
+// model's shapes: the extra cursor and wait cost more than the longer flight buys.  profiles/r02_gemm_two_phase.md)
+#include "gemm_common.h"
+#include <type_traits>
+
+static constexpr int QBM = 256, QBN = 256, QBK = 64;
+static constexpr int Q_A_BYTES = QBM * QBK * 2, Q_B_BYTES = QBN * QBK * 2, Q_STAGE = Q_A_BYTES + Q_B_BYTES;   // 32 + 32 KiB
+static constexpr int Q_BIAS_OFF = 2 * Q_STAGE, Q_LDS = 2 * Q_STAGE + 2 * 1024;
+
+template <int N> __device__ __forceinline__ void q_wait() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void q_wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void q_bar() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hi = lane >> 5;
+    const int grp = w >> 2, wc = w & 3;
+    const int nk = (int)(p.K / QBK);                 // >= 2 (host checks)
+    const int nitems = p.tiles_m * p.tiles_n;
+    int item, item_end, item_step;
+    if (p.persistent) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, chunk = (nitems + 7) >> 3;
+        item = xcd * chunk + idx; item_end = min(nitems, (xcd + 1) * chunk); item_step = gridDim.x >> 3;
+    } else {
+        item = xcd_remap(blockIdx.x, nitems); item_end = item + 1; item_step = 1;
+    }
+    if (item >= item_end) return;
+
+    // ---- two DMA cursors over the K-tiles in consumption order (across the persistent tile loop) ----------------------------
+    int a_item = item, a_k = 0, a_buf = 0;                     // A pieces: one K-tile ahead
+    int b_item = item, b_k = 0, b_buf = 0, b_parity = 0;       // B pieces (+ the tile's bias slice): two K-tiles ahead
+    unsigned a_voff[2][2], w_voff[2][2], b_voff = 0;           // [half][q]: wave w stages rows half*128 + (w*2+q)*8 + (lane>>3) of a half-tile
+    const bf16_t* a_base = nullptr;
+    const bf16_t* w_base = nullptr;
+    const float* b_base = nullptr;
+    const bool has_bias = p.bias != nullptr;
+    auto stage_A = [&]() {                                     // 4 VMEM ops
+        if (a_k == 0) {
+            const int tm = a_item / p.tiles_n;
+            const int64_t m0 = (int64_t)tm * QBM;
+            a_base = p.A + m0 * p.lda;
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int r = h * 128 + (w * 2 + q) * 8 + (lane >> 3);
+                    const int c = (lane & 7) ^ ((r >> 1) & 7);
+                    int64_t am = m0 + r; if (am >= p.a_rows) am = p.a_rows - 1;
+                    a_voff[h][q] = (unsigned)(((am - m0) * p.lda + c * 8) * 2);
+                }
+        }
+        unsigned char* base = lds + a_buf * Q_STAGE;
+        const unsigned char* g = (const unsigned char*)(a_base + (int64_t)a_k * QBK);
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+                __builtin_amdgcn_global_load_lds(GPTR(g + a_voff[h][q]), LPTR(base + (h * 128 + (w * 2 + q) * 8) * 128), 16, 0, 0);
+        a_buf ^= 1;
+        if (++a_k == nk) { a_k = 0; a_item += item_step; }
+    };
+    auto stage_B = [&]() -> int {                              // 4 or 5 VMEM ops
+        const bool first = b_k == 0;
+        if (first) {
+            const int tm = b_item / p.tiles_n, tn = b_item - tm * p.tiles_n;
+            const int64_t n0 = (int64_t)tn * QBN;
+            w_base = p.W + n0 * p.ldw;
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int r = h * 128 + (w * 2 + q) * 8 + (lane >> 3);
+                    const int c = (lane & 7) ^ ((r >> 1) & 7);
+                    int64_t wn = n0 + r; if (wn >= p.w_rows) wn = p.w_rows - 1;
+                    w_voff[h][q] = (unsigned)(((wn - n0) * p.ldw + c * 8) * 2);
+                }
+            if (has_bias) {
+                int64_t n = n0 + lane * 4; if (n + 4 > p.N) n = p.N - 4;
+                b_base = p.bias + n0;
+                b_voff = (unsigned)((n - n0) * 4);
+            }
+        }
+        unsigned char* base = lds + b_buf * Q_STAGE + Q_A_BYTES;
+        const unsigned char* g = (const unsigned char*)(w_base + (int64_t)b_k * QBK);
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+                __builtin_amdgcn_global_load_lds(GPTR(g + w_voff[h][q]), LPTR(base + (h * 128 + (w * 2 + q) * 8) * 128), 16, 0, 0);
+        int n_ops = 4;
+        if (first && has_bias) {
+            __builtin_amdgcn_global_load_lds(GPTR((const unsigned char*)b_base + b_voff), LPTR(lds + Q_BIAS_OFF + b_parity * 1024), 16, 0, 0);
+            n_ops = 5;
+        }
+        b_buf ^= 1;
+        if (++b_k == nk) { b_k = 0; b_item += item_step; b_parity ^= 1; }
+        return n_ops;
+    };
+
+    const int a_row0 = grp * 128 + (lane & 31), b_row0 = wc * 64 + (lane & 31);
+    const int a_base_off = a_row0 * 128, b_base_off = Q_A_BYTES + b_row0 * 128;
+    const int a_swz = (a_row0 >> 1) & 7, b_swz = (b_row0 >> 1) & 7;
+
+    // prologue: B(0) (+ bias), A(0), B(1) requested; K-tile 0 landed (B(1) may stay in flight)
+    stage_B(); stage_A(); stage_B();
+    q_wait<4>();
+    q_bar();
+
+    int cur = 0, tile_parity = 0;
+    while (true) {
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+        const int tm = item / p.tiles_n, tn = item - tm * p.tiles_n;
+        const int64_t cm0 = (int64_t)tm * QBM, cn0 = (int64_t)tn * QBN;
+        if (grp == 1) q_bar();                       // (re-)create the one-barrier offset
+        for (int kt = 0; kt < nk; kt++) {
+            const unsigned char* tb = lds + cur * Q_STAGE;
+            bf16x8 fa[2][4], fb[2][4];                // [row tile of the phase][kc], [j][kc]
+            auto ld_a = [&](int ih) {
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+#pragma unroll
+                    for (int kc = 0; kc < 4; kc++)
+                        fa[t][kc] = *(const bf16x8*)(tb + a_base_off + (2 * ih + t) * 4096 + (((kc * 2 + hi) ^ a_swz) << 4));
+            };
+            auto mma = [&](int ih) {                   // 16 MFMAs, four independent chains (kc outer: every chain sees kc = 0..3 in order)
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int kc = 0; kc < 4; kc++)
+#pragma unroll
+                    for (int t = 0; t < 2; t++)
+#pragma unroll
+                        for (int j = 0; j < 2; j++)
+                            acc[2 * ih + t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][kc], fa[t][kc], acc[2 * ih + t][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+            };
+            // ---- phase A ----
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int kc = 0; kc < 4; kc++) fb[j][kc] = *(const bf16x8*)(tb + b_base_off + j * 4096 + (((kc * 2 + hi) ^ b_swz) << 4));
+            ld_a(0);
+            if (a_item < item_end) stage_A();         // A rows of the OTHER buffer: released by both groups' LOAD B of the previous K-tile
+            q_wait_lgkm();
+            q_bar();
+            mma(0);
+            q_bar();
+            // ---- phase B ----
+            ld_a(1);
+            int n_new = 0;
+            if (b_item < item_end) n_new = stage_B();   // B rows of THIS buffer: both groups have run LOAD A
+            if (n_new == 5) q_wait<5>(); else if (n_new == 4) q_wait<4>(); else q_wait<0>();   // K-tile kt+1 complete (all but the pieces just requested)
+            q_bar();
+            mma(1);
+            q_bar();
+            cur ^= 1;
+        }
+        if (grp == 0) q_bar();                       // let group 1 finish its last MFMA half: epilogues run together
+        const bool inner = (cm0 + QBM <= p.M) && (cn0 + QBN <= p.N);
+        const float* lbias = (const float*)(lds + Q_BIAS_OFF + tile_parity * 1024) + wc * 64;
+        auto run = [&](auto guard_tag) {
+            constexpr bool G = decltype(guard_tag)::value;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const int64_t mt = cm0 + grp * 128 + i * 32, nt = cn0 + wc * 64 + j * 32;
+                    uint4 c0, c1;
+                    epi_tile_bf16<EPI, G>(p, acc[i][j], mt, nt, lane, c0, c1, lbias + j * 32);
+                    epi_store_chunk<EPI, G>(p, c0, mt, nt, 0, lane);
+                    epi_store_chunk<EPI, G>(p, c1, mt, nt, 1, lane);
+                }
+        };
+        if (inner) run(std::false_type{}); else run(std::true_type{});
+        item += item_step;
+        if (item >= item_end) break;
+        tile_parity ^= 1;
+    }
+}
+
+template <int EPI>
+static int launch_pp2(hipStream_t s, GemmP p) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)gemm_pp2_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
+        attr_done = true;
+    }
+    p.tiles_m = (int)((p.M + QBM - 1) / QBM); p.tiles_n = (int)((p.N + QBN - 1) / QBN);
+    p.nsplit = 1; p.dbg = 0;
+    const int nitems = p.tiles_m * p.tiles_n;
+    p.persistent = nitems > 256 ? 1 : 0;
+    hipLaunchKernelGGL((gemm_pp2_kernel<EPI>), dim3(p.persistent ? 256 : nitems), dim3(512), Q_LDS, s, p);
+    OWL_LAUNCH_CHECK();
+    return 0;
+}
+
+// called from gemm.hip's dispatcher; returns 1 if this variant does not handle `epi`
+int owl_gemm_pp2_launch(hipStream_t s, int epi, const GemmP& p) {
+    switch (epi) {
+        case EPI_BIAS_BF16: return launch_pp2<EPI_BIAS_BF16>(s, p);
+        case EPI_QGELU_BF16: return launch_pp2<EPI_QGELU_BF16>(s, p);
+        default: return 1;
+    }
+}

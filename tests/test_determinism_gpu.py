@@ -87,6 +87,10 @@ def test_gemm_pingpong_matches_tile256_bitwise(N, K, epi):
     # software-pipelined inside the wave, LDS-DMA pieces spread over three K-steps) shares the epilogue and the K order
     for _ in range(6):
         assert torch.equal(run(4), ref)
+    # the two-phase ping-pong kernel (csrc/gemm_pp2.hip: a K-tile = two phases of 16 MFMAs on four accumulator tiles, A pieces one K-tile
+    # ahead / B pieces two ahead on separate DMA cursors); handles the bias and quick-GELU epilogues, falls through to tile 8 otherwise
+    for _ in range(12):
+        assert torch.equal(run(7), ref)
 
 
 def test_attention_bwd_bitwise_repeatable():
