@@ -130,6 +130,13 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
     q_bar();
 
     int cur = 0, tile_parity = 0;
+    // Store-bound epilogue (bias): group 1 runs ONE barrier interval behind group 0 for the WHOLE persistent loop -- the epilogue is just
+    // another interval: group 0 converts and stores its half of a tile while group 1 runs its last MFMA phase, group 1 stores while group 0
+    // already reads the next tile's first fragments (+2 % on top of the two-phase K-tile at K = 768 / 3072).  VALU-bound epilogue (quick-GELU:
+    // an exp and a reciprocal per element): two staggered epilogues in a row cost more than both together (-6 %), so there the groups are
+    // re-synchronised at every tile as in gemm_pp.hip -- group 0 waits for group 1's last MFMA phase, both run their epilogues in one interval.
+    constexpr bool STAGGERED_EPI = (EPI == EPI_BIAS_BF16);
+    if (STAGGERED_EPI && grp == 1) q_bar();
     while (true) {
         f32x16 acc[4][2];
 #pragma unroll
@@ -140,7 +147,7 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
                 for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
         const int tm = item / p.tiles_n, tn = item - tm * p.tiles_n;
         const int64_t cm0 = (int64_t)tm * QBM, cn0 = (int64_t)tn * QBN;
-        if (grp == 1) q_bar();                       // (re-)create the one-barrier offset
+        if (!STAGGERED_EPI && grp == 1) q_bar();     // (re-)create the one-barrier offset
         for (int kt = 0; kt < nk; kt++) {
             const unsigned char* tb = lds + cur * Q_STAGE;
             bf16x8 fa[2][4], fb[2][4];                // [row tile of the phase][kc], [j][kc]
@@ -183,7 +190,7 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
             q_bar();
             cur ^= 1;
         }
-        if (grp == 0) q_bar();                       // let group 1 finish its last MFMA half: epilogues run together
+        if (!STAGGERED_EPI && grp == 0) q_bar();     // let group 1 finish its last MFMA phase: epilogues run together
         const bool inner = (cm0 + QBM <= p.M) && (cn0 + QBN <= p.N);
         const float* lbias = (const float*)(lds + Q_BIAS_OFF + tile_parity * 1024) + wc * 64;
         auto run = [&](auto guard_tag) {
@@ -200,10 +207,12 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
                 }
         };
         if (inner) run(std::false_type{}); else run(std::true_type{});
+        if (STAGGERED_EPI) q_bar();                  // the epilogue interval
         item += item_step;
         if (item >= item_end) break;
         tile_parity ^= 1;
     }
+    if (STAGGERED_EPI && grp == 0) q_bar();          // group 1's last interval
 }
 
 template <int EPI>
