@@ -13,10 +13,10 @@ HBM, random-init weights (no network on the box).
 (torch.distributed.run, one process per GPU, RCCL); it exits non-zero if fewer than N GPUs are visible.
 
 Prints ONE JSON line (rank 0) with the driver's contract plus:
-  roofline       -- the dominant kernel by time (`gemm_pp_kernel<bias>`: QKV / out-proj / fc2 / dX GEMMs, ~30 % of the
+  roofline       -- the dominant kernel by time (`gemm_pp2_kernel<bias>`: QKV / out-proj / fc2 / dX GEMMs, ~30 % of the
                     step): algorithmic FLOPs per launch / mean launch duration, HIP events on the launch stream inside
                     the timed region; peak = 2.5 PFLOP/s dense bf16 MFMA (MI355X_MICROARCH.md)
-  roofline_other -- the same measurement for the fc1 GEMM (`gemm_pp_kernel<qgelu>`) and the fused attention forward
+  roofline_other -- the same measurement for the fc1 GEMM (`gemm_pp2_kernel<qgelu>`) and the fused attention forward
   cpu_baseline   -- the CPU oracle (parity-checked restatement of the reference path) timed on this box's host cores
                     (batch 1 and batch 8, median of >= 5 steps after 2 warm-ups), rank 0 at N = 1 only
 """
@@ -45,7 +45,7 @@ PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md "Peak BF16/FP
 # HBM bytes per launch of the timed kernels for the default workload (B/16, batch 32): PMC passes over this very command
 # (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE in separate passes, FETCH x2 per MI355X_MICROARCH.md "HBM"); None elsewhere
 TRAFFIC_SOURCE = "profiles/r02_hbm_traffic.md"
-TRAFFIC = {"gemm_pp_kernel<bias>": None, "gemm_pp_kernel<qgelu>": None, "attn_fwd_kernel<VROW>": None}
+TRAFFIC = {"gemm_pp2_kernel<bias>": None, "gemm_pp2_kernel<qgelu>": None, "attn_fwd_kernel<VROW>": None}
 try:
     with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as _f:
         TRAFFIC.update(json.load(_f))
@@ -236,7 +236,7 @@ def main():
         K = K if K is not None else A.shape[-1]; N = N if N is not None else W.shape[0]; M = M if M is not None else A.shape[0]
         if not (K % 128 == 0 and M >= 512 and N >= 256):
             return None                                            # not the ping-pong kernel (csrc/gemm.hip dispatch)
-        return ("gemm_pp_kernel<bias>" if epi == ops.EPI_BIAS_BF16 else "gemm_pp_kernel<qgelu>", 2.0 * M * N * K)
+        return ("gemm_pp2_kernel<bias>" if epi == ops.EPI_BIAS_BF16 else "gemm_pp2_kernel<qgelu>", 2.0 * M * N * K)
 
     def classify_attn(q, k, v, ld, out, ld_out, lse, B_, H, T, Tp, scale):
         return ("attn_fwd_kernel<VROW>", 4.0 * B_ * H * T * T * 64)   # QK^T + PV per launch
@@ -337,7 +337,7 @@ def main():
             out["allreduce_ms"] = round(float(np.mean([a.elapsed_time(b) for a, b in ar_events])), 4)
             out["allreduce_bytes"] = int(model.flat_numel * 4)
         main_r, others = None, []
-        for label in ("gemm_pp_kernel<bias>", "gemm_pp_kernel<qgelu>", "attn_fwd_kernel<VROW>"):
+        for label in ("gemm_pp2_kernel<bias>", "gemm_pp2_kernel<qgelu>", "attn_fwd_kernel<VROW>"):
             r = kt.summary(label)
             if r is None:
                 continue

@@ -1,4 +1,4 @@
-// Two-phase ping-pong variant of the 256x256x64 bf16 GEMM (bias / quick-GELU epilogues): same tile, same LDS image, same epilogues and the
+// Two-phase ping-pong variant of the 256x256x64 bf16 GEMM (every epilogue but the transposing one): same tile, same LDS image, same epilogues and the
 // same accumulation order as gemm_pp.hip (identical bits) -- a different split of the K-tile into phases.
 //
 // gemm_pp.hip runs a K-tile as FOUR quadrant phases of 8 MFMAs on TWO accumulator tiles: two dependent chains, which one wave issues at
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
     // already reads the next tile's first fragments (+2 % on top of the two-phase K-tile at K = 768 / 3072).  VALU-bound epilogue (quick-GELU:
     // an exp and a reciprocal per element): two staggered epilogues in a row cost more than both together (-6 %), so there the groups are
     // re-synchronised at every tile as in gemm_pp.hip -- group 0 waits for group 1's last MFMA phase, both run their epilogues in one interval.
-    constexpr bool STAGGERED_EPI = (EPI == EPI_BIAS_BF16);
+    constexpr bool STAGGERED_EPI = (EPI == EPI_BIAS_BF16 || EPI == EPI_F32 || EPI == EPI_ACC_F32);
     if (STAGGERED_EPI && grp == 1) q_bar();
     while (true) {
         f32x16 acc[4][2];
@@ -195,15 +195,27 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
         const float* lbias = (const float*)(lds + Q_BIAS_OFF + tile_parity * 1024) + wc * 64;
         auto run = [&](auto guard_tag) {
             constexpr bool G = decltype(guard_tag)::value;
+            constexpr bool AUX_IN = (EPI == EPI_DQGELU_BF16);     // saved pre-activations of all eight 32x32 tiles requested up front (gemm_pp.hip)
+            uint4 auxr[AUX_IN ? 4 : 1][2][2];
+            if constexpr (AUX_IN) {
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++) epi_aux_load<G>(p, cm0 + grp * 128 + i * 32, cn0 + wc * 64 + j * 32, lane, auxr[i][j]);
+            }
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
                     const int64_t mt = cm0 + grp * 128 + i * 32, nt = cn0 + wc * 64 + j * 32;
-                    uint4 c0, c1;
-                    epi_tile_bf16<EPI, G>(p, acc[i][j], mt, nt, lane, c0, c1, lbias + j * 32);
-                    epi_store_chunk<EPI, G>(p, c0, mt, nt, 0, lane);
-                    epi_store_chunk<EPI, G>(p, c1, mt, nt, 1, lane);
+                    if constexpr (EPI == EPI_F32 || EPI == EPI_ACC_F32) {
+                        epi_tile_f32<EPI, G>(p, acc[i][j], mt, nt, lane, lbias + j * 32);
+                    } else {
+                        uint4 c0, c1;
+                        epi_tile_bf16<EPI, G>(p, acc[i][j], mt, nt, lane, c0, c1, lbias + j * 32, AUX_IN ? auxr[AUX_IN ? i : 0][j] : nullptr);
+                        epi_store_chunk<EPI, G>(p, c0, mt, nt, 0, lane);
+                        epi_store_chunk<EPI, G>(p, c1, mt, nt, 1, lane);
+                    }
                 }
         };
         if (inner) run(std::false_type{}); else run(std::true_type{});
@@ -236,6 +248,11 @@ int owl_gemm_pp2_launch(hipStream_t s, int epi, const GemmP& p) {
     switch (epi) {
         case EPI_BIAS_BF16: return launch_pp2<EPI_BIAS_BF16>(s, p);
         case EPI_QGELU_BF16: return launch_pp2<EPI_QGELU_BF16>(s, p);
-        default: return 1;
+        case EPI_DQGELU_BF16: return launch_pp2<EPI_DQGELU_BF16>(s, p);
+        case EPI_GELU_BF16: return launch_pp2<EPI_GELU_BF16>(s, p);
+        case EPI_DGELU_BF16: return launch_pp2<EPI_DGELU_BF16>(s, p);
+        case EPI_F32: return launch_pp2<EPI_F32>(s, p);               // class head e = W feats + b, dfeats
+        case EPI_ACC_F32: return launch_pp2<EPI_ACC_F32>(s, p);       // dfeats += (box head)
+        default: return 1;                                            // (the transposing epilogue stays on the four-phase kernel)
     }
 }

@@ -88,7 +88,7 @@ def test_gemm_pingpong_matches_tile256_bitwise(N, K, epi):
     for _ in range(6):
         assert torch.equal(run(4), ref)
     # the two-phase ping-pong kernel (csrc/gemm_pp2.hip: a K-tile = two phases of 16 MFMAs on four accumulator tiles, A pieces one K-tile
-    # ahead / B pieces two ahead on separate DMA cursors); handles the bias and quick-GELU epilogues, falls through to tile 8 otherwise
+    # ahead / B pieces two ahead on separate DMA cursors); every epilogue but the transposing one
     for _ in range(12):
         assert torch.equal(run(7), ref)
 
@@ -192,6 +192,8 @@ def test_gemm_f32_epilogues_pingpong_matches_tile256_bitwise(N, K, epi):
     assert not torch.equal(ref[:M], base[:M])
     for _ in range(6):
         assert torch.equal(run(8), ref)
+    for _ in range(6):
+        assert torch.equal(run(7), ref)             # two-phase ping-pong kernel
     assert torch.equal(run(0), ref)
 
 

@@ -10,21 +10,29 @@ DEV = "cuda"
 def case(name, M, N, K, epi, rounds=5, iters=10):
     A = torch.randn(ops.pad_rows(M), K, device=DEV).bfloat16(); W = (torch.randn(N, K, device=DEV) * 0.05).bfloat16()
     b = torch.randn(N, device=DEV)
+    f32 = epi in (ops.EPI_F32, ops.EPI_ACC_F32)
+    aux = torch.randn(ops.pad_rows(M), N, device=DEV).bfloat16() if epi in (ops.EPI_DQGELU_BF16, ops.EPI_DGELU_BF16) else None
+    _gemm = ops.gemm
+    def gemm(epi, A, W, o, bias=None, M=None, tile=None):
+        return _gemm(epi, A, W, o, bias=None if aux is not None else bias, aux=aux, M=M, tile=tile)
+    class _O:                                      # (local shim: same call shape for every epilogue)
+        pass
+    ops_gemm = gemm
     outs = {}
     for t in (8, 7):
-        o = torch.zeros(ops.pad_rows(M), N, device=DEV, dtype=torch.bfloat16)
-        ops.gemm(epi, A, W, o, bias=b, M=M, tile=t); outs[t] = o
+        o = torch.zeros(ops.pad_rows(M), N, device=DEV, dtype=torch.float32 if f32 else torch.bfloat16)
+        ops_gemm(epi, A, W, o, bias=b, M=M, tile=t); outs[t] = o
     torch.cuda.synchronize()
     eq = torch.equal(outs[7], outs[8])
     o = outs[8]
     times = {8: [], 7: []}
     for _ in range(2):
         for t in (8, 7):
-            for _ in range(iters): ops.gemm(epi, A, W, o, bias=b, M=M, tile=t)
+            for _ in range(iters): ops_gemm(epi, A, W, o, bias=b, M=M, tile=t)
     for r in range(rounds):
         for t in (8, 7):
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
-            for _ in range(iters): ops.gemm(epi, A, W, o, bias=b, M=M, tile=t)
+            for _ in range(iters): ops_gemm(epi, A, W, o, bias=b, M=M, tile=t)
             e1.record(); torch.cuda.synchronize(); times[t].append(e0.elapsed_time(e1) / iters)
     fl = 2.0 * M * N * K
     m8, m7 = sorted(times[8])[rounds // 2], sorted(times[7])[rounds // 2]
@@ -41,4 +49,8 @@ if __name__ == "__main__":
     case("half batch fc1", M // 2, 3072, 768, ops.EPI_QGELU_BF16)
     case("half batch fc2", M // 2, 768, 3072, ops.EPI_BIAS_BF16)
     case("L/14 fc1", 16 * 3608, 4096, 1024, ops.EPI_QGELU_BF16)
+    case("dX through quick-GELU'", M, 3072, 768, ops.EPI_DQGELU_BF16)
+    case("box head dense (GELU)", 32 * 2304, 768, 768, ops.EPI_GELU_BF16)
+    case("box head dX (GELU')", 32 * 2304, 768, 768, ops.EPI_DGELU_BF16)
+    case("class head (f32 out)", 32 * 2304, 512, 768, ops.EPI_F32)
     case("8192^3", 8192, 8192, 8192, ops.EPI_BIAS_BF16, iters=5)
