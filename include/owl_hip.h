@@ -42,9 +42,10 @@ int owl_abi_version(void);
  *      6 per-head transposed bf16 out_t[b][n][t] (m = b*Tp + t) | 8 acc*quick_gelu'(aux)->bf16 |
  *      9 acc*gelu'(aux)->bf16 | 10 out f32 += acc | 11 split-K slab.
  * a_rows / w_rows clamp the tile loads; M, N guard the stores; K % 64 == 0.
- * tile: kernel choice, per call (no global state): 0 = automatic (256x256x64 ping-pong / 8-wave tiles for large shapes -- for narrow outputs
- *       with the remainder round on half-height 128x256 tiles --, 128x128x64 otherwise); tests pin one kernel with 128 | 256 | 8 (ping-pong
- *       schedule where it applies, never split) | 9 (ping-pong + half-height remainder wherever it fits) | 4 (experimental four-wave).      */
+ * tile: kernel choice, per call (no global state): 0 = automatic (large shapes: 256x256x64 tiles on the two-phase ping-pong schedule, 8 waves,
+ *       gemm_pp2.hip -- for narrow outputs with the remainder round on half-height 128x256 tiles --; 128x128x64 otherwise); tests and tools pin one
+ *       kernel with 128 | 256 (single-phase) | 8 (four-phase ping-pong, never split) | 9 (four-phase ping-pong + half-height remainder wherever it
+ *       fits) | 7 (two-phase ping-pong on the whole problem) | 4 (experimental four-wave).  All give identical bits.                           */
 int owl_gemm_nt_bf16(void* stream, int epi, const void* A, int64_t lda, int64_t a_rows, const void* W, int64_t ldw, int64_t w_rows, const float* bias, void* out, int64_t ldo, const float* resid, void* aux, int64_t ld_aux, int64_t M, int64_t N, int64_t K, float alpha, int splits, int64_t Tp, int tile);
 /* epi 11 = split-K partial slabs out[split][M][ldo] (f32, no atomics); reduce them with owl_slab_reduce */
 int owl_gemm_effective_splits(int64_t K, int splits);

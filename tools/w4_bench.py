@@ -1,4 +1,4 @@
-"""A/B of the experimental four-wave GEMM (owl_gemm_set_tile(4)) against the ping-pong kernel: bit-equality + time."""
+"""A/B of the experimental four-wave GEMM (tile = 4) against the ping-pong kernel: bit-equality + time."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import io, contextlib, torch
