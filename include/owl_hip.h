@@ -152,8 +152,9 @@ int owl_text_pool_project(void* stream, const float* x, const int64_t* ids, cons
 /* weight gradients without transposed copies:  slab[s][n][k] = sum_{m in split s} dY[m][n] * X[m][k]  (dW = dY^T X; both
  * operands token-major bf16 as the other kernels leave them; the transposition happens in LDS via ds_read_b64_tr_b16).
  * zero_row: >= 512 B of device zeros (source of rows m >= M); slabs [splits_used][N][K] f32 are reduced by owl_slab_reduce;
- * splits_used is a HOST pointer.  owl_colsum_bf16: colsum[c] += sum_r in[r][c] (bias gradients).                       */
-int owl_gemm_tn_slab_bf16(void* stream, const void* dY, int64_t ldy, const void* X, int64_t ldx, const void* zero_row, float* slab, int64_t M, int64_t N, int64_t K, int splits, int* splits_used);
+ * splits_used is a HOST pointer.  variant: 0 = the library's choice (the ping-pong schedule), 1 = single-phase kernel, 2 = ping-pong; same bits.
+ * owl_colsum_bf16: colsum[c] += sum_r in[r][c] (bias gradients).                                                                   */
+int owl_gemm_tn_slab_bf16(void* stream, const void* dY, int64_t ldy, const void* X, int64_t ldx, const void* zero_row, float* slab, int64_t M, int64_t N, int64_t K, int splits, int* splits_used, int variant);
 int owl_colsum_bf16(void* stream, const void* in_bf16, int64_t ld, float* colsum, int64_t R, int64_t C, float* partials, int64_t partials_floats);
 /* f32 slab scratch of the call above for (M, N, K, splits): bytes = splits_used * N * K * 4 (`bytes` is a HOST pointer) */
 int owl_gemm_tn_slab_workspace_bytes(int64_t M, int64_t N, int64_t K, int splits, int64_t* bytes);

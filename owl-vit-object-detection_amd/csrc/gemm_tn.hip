@@ -170,6 +170,181 @@ __global__ __launch_bounds__(512) void gemm_tn_slab_kernel(TnP p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Ping-pong schedule for the same tile (round 2): the K-tile body of gemm_pp.hip -- two wave groups (waves 0-3 / 4-7 = output rows n 0-127 /
+// 128-255, one wave of each per SIMD) one barrier apart, four quadrant phases per K-tile each split into a LOAD half (fragment reads + LDS-DMA
+// requests, lgkmcnt(0) before the barrier) and an MFMA half (8 MFMAs), counted vmcnt -- with the fragments coming out of the token-major
+// tiles by transpose-reads.  A token row of the LDS image serves every output column, so the X tile (the "B" side, read in q0 / q1) is free
+// once both groups have run their q1 LOAD and the dY tile (read in q0 / q2) once both have run q2: K-tile c+2 is requested into the buffer K-tile c
+// is being computed from (X pieces in q2, dY pieces in q3, then the counted wait that retires K-tile c+1) -- more than a K-tile of flight.
+// hipcc puts a vmcnt(0) in front of every ds_read_tr BUILTIN that follows an LDS-DMA, which would drain the requests just made in every LOAD
+// half: the transpose-reads are hand-issued (asm) and waited for with one lgkmcnt(0) tied to their destination registers.
+// One (tile, split) item per workgroup (the host sizes the splits for ~256 items), so no cross-item stream; the f32 epilogue is the shared
+// LDS-staged one, in the stage buffers after the last K-tile.  Same accumulation order as the kernel above: identical bits.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int N> __device__ __forceinline__ void tnp_wait() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void tnp_bar() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+// the K-fragment (8 tokens of one feature column) = two transpose-reads; `lo` / `hi` land in adjacent registers of the MFMA operand
+#define TNP_TR2(lo, hi, addr, OFF) \
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4" : "=&v"(lo), "=&v"(hi) : "v"(addr), "n"(OFF), "n"((OFF) + 2048))
+
+__global__ __launch_bounds__(512) void gemm_tn_pp_kernel(TnP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = w >> 2, wc = w & 3;                       // group = 128-row half of the output tile (rows = dY features n)
+    const int nk_all = (int)((p.M + TBK - 1) / TBK);
+    const int nitems = p.tiles_n * p.tiles_k * p.nsplit;
+    const int item = xcd_remap(blockIdx.x, nitems);
+    if (item >= nitems) return;
+    const int ntiles = p.tiles_n * p.tiles_k;
+    const int split = item / ntiles;
+    const int tile = item - split * ntiles;
+    const int tn = tile / p.tiles_k, tk = tile - tn * p.tiles_k;
+    const int64_t n0 = (int64_t)tn * 256, k0 = (int64_t)tk * 256;
+    const int kt0 = split * p.kt_per_split, kt1 = min(nk_all, kt0 + p.kt_per_split);
+    const int nkt = kt1 - kt0;                                 // >= 1
+
+    // ---- staging (as above): wave w fills token rows [w*8, w*8+8) of both operand tiles, 4 pieces (2 rows each) per operand --------------
+    int s_kt = kt0, s_buf = 0;                                 // next K-tile to request, and its buffer
+    // lane offsets inside a K-tile, computed once (the K-tile's own offset is wave-uniform: no address VALU per piece); only a K-tile that
+    // reaches past row M -- the last one of the whole token range -- takes the per-lane path that substitutes the zero row
+    unsigned y_voff[4], x_voff[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int r = w * 8 + q * 2 + (lane >> 5);
+        const int c = (lane & 31) ^ ((r & 3) << 2);
+        int64_t nn = n0 + c * 8; if (nn + 8 > p.N) nn = p.N - 8;
+        int64_t kk = k0 + c * 8; if (kk + 8 > p.K) kk = p.K - 8;
+        y_voff[q] = (unsigned)((r * p.ldy + nn) * 2);
+        x_voff[q] = (unsigned)((r * p.ldx + kk) * 2);
+    }
+    auto stage_one = [&](bool x_side) {                        // 4 VMEM ops
+        unsigned char* base = lds + s_buf * T_STAGE + (x_side ? T_OP_BYTES : 0);
+        if ((int64_t)(s_kt + 1) * TBK <= p.M) {
+            const unsigned char* g = x_side ? (const unsigned char*)(p.X + (int64_t)s_kt * TBK * p.ldx) : (const unsigned char*)(p.dY + (int64_t)s_kt * TBK * p.ldy);
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                __builtin_amdgcn_global_load_lds(GPTR(g + (x_side ? x_voff[q] : y_voff[q])), LPTR(base + (w * 8 + q * 2) * 512), 16, 0, 0);
+            return;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int r = w * 8 + q * 2 + (lane >> 5);
+            const int c = (lane & 31) ^ ((r & 3) << 2);
+            const int64_t m = (int64_t)s_kt * TBK + r;
+            const bool ok = m < p.M;
+            const bf16_t* g;
+            if (x_side) { int64_t kk = k0 + c * 8; if (kk + 8 > p.K) kk = p.K - 8; g = ok ? p.X + m * p.ldx + kk : p.zero_row + (lane & 31) * 8; }
+            else { int64_t nn = n0 + c * 8; if (nn + 8 > p.N) nn = p.N - 8; g = ok ? p.dY + m * p.ldy + nn : p.zero_row + (lane & 31) * 8; }
+            __builtin_amdgcn_global_load_lds(GPTR(g), LPTR(base + (w * 8 + q * 2) * 512), 16, 0, 0);
+        }
+    };
+    auto stage_advance = [&]() { s_buf ^= 1; s_kt++; };
+    auto stream_live = [&]() { return s_kt < kt1; };
+
+    // ---- transpose-read addresses (absolute LDS addresses of buffer 0; the buffer and the K-chunk ride in immediates / one add) ------------
+    const int rr = 8 * (lane >> 5) + ((lane & 15) >> 2);
+    const int sw = (rr & 3) << 2;
+    const unsigned lds0 = (unsigned)(uintptr_t)LPTR(lds);
+    unsigned a_addr[4], b_addr[2];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int f = grp * 128 + i * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+        a_addr[i] = lds0 + rr * 512 + ((((f >> 3) ^ sw)) << 4) + ((f >> 2) & 1) * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int f = wc * 64 + j * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+        b_addr[j] = lds0 + T_OP_BYTES + rr * 512 + ((((f >> 3) ^ sw)) << 4) + ((f >> 2) & 1) * 8;
+    }
+
+    // prologue: K-tiles 0 and 1 requested, K-tile 0 landed
+    stage_one(true); stage_one(false); stage_advance();
+    if (stream_live()) { stage_one(true); stage_one(false); stage_advance(); tnp_wait<8>(); } else { tnp_wait<0>(); }
+    tnp_bar();
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    int cur = 0;
+    if (grp == 1) tnp_bar();                                   // group 1 runs one barrier behind
+    for (int kt = 0; kt < nkt; kt++) {
+        const unsigned bo = (unsigned)(cur * T_STAGE);
+        bf16x8 fa[2][4], fb[2][4];                              // [tile of the quadrant][kc], [j][kc]
+        // A fragment = two transpose-reads into the two halves of one 128-bit MFMA operand.  The asm returns the halves as separate 64-bit
+        // values; they are joined ONCE, right behind the wait that covers them (joined at every use the register allocator copies each
+        // fragment into a fresh tuple: 144 v_mov per K-tile in the first version).
+        auto ld4 = [&](bf16x8 (&f)[4], unsigned ad) {
+            s16x4_t l0, h0, l1, h1, l2, h2, l3, h3;
+            TNP_TR2(l0, h0, ad, 0); TNP_TR2(l1, h1, ad, 8192); TNP_TR2(l2, h2, ad, 16384); TNP_TR2(l3, h3, ad, 24576);
+            f[0] = __builtin_shufflevector(l0, h0, 0, 1, 2, 3, 4, 5, 6, 7); f[1] = __builtin_shufflevector(l1, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+            f[2] = __builtin_shufflevector(l2, h2, 0, 1, 2, 3, 4, 5, 6, 7); f[3] = __builtin_shufflevector(l3, h3, 0, 1, 2, 3, 4, 5, 6, 7);
+        };
+        auto ld_a = [&](int ih) { ld4(fa[0], a_addr[2 * ih] + bo); ld4(fa[1], a_addr[2 * ih + 1] + bo); };
+        auto ld_b = [&](int j) { ld4(fb[j], b_addr[j] + bo); };
+        // the reads of a LOAD half have returned: lgkmcnt(0) tied to every fragment register of the K-tile (no consumer can move above it)
+        auto wait_frags = [&]() {
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fa[1][3]),
+                           "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2]), "+v"(fb[0][3]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[1][2]), "+v"(fb[1][3]));
+        };
+        auto mma = [&](int ih, int j) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kc = 0; kc < 4; kc++)
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+                    acc[2 * ih + t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][kc], fa[t][kc], acc[2 * ih + t][j], 0, 0, 0);   // D rows = k, cols = n
+            __builtin_amdgcn_s_setprio(0);
+        };
+        // ---- q0 ----
+        ld_b(0); ld_a(0);
+        wait_frags(); tnp_bar();
+        mma(0, 0);
+        tnp_bar();
+        // ---- q1 ----
+        ld_b(1);
+        wait_frags(); tnp_bar();
+        mma(0, 1);
+        tnp_bar();
+        // ---- q2: the X tile of this buffer is free (both groups have read both column fragments) ----
+        ld_a(1);
+        const bool live = stream_live();
+        if (live) stage_one(true);
+        wait_frags(); tnp_bar();
+        mma(1, 1);
+        tnp_bar();
+        // ---- q3: the dY tile is free; retire K-tile kt+1, leave kt+2 in flight ----
+        if (live) { stage_one(false); stage_advance(); tnp_wait<8>(); } else { tnp_wait<0>(); }
+        tnp_bar();
+        mma(1, 0);
+        tnp_bar();
+        cur ^= 1;
+    }
+    if (grp == 0) tnp_bar();                                   // group 1's last MFMA half
+    {
+        // every request has landed and every fragment has been read (the loop ends in waits + barriers): the stage buffers are free, each
+        // wave stages its f32 passes through 2 x 4 KiB of its own
+        GemmP ep{};
+        ep.out = p.slab; ep.ldo = p.K; ep.M = p.N; ep.N = p.K; ep.alpha = 1.0f; ep.slab_stride = p.slab_stride;
+        unsigned char* pieceA = lds + (w * 8) * 512;
+        unsigned char* pieceB = lds + T_OP_BYTES + (w * 8) * 512;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            epi_pass<EPI_SLAB_F32>(ep, acc[i][0], acc[i][1], pieceA, pieceB, n0 + grp * 128 + i * 32, k0 + wc * 64, lane, split);
+    }
+}
+
 extern "C" int owl_gemm_tn_slab_workspace_bytes(int64_t M, int64_t N, int64_t K, int splits, int64_t* bytes) {
     OWL_CHECK_ARG(bytes && M > 0 && N > 0 && K > 0 && splits >= 1, "owl_gemm_tn_slab_workspace_bytes: bad arguments");
     const int nk = (int)((M + TBK - 1) / TBK);
@@ -180,7 +355,7 @@ extern "C" int owl_gemm_tn_slab_workspace_bytes(int64_t M, int64_t N, int64_t K,
 }
 
 extern "C" int owl_gemm_tn_slab_bf16(void* stream, const void* dY, int64_t ldy, const void* X, int64_t ldx, const void* zero_row,
-                                     float* slab, int64_t M, int64_t N, int64_t K, int splits, int* splits_used) {
+                                     float* slab, int64_t M, int64_t N, int64_t K, int splits, int* splits_used, int variant) {
     OWL_CHECK_ARG(dY && X && zero_row && slab && splits_used, "owl_gemm_tn_slab_bf16: null pointer");
     OWL_CHECK_ARG(M > 0 && N >= 8 && K >= 8 && N % 8 == 0 && K % 8 == 0, "owl_gemm_tn_slab_bf16: bad M=%lld N=%lld K=%lld (N, K %% 8 == 0)", (long long)M, (long long)N, (long long)K);
     OWL_CHECK_ARG(ldy % 8 == 0 && ldx % 8 == 0 && splits >= 1, "owl_gemm_tn_slab_bf16: ldy/ldx must be multiples of 8, splits >= 1");
@@ -198,7 +373,18 @@ extern "C" int owl_gemm_tn_slab_bf16(void* stream, const void* dY, int64_t ldy, 
         (void)hipFuncSetAttribute((const void*)gemm_tn_slab_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
         attr_done = true;
     }
+    OWL_CHECK_ARG(variant == 0 || variant == 1 || variant == 2, "owl_gemm_tn_slab_bf16: variant must be 0 (automatic), 1 (single-phase) or 2 (ping-pong)");
     const int nitems = p.tiles_n * p.tiles_k * p.nsplit;
+    if (variant != 1) {
+        static bool attr2_done = false;
+        if (!attr2_done) {
+            (void)hipFuncSetAttribute((const void*)gemm_tn_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
+            attr2_done = true;
+        }
+        hipLaunchKernelGGL(gemm_tn_pp_kernel, dim3(nitems), dim3(512), T_LDS, (hipStream_t)stream, p);
+        OWL_LAUNCH_CHECK();
+        return 0;
+    }
     p.persistent = nitems > 256 ? 1 : 0;
     hipLaunchKernelGGL(gemm_tn_slab_kernel, dim3(p.persistent ? 256 : nitems), dim3(512), T_LDS, (hipStream_t)stream, p);
     OWL_LAUNCH_CHECK();

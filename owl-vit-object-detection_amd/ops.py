@@ -219,7 +219,7 @@ def postprocess(boxes, sims, max_out, conf_thr, iou_thr):
 _zero_row = {}
 
 
-def gemm_tn_slab(dy, x, slab, rows, n_out, n_in, splits):
+def gemm_tn_slab(dy, x, slab, rows, n_out, n_in, splits, variant=0):
     """slab[s][n][k] = sum_{m in split s} dy[m][n] * x[m][k] (weight gradient, no transposed copies) -> splits used."""
     _chk(dy, torch.bfloat16, "dy"); _chk(x, torch.bfloat16, "x"); _chk(slab, torch.float32, "slab")
     dev = dy.device
@@ -227,7 +227,7 @@ def gemm_tn_slab(dy, x, slab, rows, n_out, n_in, splits):
         _zero_row[dev] = torch.zeros(512, dtype=torch.bfloat16, device=dev)
     used = torch.zeros(1, dtype=torch.int32)
     _lib.call("owl_gemm_tn_slab_bf16", stream(), dy, dy.shape[-1], x, x.shape[-1], _zero_row[dev], slab, rows, n_out, n_in,
-              int(splits), used)
+              int(splits), used, int(variant))
     return int(used.item())
 
 

@@ -308,6 +308,11 @@ def test_gemm_tn_slab_weight_gradient(rows, n_out, n_in, splits):
     assert err <= 2e-3 * scale + 1e-3, (err, scale)          # f32 accumulation, different summation order
     slab2 = torch.zeros_like(slab)
     assert ops.gemm_tn_slab(dy, x, slab2, rows, n_out, n_in, splits) == ns and torch.equal(slab, slab2)     # bitwise repeatable
+    # the ping-pong schedule (variant 2 = what variant 0 picks) and the single-phase kernel (variant 1) accumulate in the same order: same bits
+    for variant in (1, 2, 2, 1):
+        slab3 = torch.zeros_like(slab)
+        assert ops.gemm_tn_slab(dy, x, slab3, rows, n_out, n_in, splits, variant=variant) == ns
+        assert torch.equal(slab3[: ns * n_out * n_in], slab[: ns * n_out * n_in]), variant
     cs = torch.zeros(n_out, device=DEV)
     ops.colsum_bf16(dy, cs, rows, n_out)
     assert (cs - dy[:rows].float().sum(0)).abs().max().item() <= 1e-3 * rows ** 0.5 + 1e-3
