@@ -57,8 +57,9 @@ int owl_slab_reduce(void* stream, const float* slabs, float* out, int64_t n, int
  * im2row-free: the A-operand loader gathers 16-byte runs of each patch row straight from the
  * bf16 image [B,3,S,S] into LDS.  x_out[b*Tp + 1 + p, :] = W_pe . vec(patch) + pos[1+p, :].      */
 /* patch sizes that are not a power of two (L/14): pass `scratch` = bf16 [rows128(B*P), Kpad] for an explicit im2row and
- * w_pe as [D, Kpad] (Kpad = 3*ps*ps rounded up to 64, zero columns beyond); otherwise scratch may be NULL.           */
-int owl_patch_embed_bf16(void* stream, const void* image_bf16, const void* w_pe, const float* pos, float* x_out, void* scratch, int64_t B, int64_t S, int64_t ps, int64_t D, int64_t Tp);
+ * w_pe as [D, Kpad] (Kpad = 3*ps*ps rounded up to 64, zero columns beyond); otherwise scratch may be NULL.
+ * tile: 0 = automatic (two-phase ping-pong kernel for big problems), 7 / 256 / 128 pin a kernel (tests); same bits.       */
+int owl_patch_embed_bf16(void* stream, const void* image_bf16, const void* w_pe, const float* pos, float* x_out, void* scratch, int64_t B, int64_t S, int64_t ps, int64_t D, int64_t Tp, int tile);
 /* class-token rows x[b*Tp, :] = class_embedding + pos[0, :]  (HF5:338-343)                        */
 int owl_cls_rows(void* stream, float* x, const float* cls, const float* pos, int64_t B, int64_t Tp, int64_t D);
 

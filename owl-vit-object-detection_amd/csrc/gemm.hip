@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) void im2row_kernel(const bf16_t* __restrict__ 
 // Otherwise: `scratch` (bf16 [B*P (row-padded to 128), Kpad]) receives an explicit im2row and w_pe must be [D, Kpad]
 // with zero columns beyond 3*ps*ps; Kpad = 3*ps*ps rounded up to 64.
 extern "C" int owl_patch_embed_bf16(void* stream, const void* image_bf16, const void* w_pe, const float* pos,
-                                    float* x_out, void* scratch, int64_t B, int64_t S, int64_t ps, int64_t D, int64_t Tp) {
+                                    float* x_out, void* scratch, int64_t B, int64_t S, int64_t ps, int64_t D, int64_t Tp, int tile) {
     OWL_CHECK_ARG(image_bf16 && w_pe && pos && x_out, "owl_patch_embed_bf16: null pointer");
     OWL_CHECK_ARG(S % ps == 0, "owl_patch_embed_bf16: image side must be a multiple of the patch size");
     const int64_t G = S / ps, P = G * G, K = 3 * ps * ps;
@@ -495,7 +495,12 @@ extern "C" int owl_patch_embed_bf16(void* stream, const void* image_bf16, const 
         p.A = (const bf16_t*)image_bf16; p.lda = 0; p.ldw = K; p.K = K;
         p.ps_log2 = 0; while ((1LL << p.ps_log2) < ps) p.ps_log2++;
         p.kt_per_split = (int)(K / BK);
-        return launch<EPI_PATCH_F32>((hipStream_t)stream, p, 1);
+        p.nsplit = 1;
+        // big problems: the two-phase ping-pong kernel (same bits); tile = 256 / 128 pins the single-phase kernels, 7 the ping-pong one
+        const bool pp2 = tile == 7 || (tile == 0 && p.M >= 512 && D >= 256 && K >= 128 && ((p.M + 255) / 256) * ((D + 255) / 256) >= 48);
+        OWL_CHECK_ARG(tile == 0 || tile == 7 || tile == 256 || tile == 128, "owl_patch_embed_bf16: tile must be 0 (auto), 7, 256 or 128");
+        if (pp2 && K >= 128) return owl_gemm_pp2_launch((hipStream_t)stream, EPI_PATCH_F32, p);
+        return launch<EPI_PATCH_F32>((hipStream_t)stream, p, 1, tile);
     }
     OWL_CHECK_ARG(scratch, "owl_patch_embed_bf16: patch size %lld needs the im2row scratch buffer", (long long)ps);
     const int64_t Kpad = (K + BK - 1) / BK * BK;
@@ -504,5 +509,9 @@ extern "C" int owl_patch_embed_bf16(void* stream, const void* image_bf16, const 
     OWL_LAUNCH_CHECK();
     p.A = (const bf16_t*)scratch; p.lda = Kpad; p.ldw = Kpad; p.K = Kpad;
     p.kt_per_split = (int)(Kpad / BK);
-    return launch<EPI_PATCHM_F32>((hipStream_t)stream, p, 1);
+    p.nsplit = 1;
+    OWL_CHECK_ARG(tile == 0 || tile == 7 || tile == 256 || tile == 128, "owl_patch_embed_bf16: tile must be 0 (auto), 7, 256 or 128");
+    const bool pp2 = tile == 7 || (tile == 0 && p.M >= 512 && D >= 256 && ((p.M + 255) / 256) * ((D + 255) / 256) >= 48);
+    if (pp2 && Kpad >= 128) return owl_gemm_pp2_launch((hipStream_t)stream, EPI_PATCHM_F32, p);
+    return launch<EPI_PATCHM_F32>((hipStream_t)stream, p, 1, tile);
 }

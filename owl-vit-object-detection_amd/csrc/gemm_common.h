@@ -304,6 +304,26 @@ __device__ __forceinline__ void epi_tile_f32(const GemmP& p, const f32x16& acc, 
     }
 }
 
+// ---- register-resident patch-embed epilogue of ONE 32x32 accumulator tile: out f32 [b*Tp + 1 + p][n] = alpha*acc + pos[1 + p][n] for output row
+// m = b*P + p (HF5:282-288,336-343; no bias).  Same operations in the same order as epi_quad's patch branch: identical bits to the LDS-staged epilogue.
+template <bool GUARD>
+__device__ __forceinline__ void epi_tile_patch(const GemmP& p, const f32x16& acc, int64_t m_tile, int64_t n_tile, int lane) {
+    const int hi = lane >> 5;
+    const int64_t m = m_tile + (lane & 31);
+    const bool m_ok = !GUARD || m < p.M;
+    const int64_t mm = m_ok ? m : 0;
+    const int64_t b = mm / p.P, pp = mm - b * p.P;
+    float* orow = (float*)p.out + (b * p.Tp + 1 + pp) * p.ldo + n_tile + 4 * hi;
+    const float* prow = p.pos + (1 + pp) * p.N + n_tile + 4 * hi;
+#pragma unroll
+    for (int qd = 0; qd < 4; qd++) {
+        if (!m_ok || (GUARD && (n_tile + 8 * qd + 4 * hi) >= p.N)) continue;
+        const float4 p4 = *(const float4*)(prow + 8 * qd);
+        *(float4*)(orow + 8 * qd) = make_float4(acc[qd * 4 + 0] * p.alpha + p4.x, acc[qd * 4 + 1] * p.alpha + p4.y,
+                                                acc[qd * 4 + 2] * p.alpha + p4.z, acc[qd * 4 + 3] * p.alpha + p4.w);
+    }
+}
+
 // issue one 16-byte chunk (c = 0/1 within the tile)
 template <int EPI, bool GUARD>
 __device__ __forceinline__ void epi_store_chunk(const GemmP& p, const uint4& ch, int64_t m_tile, int64_t n_tile, int c, int lane) {

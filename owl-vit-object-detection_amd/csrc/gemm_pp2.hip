@@ -57,11 +57,15 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
     const bf16_t* w_base = nullptr;
     const float* b_base = nullptr;
     const bool has_bias = p.bias != nullptr;
+    // EPI_PATCH_F32: A is gathered straight from the image (power-of-two patch sizes): row m = (b, py, px), k = (channel, ky, kx); a 16-byte chunk
+    // is 8 pixels of one patch row and a K-tile is 64 / ps patch rows of one channel -- the lane's part of the address (patch origin + the chunk's
+    // row / column inside the K-tile) is K-tile-invariant, the K-tile's part (channel, first row) is wave-uniform: same scheme as a plain A matrix.
+    constexpr bool GATHER = (EPI == EPI_PATCH_F32);
     auto stage_A = [&]() {                                     // 4 VMEM ops
         if (a_k == 0) {
             const int tm = a_item / p.tiles_n;
             const int64_t m0 = (int64_t)tm * QBM;
-            a_base = p.A + m0 * p.lda;
+            a_base = GATHER ? p.A : p.A + m0 * p.lda;
 #pragma unroll
             for (int h = 0; h < 2; h++)
 #pragma unroll
@@ -69,11 +73,24 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
                     const int r = h * 128 + (w * 2 + q) * 8 + (lane >> 3);
                     const int c = (lane & 7) ^ ((r >> 1) & 7);
                     int64_t am = m0 + r; if (am >= p.a_rows) am = p.a_rows - 1;
-                    a_voff[h][q] = (unsigned)(((am - m0) * p.lda + c * 8) * 2);
+                    if constexpr (GATHER) {
+                        const int64_t b = am / p.P, pp = am - b * p.P;
+                        const int64_t py = pp / p.G, px = pp - py * p.G;
+                        const int ky = (c * 8) >> p.ps_log2, kx = (c * 8) & ((1 << p.ps_log2) - 1);
+                        a_voff[h][q] = (unsigned)(((((b * 3) * p.S + py * p.ps + ky) * p.S) + px * p.ps + kx) * 2);
+                    } else {
+                        a_voff[h][q] = (unsigned)(((am - m0) * p.lda + c * 8) * 2);
+                    }
                 }
         }
         unsigned char* base = lds + a_buf * Q_STAGE;
-        const unsigned char* g = (const unsigned char*)(a_base + (int64_t)a_k * QBK);
+        int64_t koff = (int64_t)a_k * QBK;                     // elements from a_base to the K-tile
+        if constexpr (GATHER) {
+            const int k = a_k * QBK;
+            const int ch = k >> (2 * p.ps_log2), ky = (k & ((1 << (2 * p.ps_log2)) - 1)) >> p.ps_log2;
+            koff = ((int64_t)ch * p.S + ky) * p.S;
+        }
+        const unsigned char* g = (const unsigned char*)(a_base + koff);
 #pragma unroll
         for (int h = 0; h < 2; h++)
 #pragma unroll
@@ -135,7 +152,7 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
     // already reads the next tile's first fragments (+2 % on top of the two-phase K-tile at K = 768 / 3072).  VALU-bound epilogue (quick-GELU:
     // an exp and a reciprocal per element): two staggered epilogues in a row cost more than both together (-6 %), so there the groups are
     // re-synchronised at every tile as in gemm_pp.hip -- group 0 waits for group 1's last MFMA phase, both run their epilogues in one interval.
-    constexpr bool STAGGERED_EPI = (EPI == EPI_BIAS_BF16 || EPI == EPI_F32 || EPI == EPI_ACC_F32);
+    constexpr bool STAGGERED_EPI = (EPI == EPI_BIAS_BF16 || EPI == EPI_F32 || EPI == EPI_ACC_F32 || EPI == EPI_PATCH_F32 || EPI == EPI_PATCHM_F32);
     if (STAGGERED_EPI && grp == 1) q_bar();
     while (true) {
         f32x16 acc[4][2];
@@ -210,6 +227,8 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
                     const int64_t mt = cm0 + grp * 128 + i * 32, nt = cn0 + wc * 64 + j * 32;
                     if constexpr (EPI == EPI_F32 || EPI == EPI_ACC_F32) {
                         epi_tile_f32<EPI, G>(p, acc[i][j], mt, nt, lane, lbias + j * 32);
+                    } else if constexpr (EPI == EPI_PATCH_F32 || EPI == EPI_PATCHM_F32) {
+                        epi_tile_patch<G>(p, acc[i][j], mt, nt, lane);
                     } else {
                         uint4 c0, c1;
                         epi_tile_bf16<EPI, G>(p, acc[i][j], mt, nt, lane, c0, c1, lbias + j * 32, AUX_IN ? auxr[AUX_IN ? i : 0][j] : nullptr);
@@ -253,6 +272,8 @@ int owl_gemm_pp2_launch(hipStream_t s, int epi, const GemmP& p) {
         case EPI_DGELU_BF16: return launch_pp2<EPI_DGELU_BF16>(s, p);
         case EPI_F32: return launch_pp2<EPI_F32>(s, p);               // class head e = W feats + b, dfeats
         case EPI_ACC_F32: return launch_pp2<EPI_ACC_F32>(s, p);       // dfeats += (box head)
+        case EPI_PATCH_F32: return launch_pp2<EPI_PATCH_F32>(s, p);   // patch embedding, A gathered from the image
+        case EPI_PATCHM_F32: return launch_pp2<EPI_PATCHM_F32>(s, p); // ... from an explicit im2row matrix (L/14)
         default: return 1;                                            // (the transposing epilogue stays on the four-phase kernel)
     }
 }

@@ -58,10 +58,10 @@ def gemm(epi, A, W, out, bias=None, resid=None, aux=None, M=None, N=None, K=None
     return out
 
 
-def patch_embed(image_bf16, w_pe, pos, x_out, B, S, ps, D, Tp, scratch=None):
+def patch_embed(image_bf16, w_pe, pos, x_out, B, S, ps, D, Tp, scratch=None, tile=0):
     _chk(image_bf16, torch.bfloat16, "image"); _chk(w_pe, torch.bfloat16, "w_pe"); _chk(pos, torch.float32, "pos")
     _chk(x_out, torch.float32, "x_out")
-    _lib.call("owl_patch_embed_bf16", stream(), image_bf16, w_pe, pos, x_out, scratch, B, S, ps, D, Tp)
+    _lib.call("owl_patch_embed_bf16", stream(), image_bf16, w_pe, pos, x_out, scratch, B, S, ps, D, Tp, int(tile))
 
 
 def cls_rows(x, cls, pos, B, Tp, D):

@@ -228,3 +228,34 @@ def test_encoder_sub_batch_streams_give_the_single_stream_bits(arch, B):
         res.append(runs)
     for a, b in zip(res[0], res[1]):
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+
+
+@pytest.mark.parametrize("arch,B", [("owlvit-base-patch16", 32), ("owlvit-base-patch32", 16), ("owlvit-large-patch14", 4)])
+def test_patch_embed_pingpong_matches_single_phase_bitwise(arch, B):
+    """The patch embedding on the two-phase ping-pong kernel (A gathered straight from the image for ps = 16 / 32, an im2row matrix for ps = 14) gives the
+    bits of the single-phase kernel's LDS-staged epilogue, every launch; the class-token rows and the pad rows are not touched."""
+    from owl_vit_object_detection_amd.config import get_config
+    cfg = get_config(arch)
+    torch.manual_seed(1)
+    S, ps, D, Tp, P = cfg.image_size, cfg.patch_size, cfg.hidden, cfg.tokens_padded, cfg.patches
+    img = torch.randn(B, 3, S, S, device=DEV).bfloat16()
+    kpad = (3 * ps * ps + 63) // 64 * 64
+    w = torch.zeros(D, kpad, device=DEV, dtype=torch.bfloat16); w[:, : 3 * ps * ps] = (torch.randn(D, 3 * ps * ps, device=DEV) * 0.05).bfloat16()
+    pos = torch.randn(cfg.tokens, D, device=DEV)
+    fused = ps >= 8 and (ps & (ps - 1)) == 0
+    wk = w[:, : 3 * ps * ps].contiguous() if fused else w
+    scratch = None if fused else ops.zeros_rows(B * P, kpad, torch.bfloat16, DEV)
+
+    def run(tile):
+        x = ops.zeros_rows(B * Tp, D, torch.float32, DEV)
+        x[:] = 7.0
+        ops.patch_embed(img, wk, pos, x, B, S, ps, D, Tp, scratch=scratch, tile=tile)
+        torch.cuda.synchronize()
+        return x
+
+    ref = run(256)
+    v = ref[: B * Tp].view(B, Tp, D)
+    assert bool((v[:, 0] == 7.0).all()) and bool((v[:, P + 1:] == 7.0).all()) and not bool((v[:, 1:P + 1] == 7.0).all())
+    for _ in range(6):
+        assert torch.equal(run(7), ref)
+    assert torch.equal(run(0), ref)
