@@ -147,6 +147,8 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
     q_bar();
 
     int cur = 0, tile_parity = 0;
+    bool a_early = false;            // the A pieces of the next tile's K-tile 1 went out before this tile's epilogue stores
+    int pending_stores = 0;          // epilogue stores issued after them (known counts only; otherwise the epilogue is followed by a full wait)
     // Store-bound epilogue (bias): group 1 runs ONE barrier interval behind group 0 for the WHOLE persistent loop -- the epilogue is just
     // another interval: group 0 converts and stores its half of a tile while group 1 runs its last MFMA phase, group 1 stores while group 0
     // already reads the next tile's first fragments (+2 % on top of the two-phase K-tile at K = 768 / 3072).  VALU-bound epilogue (quick-GELU:
@@ -192,7 +194,8 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
 #pragma unroll
                 for (int kc = 0; kc < 4; kc++) fb[j][kc] = *(const bf16x8*)(tb + b_base_off + j * 4096 + (((kc * 2 + hi) ^ b_swz) << 4));
             ld_a(0);
-            if (a_item < item_end) stage_A();         // A rows of the OTHER buffer: released by both groups' LOAD B of the previous K-tile
+            if (a_early) a_early = false;             // (requested ahead of the previous tile's epilogue)
+            else if (a_item < item_end) stage_A();    // A rows of the OTHER buffer: released by both groups' LOAD B of the previous K-tile
             q_wait_lgkm();
             q_bar();
             mma(0);
@@ -201,7 +204,16 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
             ld_a(1);
             int n_new = 0;
             if (b_item < item_end) n_new = stage_B();   // B rows of THIS buffer: both groups have run LOAD A
-            if (n_new == 5) q_wait<5>(); else if (n_new == 4) q_wait<4>(); else q_wait<0>();   // K-tile kt+1 complete (all but the pieces just requested)
+            // K-tile kt+1 complete: all but the pieces just requested -- and, in a tile's first K-tile, the previous tile's epilogue stores, which
+            // are younger than the A pieces of K-tile 1 (vmcnt is one in-order counter for loads and stores)
+            switch (n_new + pending_stores) {
+                case 4: q_wait<4>(); break;
+                case 5: q_wait<5>(); break;
+                case 20: q_wait<20>(); break;
+                case 21: q_wait<21>(); break;
+                default: q_wait<0>(); break;
+            }
+            pending_stores = 0;
             q_bar();
             mma(1);
             q_bar();
@@ -209,6 +221,11 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
         }
         if (!STAGGERED_EPI && grp == 0) q_bar();     // let group 1 finish its last MFMA phase: epilogues run together
         const bool inner = (cm0 + QBM <= p.M) && (cn0 + QBN <= p.N);
+        // The next tile's K-tile 1 goes into the buffer the last K-tile just left (its A rows: both groups are past LOAD B).  Its A pieces are
+        // requested HERE, ahead of the epilogue's stores, so that the counted wait of the next LOAD B can leave the stores in flight.
+        // (Only where the epilogue issues a known number of stores and no loads: plain bf16 epilogues on interior tiles.)
+        constexpr bool PLAIN_EPI = (EPI == EPI_BIAS_BF16 || EPI == EPI_QGELU_BF16 || EPI == EPI_GELU_BF16);
+        if (PLAIN_EPI && inner && !p.aux && a_item < item_end) { stage_A(); a_early = true; pending_stores = 16; }
         const float* lbias = (const float*)(lds + Q_BIAS_OFF + tile_parity * 1024) + wc * 64;
         auto run = [&](auto guard_tag) {
             constexpr bool G = decltype(guard_tag)::value;
