@@ -256,9 +256,9 @@ class OwlViT(nn.Module):
 
     # -- encoder schedule --------------------------------------------------------------------------------
     def _encoder_chunks(self, B: int):
-        """[(first image, images)] of the sub-batches the encoder runs on separate streams.  Small batches stay whole: below ~4 images per
-        sub-batch the GEMMs no longer fill the chip on their own."""
-        n = self.encoder_streams if B >= 8 else 1
+        """[(first image, images)] of the sub-batches the encoder runs on separate streams.  Batches below 4 stay whole (train step, same process:
+        batch 2 -7 %, batch 4 +8 %, batch 6 +0.5 %, batch 8 +4 % with two sub-batches)."""
+        n = self.encoder_streams if B >= 4 else 1
         if n <= 1:
             return [(0, B)]
         base, extra = divmod(B, n)
