@@ -176,92 +176,107 @@ extern "C" int owl_layernorm_bwd(void* stream, const void* dy, int dy_bf16, cons
 // stream rows 1..P of each image, accumulating d(cls_ln)[b,:] and the four LN parameter gradients.
 // grid = (ceil(P / RPB), B).
 // ---------------------------------------------------------------------------------------------------
+// A THREAD owns four columns for the whole workgroup (D <= 1024): its slices of the four parameter vectors and of cls_ln are loaded once, its
+// five column sums need no cross-wave reduction, and the only traffic per row is the row itself (x, dfeats in; dx f32 + bf16 out).  The
+// workgroup walks its rows MLR at a time: the two pairs of row moments go through LDS (wave sums -> [wave][row] -> every thread adds the four
+// waves' parts in wave order), two barriers per MLR rows.  (The wave-per-row form this replaces re-read seven parameter vectors per row --
+// 78 % of its load instructions -- and needed 244 registers for its 5 x 16 accumulators: 238 us at the headline size, this one 190.)
+static constexpr int MLR = 2;
 __global__ __launch_bounds__(256) void merge_ln_bwd_kernel(const float* __restrict__ dfeats, const float* __restrict__ x,
                                                            const float* __restrict__ cls_ln, const float2* __restrict__ stats1,
                                                            const float2* __restrict__ stats2, const float* __restrict__ g1,
-                                                           const float* __restrict__ b1, const float* __restrict__ g2, float* dx,
-                                                           float* part, int64_t P, int64_t Tp, int D, int rows_per_block, bf16_t* dx_bf16) {
-    __shared__ float red[4][LN_MAXV * 256 + 4];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+                                                           const float* __restrict__ b1, const float* __restrict__ g2, float* __restrict__ dx,
+                                                           float* __restrict__ part, int64_t P, int64_t Tp, int D, int rows_per_block,
+                                                           bf16_t* __restrict__ dx_bf16) {
+    __shared__ float2 redm[2][4][MLR];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int64_t b = blockIdx.y;
-    const int nvec = D >> 2;
-    float4 a_c[LN_MAXV], a_g1[LN_MAXV], a_b1[LN_MAXV], a_g2[LN_MAXV], a_b2[LN_MAXV];
-#pragma unroll
-    for (int i = 0; i < LN_MAXV; i++) a_c[i] = a_g1[i] = a_b1[i] = a_g2[i] = a_b2[i] = make_float4(0, 0, 0, 0);
+    const bool ok = 4 * t < D;
+    const float4 z4 = make_float4(0, 0, 0, 0);
+    float4 ga = z4, be = z4, gb = z4, cv = z4;
+    if (ok) { ga = ((const float4*)g1)[t]; be = ((const float4*)b1)[t]; gb = ((const float4*)g2)[t]; cv = ((const float4*)(cls_ln + b * D))[t]; }
+    float4 a_c = z4, a_g1 = z4, a_b1 = z4, a_g2 = z4, a_b2 = z4;
+    const float invD = 1.0f / (float)D;
     const int64_t p_begin = (int64_t)blockIdx.x * rows_per_block, p_end = min(P, p_begin + rows_per_block);
-    for (int64_t pp = p_begin + w; pp < p_end; pp += 4) {
-        const int64_t xrow = b * Tp + 1 + pp, frow = b * P + pp;
-        const float2 s1 = stats1[xrow], s2 = stats2[frow];
-        float4 xh[LN_MAXV], y[LN_MAXV], zh[LN_MAXV], gz[LN_MAXV], cv[LN_MAXV];
-        float m1 = 0.f, m2 = 0.f;
+    // the NEXT MLR rows are requested before these are worked on: a workgroup's loads stay in flight through its compute and barrier phases
+    float4 xn[MLR], dn[MLR];
+    auto fetch = [&](int64_t p0) {
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; i++) {
-            const int idx = lane + i * 64;
-            if (idx < nvec) {
-                const float4 xv = ((const float4*)(x + xrow * D))[idx];
-                const float4 ga = ((const float4*)g1)[idx], be = ((const float4*)b1)[idx], gb = ((const float4*)g2)[idx];
-                cv[i] = ((const float4*)(cls_ln + b * D))[idx];
-                const float4 df = ((const float4*)(dfeats + frow * D))[idx];
-                xh[i] = make_float4((xv.x - s1.x) * s1.y, (xv.y - s1.x) * s1.y, (xv.z - s1.x) * s1.y, (xv.w - s1.x) * s1.y);
-                y[i] = make_float4(xh[i].x * ga.x + be.x, xh[i].y * ga.y + be.y, xh[i].z * ga.z + be.z, xh[i].w * ga.w + be.w);
-                zh[i] = make_float4((y[i].x * cv[i].x - s2.x) * s2.y, (y[i].y * cv[i].y - s2.x) * s2.y,
-                                    (y[i].z * cv[i].z - s2.x) * s2.y, (y[i].w * cv[i].w - s2.x) * s2.y);
-                gz[i] = make_float4(df.x * gb.x, df.y * gb.y, df.z * gb.z, df.w * gb.w);
-                a_g2[i].x += df.x * zh[i].x; a_g2[i].y += df.y * zh[i].y; a_g2[i].z += df.z * zh[i].z; a_g2[i].w += df.w * zh[i].w;
-                a_b2[i].x += df.x; a_b2[i].y += df.y; a_b2[i].z += df.z; a_b2[i].w += df.w;
-                m1 += gz[i].x + gz[i].y + gz[i].z + gz[i].w;
-                m2 += gz[i].x * zh[i].x + gz[i].y * zh[i].y + gz[i].z * zh[i].z + gz[i].w * zh[i].w;
+        for (int r = 0; r < MLR; r++) {
+            xn[r] = z4; dn[r] = z4;                       // (rows past the end: zero statistics and zero dfeats -> zero contributions, no store)
+            if (ok && p0 + r < p_end) {
+                xn[r] = ((const float4*)(x + (b * Tp + 1 + p0 + r) * D))[t];
+                dn[r] = ((const float4*)(dfeats + (b * P + p0 + r) * D))[t];
             }
         }
-        m1 = wave_sum(m1) / (float)D; m2 = wave_sum(m2) / (float)D;
-        float4 gd[LN_MAXV];
-        float n1 = 0.f, n2 = 0.f;
+    };
+    fetch(p_begin);
+    for (int64_t p0 = p_begin; p0 < p_end; p0 += MLR) {
+        float4 xh[MLR], zh[MLR], gz[MLR];
+        float r1[MLR], r2[MLR];
+        {
+            float4 xv[MLR], df[MLR];
+            float2 s1[MLR], s2[MLR];
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; i++) {
-            const int idx = lane + i * 64;
-            if (idx < nvec) {
-                const float4 ga = ((const float4*)g1)[idx];
-                // dz
-                const float4 dz = make_float4(s2.y * (gz[i].x - m1 - zh[i].x * m2), s2.y * (gz[i].y - m1 - zh[i].y * m2),
-                                              s2.y * (gz[i].z - m1 - zh[i].z * m2), s2.y * (gz[i].w - m1 - zh[i].w * m2));
-                a_c[i].x += dz.x * y[i].x; a_c[i].y += dz.y * y[i].y; a_c[i].z += dz.z * y[i].z; a_c[i].w += dz.w * y[i].w;
-                const float4 dy = make_float4(dz.x * cv[i].x, dz.y * cv[i].y, dz.z * cv[i].z, dz.w * cv[i].w);
-                a_g1[i].x += dy.x * xh[i].x; a_g1[i].y += dy.y * xh[i].y; a_g1[i].z += dy.z * xh[i].z; a_g1[i].w += dy.w * xh[i].w;
-                a_b1[i].x += dy.x; a_b1[i].y += dy.y; a_b1[i].z += dy.z; a_b1[i].w += dy.w;
-                gd[i] = make_float4(dy.x * ga.x, dy.y * ga.y, dy.z * ga.z, dy.w * ga.w);
-                n1 += gd[i].x + gd[i].y + gd[i].z + gd[i].w;
-                n2 += gd[i].x * xh[i].x + gd[i].y * xh[i].y + gd[i].z * xh[i].z + gd[i].w * xh[i].w;
+            for (int r = 0; r < MLR; r++) {
+                xv[r] = xn[r]; df[r] = dn[r];
+                s1[r] = make_float2(0.f, 0.f); s2[r] = make_float2(0.f, 0.f);
+                if (p0 + r < p_end) { s1[r] = stats1[b * Tp + 1 + p0 + r]; s2[r] = stats2[b * P + p0 + r]; }
+            }
+            if (p0 + MLR < p_end) fetch(p0 + MLR);
+#pragma unroll
+            for (int r = 0; r < MLR; r++) {
+                r1[r] = s1[r].y; r2[r] = s2[r].y;
+                xh[r] = make_float4((xv[r].x - s1[r].x) * s1[r].y, (xv[r].y - s1[r].x) * s1[r].y, (xv[r].z - s1[r].x) * s1[r].y, (xv[r].w - s1[r].x) * s1[r].y);
+                const float4 y = make_float4(fmaf(xh[r].x, ga.x, be.x), fmaf(xh[r].y, ga.y, be.y), fmaf(xh[r].z, ga.z, be.z), fmaf(xh[r].w, ga.w, be.w));
+                zh[r] = make_float4((y.x * cv.x - s2[r].x) * s2[r].y, (y.y * cv.y - s2[r].x) * s2[r].y, (y.z * cv.z - s2[r].x) * s2[r].y, (y.w * cv.w - s2[r].x) * s2[r].y);
+                gz[r] = make_float4(df[r].x * gb.x, df[r].y * gb.y, df[r].z * gb.z, df[r].w * gb.w);
+                a_g2.x += df[r].x * zh[r].x; a_g2.y += df[r].y * zh[r].y; a_g2.z += df[r].z * zh[r].z; a_g2.w += df[r].w * zh[r].w;
+                a_b2.x += df[r].x; a_b2.y += df[r].y; a_b2.z += df[r].z; a_b2.w += df[r].w;
+                const float m1 = wave_sum(gz[r].x + gz[r].y + gz[r].z + gz[r].w);
+                const float m2 = wave_sum(gz[r].x * zh[r].x + gz[r].y * zh[r].y + gz[r].z * zh[r].z + gz[r].w * zh[r].w);
+                if (lane == 0) redm[0][w][r] = make_float2(m1, m2);
             }
         }
-        n1 = wave_sum(n1) / (float)D; n2 = wave_sum(n2) / (float)D;
+        __syncthreads();
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; i++) {
-            const int idx = lane + i * 64;
-            if (idx < nvec) {
-                const float4 o = make_float4(s1.y * (gd[i].x - n1 - xh[i].x * n2), s1.y * (gd[i].y - n1 - xh[i].y * n2),
-                                             s1.y * (gd[i].z - n1 - xh[i].z * n2), s1.y * (gd[i].w - n1 - xh[i].w * n2));
-                ((float4*)(dx + xrow * D))[idx] = o;
-                if (dx_bf16) {                              // the bf16 copy the first dX GEMM reads (saves a separate cast pass)
-                    uint2 ob; ob.x = pack_bf2(o.x, o.y); ob.y = pack_bf2(o.z, o.w);
-                    ((uint2*)(dx_bf16 + xrow * D))[idx] = ob;
-                }
+        for (int r = 0; r < MLR; r++) {
+            const float2 q0 = redm[0][0][r], q1 = redm[0][1][r], q2 = redm[0][2][r], q3 = redm[0][3][r];
+            const float m1 = (q0.x + q1.x + q2.x + q3.x) * invD, m2 = (q0.y + q1.y + q2.y + q3.y) * invD;
+            const float4 y = make_float4(fmaf(xh[r].x, ga.x, be.x), fmaf(xh[r].y, ga.y, be.y), fmaf(xh[r].z, ga.z, be.z), fmaf(xh[r].w, ga.w, be.w));
+            const float4 dz = make_float4(r2[r] * (gz[r].x - m1 - zh[r].x * m2), r2[r] * (gz[r].y - m1 - zh[r].y * m2),
+                                          r2[r] * (gz[r].z - m1 - zh[r].z * m2), r2[r] * (gz[r].w - m1 - zh[r].w * m2));
+            a_c.x += dz.x * y.x; a_c.y += dz.y * y.y; a_c.z += dz.z * y.z; a_c.w += dz.w * y.w;
+            const float4 dy = make_float4(dz.x * cv.x, dz.y * cv.y, dz.z * cv.z, dz.w * cv.w);
+            a_g1.x += dy.x * xh[r].x; a_g1.y += dy.y * xh[r].y; a_g1.z += dy.z * xh[r].z; a_g1.w += dy.w * xh[r].w;
+            a_b1.x += dy.x; a_b1.y += dy.y; a_b1.z += dy.z; a_b1.w += dy.w;
+            gz[r] = make_float4(dy.x * ga.x, dy.y * ga.y, dy.z * ga.z, dy.w * ga.w);               // (g.d from here on)
+            const float n1 = wave_sum(gz[r].x + gz[r].y + gz[r].z + gz[r].w);
+            const float n2 = wave_sum(gz[r].x * xh[r].x + gz[r].y * xh[r].y + gz[r].z * xh[r].z + gz[r].w * xh[r].w);
+            if (lane == 0) redm[1][w][r] = make_float2(n1, n2);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < MLR; r++) {
+            if (!ok || p0 + r >= p_end) continue;
+            const float2 q0 = redm[1][0][r], q1 = redm[1][1][r], q2 = redm[1][2][r], q3 = redm[1][3][r];
+            const float n1 = (q0.x + q1.x + q2.x + q3.x) * invD, n2 = (q0.y + q1.y + q2.y + q3.y) * invD;
+            const int64_t xrow = b * Tp + 1 + p0 + r;
+            const float4 o = make_float4(r1[r] * (gz[r].x - n1 - xh[r].x * n2), r1[r] * (gz[r].y - n1 - xh[r].y * n2),
+                                         r1[r] * (gz[r].z - n1 - xh[r].z * n2), r1[r] * (gz[r].w - n1 - xh[r].w * n2));
+            ((float4*)(dx + xrow * D))[t] = o;
+            if (dx_bf16) {                              // the bf16 copy the first dX GEMM reads (saves a separate cast pass)
+                uint2 ob; ob.x = pack_bf2(o.x, o.y); ob.y = pack_bf2(o.z, o.w);
+                ((uint2*)(dx_bf16 + xrow * D))[t] = ob;
             }
         }
     }
-    // five column reductions: 4 waves -> LDS -> this workgroup's slab part[b][blockIdx.x][{dcls, dg1, db1, dg2, db2}][D]
-    float* mine = part + ((int64_t)b * gridDim.x + blockIdx.x) * 5 * D;
-    auto flush = [&](float4 (&acc)[LN_MAXV], float* dst) {
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < LN_MAXV; i++) {
-            const int idx = lane + i * 64;
-            if (idx < nvec) *(float4*)&red[w][idx * 4] = acc[i];
-        }
-        __syncthreads();
-        for (int c = threadIdx.x; c < D; c += 256) dst[c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
-    };
-    flush(a_c, mine);
-    flush(a_g1, mine + D); flush(a_b1, mine + 2 * D); flush(a_g2, mine + 3 * D); flush(a_b2, mine + 4 * D);
+    // this workgroup's slab part[b][blockIdx.x][{dcls, dg1, db1, dg2, db2}][D]: every thread owns its columns
+    if (ok) {
+        float* mine = part + ((int64_t)b * gridDim.x + blockIdx.x) * 5 * D;
+        ((float4*)mine)[t] = a_c; ((float4*)(mine + D))[t] = a_g1; ((float4*)(mine + 2 * D))[t] = a_b1;
+        ((float4*)(mine + 3 * D))[t] = a_g2; ((float4*)(mine + 4 * D))[t] = a_b2;
+    }
 }
 
 // cls rows: dy0 = dcls[b,:] -> LN1 backward on token 0 of image b
@@ -444,22 +459,29 @@ extern "C" int owl_query_normalize_bwd(void* stream, const float* dqhat, const f
 // box head tail backward: d(xyxy) -> d(cx,cy,w,h) -> sigmoid' -> dense2 backward fused with dense1's
 // erf-GELU derivative.  du1 = (dpre . W2) * gelu'(u1) (bf16) ; dW2 += dpre^T h1 ; db2 += sum dpre.
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float dgelu_erf(float u) {
-    return 0.5f * (1.0f + erff(u * 0.70710678118654752f)) + u * 0.39894228040143268f * __expf(-0.5f * u * u);
-}
 
+// One thread owns FOUR consecutive columns (8-byte loads of h1 / u1, 8-byte store of du1; its 16 dense2 weights live in registers) and walks
+// the workgroup's rows four at a time (eight loads in flight); D <= 1024, D % 4 == 0.  Per column the arithmetic and the row order of the
+// dW2 sums are those of a plain row loop.
 __global__ __launch_bounds__(256) void box_final_bwd_kernel(const float* __restrict__ dboxes, const float* __restrict__ sig,
                                                             const bf16_t* __restrict__ h1, const bf16_t* __restrict__ u1,
-                                                            const float* __restrict__ w2, bf16_t* du1, float* part,
+                                                            const float* __restrict__ w2, bf16_t* __restrict__ du1, float* __restrict__ part,
                                                             int64_t rows, int D, int rows_per_block) {
     __shared__ float4 dpre_s[256];
     const int t = threadIdx.x;
+    const int col = 4 * t;
+    const bool col_ok = col < D;
     const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block, r_end = min(rows, r_begin + rows_per_block);
-    float accw[4][4];   // [k][column slot]
+    float accw[4][4];   // [k][column]
 #pragma unroll
     for (int k = 0; k < 4; k++)
 #pragma unroll
         for (int c = 0; c < 4; c++) accw[k][c] = 0.f;
+    float4 wk[4] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+    if (col_ok) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) wk[k] = *(const float4*)(w2 + (int64_t)k * D + col);
+    }
     float4 accb = make_float4(0, 0, 0, 0);
     for (int64_t r0 = r_begin; r0 < r_end; r0 += 256) {
         const int64_t r = r0 + t;
@@ -474,29 +496,48 @@ __global__ __launch_bounds__(256) void box_final_bwd_kernel(const float* __restr
         dpre_s[t] = dp;
         __syncthreads();
         const int nr = (int)min((int64_t)256, r_end - r0);
-        for (int rr = 0; rr < nr; rr++) {
-            const float4 d = dpre_s[rr];
-            const int64_t row = r0 + rr;
+        if (col_ok) {
+            uint2 hn[4], un[4];                          // the NEXT four rows' operands: in flight while these four are computed
+            auto fetch = [&](int rr) {
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const int col = t + c * 256;
-                if (col < D) {
-                    const float hv = bf2f(h1[row * D + col]), uv = bf2f(u1[row * D + col]);
-                    const float dh1 = d.x * w2[col] + d.y * w2[D + col] + d.z * w2[2 * D + col] + d.w * w2[3 * D + col];
-                    du1[row * D + col] = f2bf(dh1 * dgelu_erf(uv));
-                    accw[0][c] += d.x * hv; accw[1][c] += d.y * hv; accw[2][c] += d.z * hv; accw[3][c] += d.w * hv;
+                for (int j = 0; j < 4; j++) {
+                    const int64_t row = r0 + min(rr + j, nr - 1);
+                    hn[j] = *(const uint2*)(h1 + row * D + col);
+                    un[j] = *(const uint2*)(u1 + row * D + col);
+                }
+            };
+            fetch(0);
+            for (int rr = 0; rr < nr; rr += 4) {
+                uint2 hq[4], uq[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) { hq[j] = hn[j]; uq[j] = un[j]; }
+                if (rr + 4 < nr) fetch(rr + 4);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (rr + j >= nr) break;
+                    const float4 d = dpre_s[rr + j];
+                    const float hv[4] = {bf2f(hq[j].x & 0xffff), bf2f(hq[j].x >> 16), bf2f(hq[j].y & 0xffff), bf2f(hq[j].y >> 16)};
+                    const float uv[4] = {bf2f(uq[j].x & 0xffff), bf2f(uq[j].x >> 16), bf2f(uq[j].y & 0xffff), bf2f(uq[j].y >> 16)};
+                    const float w0[4] = {wk[0].x, wk[0].y, wk[0].z, wk[0].w}, w1[4] = {wk[1].x, wk[1].y, wk[1].z, wk[1].w};
+                    const float w2r[4] = {wk[2].x, wk[2].y, wk[2].z, wk[2].w}, w3[4] = {wk[3].x, wk[3].y, wk[3].z, wk[3].w};
+                    float o[4];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const float dh1 = d.x * w0[c] + d.y * w1[c] + d.z * w2r[c] + d.w * w3[c];
+                        o[c] = dh1 * dgelu_erf_f(uv[c]);
+                        accw[0][c] += d.x * hv[c]; accw[1][c] += d.y * hv[c]; accw[2][c] += d.z * hv[c]; accw[3][c] += d.w * hv[c];
+                    }
+                    uint2 ov; ov.x = pack_bf2(o[0], o[1]); ov.y = pack_bf2(o[2], o[3]);
+                    *(uint2*)(du1 + (r0 + rr + j) * D + col) = ov;
                 }
             }
         }
     }
     // per-workgroup partials [nblk][4*D + 4] (reduced deterministically by owl_slab_reduce)
     float* mypart = part + (int64_t)blockIdx.x * (4 * D + 4);
+    if (col_ok) {
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-        const int col = t + c * 256;
-        if (col < D)
-#pragma unroll
-            for (int k = 0; k < 4; k++) mypart[k * D + col] = accw[k][c];
+        for (int k = 0; k < 4; k++) *(float4*)(mypart + (int64_t)k * D + col) = make_float4(accw[k][0], accw[k][1], accw[k][2], accw[k][3]);
     }
     __shared__ float4 redb[4];
     accb.x = wave_sum(accb.x); accb.y = wave_sum(accb.y); accb.z = wave_sum(accb.z); accb.w = wave_sum(accb.w);

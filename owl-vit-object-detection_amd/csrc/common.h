@@ -26,6 +26,18 @@ __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));   // ONE v_cvt_pk_bf16_f32
 }
 
+// d/du [u Phi(u)] = Phi(u) + u phi(u) for the BACKWARD of the erf-GELU (box head): Phi through the Abramowitz-Stegun 7.1.26 rational form of erf
+// (|error| <= 1.5e-7: an f32 ulp of Phi), which shares its exp(-u^2/2) with phi -- one v_exp, one v_rcp and a dozen FMAs instead of libm's
+// branchy erff plus an expf (the kernels that use it are bound by exactly these instructions).  Gradient-only: the forward GELU keeps erff.
+__device__ __forceinline__ float dgelu_erf_f(float u) {
+    const float x = fabsf(u) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+    const float e = __builtin_amdgcn_exp2f(u * u * -0.72134752044448170f);          // exp(-u^2 / 2)
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float erf_abs = fmaf(-poly, e, 1.0f);                                     // erf(|u| / sqrt 2)
+    return fmaf(0.5f, copysignf(erf_abs, u), 0.5f) + u * 0.39894228040143268f * e;
+}
+
 // LDS reads the compiler must not "protect": after a global_load_lds the compiler makes every later C++ LDS read
 // wait for vmcnt(0) -- and on gfx950 vmcnt also counts STORES, so one bias read between two epilogue stores turns
 // the whole store tail into store -> ack -> store -> ack (measured: ~9 us of a 34 us K=768 tile).  These helpers

@@ -46,9 +46,7 @@ __device__ __forceinline__ float dqgelu_f(float u) {
     return s * (1.0f + 1.702f * u * (1.0f - s));
 }
 __device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752f)); }
-__device__ __forceinline__ float dgelu_f(float u) {
-    return 0.5f * (1.0f + erff(u * 0.70710678118654752f)) + u * 0.39894228040143268f * __expf(-0.5f * u * u);
-}
+__device__ __forceinline__ float dgelu_f(float u) { return dgelu_erf_f(u); }   // (common.h)
 
 // ---- XCD-aware bijective tile remap (blocks b, b+8, ... share an XCD / L2) -------------------------
 __device__ __forceinline__ int xcd_remap(int bid, int ntile) {

@@ -183,6 +183,35 @@ def test_merge_ln():
     report("merge+add feats", feats[: B * P].view(B, P, D), F.layer_norm(y2[:, 1:] * y2[:, :1], (D,), g2, b2, 1e-5), 2e-2, 1e-2)
 
 
+@pytest.mark.parametrize("B,P,D", [(2, 36, 128), (3, 100, 768), (1, 67, 1024), (2, 2304, 768)])
+def test_merge_ln_bwd_matches_torch_autograd(B, P, D):
+    """Backward of `LN2(LN1(x)[1:] * LN1(x)[0])` (ref models.py:80-86): dx for every token (patch rows and the class-token row, f32 + the bf16 copy)
+    and the four LayerNorm parameter gradients accumulated into the bucket; ragged row counts (P % 64, P % 4 != 0), both model widths."""
+    T = P + 1; Tp = (T + 7) // 8 * 8
+    x = torch.zeros(B * Tp, D, device=DEV); xv = x.view(B, Tp, D)
+    xv[:, :T] = rnd(B, T, D, scale=1.5)
+    g1 = 1 + 0.1 * rnd(D, seed=1); b1 = 0.1 * rnd(D, seed=2); g2 = 1 + 0.1 * rnd(D, seed=3); b2 = 0.1 * rnd(D, seed=4)
+    cls_ln = torch.zeros(B, D, device=DEV); feats = ops.zeros_rows(B * P, D, torch.bfloat16, DEV)
+    s1 = torch.zeros(B * Tp, 2, device=DEV); s2 = torch.zeros(B * P, 2, device=DEV)
+    ops.merge_ln(x, g1, b1, g2, b2, cls_ln, feats, s1, s2, B, P, Tp, D)
+    dfeats = rnd(B * P, D, seed=7)
+    xr = xv[:, :T].clone().requires_grad_(True)
+    G1, B1, G2, B2 = (t.clone().requires_grad_(True) for t in (g1, b1, g2, b2))
+    y = F.layer_norm(xr, (D,), G1, B1, 1e-5)
+    F.layer_norm(y[:, 1:] * y[:, :1], (D,), G2, B2, 1e-5).backward(dfeats.view(B, P, D))
+    dx = torch.zeros(B * Tp, D, device=DEV); dxb = torch.zeros(B * Tp, D, device=DEV, dtype=torch.bfloat16); dcls = torch.zeros(B, D, device=DEV)
+    grads = [torch.ones(D, device=DEV) for _ in range(4)]              # accumulated onto (the bucket is not zero in general)
+    ops.merge_ln_bwd(dfeats, x, cls_ln, s1, s2, g1, b1, g2, dx, dcls, *grads, B, P, Tp, D, dx_bf16=dxb)
+    scale = float(xr.grad.abs().max())
+    report("dx", dx.view(B, Tp, D)[:, :T], xr.grad, 2e-5 * scale, 1e-4)
+    assert torch.equal(dxb.view(B, Tp, D)[:, :T], dx.view(B, Tp, D)[:, :T].bfloat16())
+    for name, got, ref in zip(("dg1", "db1", "dg2", "db2"), grads, (G1.grad, B1.grad, G2.grad, B2.grad)):
+        report(name, got - 1.0, ref, 1e-4 * float(ref.abs().max()) + 1e-5, 1e-4)
+    dx2 = torch.zeros_like(dx); grads2 = [torch.ones(D, device=DEV) for _ in range(4)]
+    ops.merge_ln_bwd(dfeats, x, cls_ln, s1, s2, g1, b1, g2, dx2, dcls, *grads2, B, P, Tp, D, dx_bf16=dxb)
+    assert torch.equal(dx, dx2) and all(torch.equal(a, b) for a, b in zip(grads, grads2))      # fixed-order sums
+
+
 def _attn_case(B, H, T, seed):
     Tp = (T + 7) // 8 * 8
     D = H * 64
@@ -262,6 +291,34 @@ def test_box_final():
     s = torch.sigmoid(h.float() @ w2.t() + b2 + bb.repeat(B, 1))
     ref = torch.stack([s[:, 0] - 0.5 * s[:, 2], s[:, 1] - 0.5 * s[:, 3], s[:, 0] + 0.5 * s[:, 2], s[:, 1] + 0.5 * s[:, 3]], -1)
     report("sig", sig, s, 1e-5, 1e-5); report("boxes", boxes, ref, 1e-5, 1e-5)
+
+
+@pytest.mark.parametrize("rows,D", [(72, 128), (2304, 768), (1000, 1024), (73728, 768)])
+def test_box_final_bwd_matches_torch_autograd(rows, D):
+    """d(xyxy) -> d(cx,cy,w,h) -> sigmoid' -> dense2 backward fused with dense1's erf-GELU derivative (ref models.py:65-73 + autograd):
+    du1 (bf16), dW2 / db2 accumulated into the bucket; ragged row counts, both model widths, the headline row count."""
+    from owl_vit_object_detection_amd import _lib
+    u1 = rnd(rows, D, seed=4).bfloat16(); h1 = torch.nn.functional.gelu(u1.float()).bfloat16()
+    w2 = rnd(4, D, scale=0.1, seed=1); b2 = rnd(4, seed=2)
+    dboxes = rnd(rows, 4, seed=5)
+    # f32 reference through autograd (h1 taken as the bf16 tensor the forward saved)
+    u = u1.float().requires_grad_(True); W = w2.clone().requires_grad_(True); bb = b2.clone().requires_grad_(True)
+    hq = h1.float() + (torch.nn.functional.gelu(u) - torch.nn.functional.gelu(u).detach())     # value = saved bf16 h1, gradient = gelu'(u)
+    s = torch.sigmoid(hq @ W.t() + bb)
+    boxes = torch.stack([s[:, 0] - 0.5 * s[:, 2], s[:, 1] - 0.5 * s[:, 3], s[:, 0] + 0.5 * s[:, 2], s[:, 1] + 0.5 * s[:, 3]], -1)
+    boxes.backward(dboxes)
+    sig = s.detach().contiguous()
+    du1 = torch.zeros(rows, D, device=DEV, dtype=torch.bfloat16)
+    nblk = _lib.load().owl_box_final_bwd_blocks(rows)
+    part = torch.zeros(nblk, 4 * D + 4, device=DEV)
+    g = torch.ones(4 * D + 4, device=DEV)                    # dW2 followed by db2, as in the flat bucket; accumulated onto
+    ops.box_final_bwd(dboxes, sig, h1, u1, w2, du1, part, g, rows, D)
+    report("du1", du1.float(), u.grad, 1e-3, 4e-3)
+    report("dW2", g[:4 * D].view(4, D) - 1.0, W.grad, 1e-2 * float(W.grad.abs().max()), 1e-3)
+    report("db2", g[4 * D:] - 1.0, bb.grad, 1e-3 * max(1.0, float(bb.grad.abs().max())), 1e-3)
+    g2 = torch.ones(4 * D + 4, device=DEV); du2 = torch.zeros_like(du1)
+    ops.box_final_bwd(dboxes, sig, h1, u1, w2, du2, part, g2, rows, D)
+    assert torch.equal(du1, du2) and torch.equal(g, g2)     # fixed-order partial sums
 
 
 def test_cast_and_transpose():
