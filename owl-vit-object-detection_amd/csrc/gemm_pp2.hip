@@ -283,9 +283,11 @@ static int launch_pp2(hipStream_t s, GemmP p) {
     p.dbg = 0;
     // column-block width of the tile order (see `decode`): the largest divisor of tiles_n up to 4 for the forward epilogues (same-process A/B at
     // M = 73 984: QKV -3 %, half-batch fc1 -4 %, others +-0); the plain row-major order (one block) elsewhere -- dX through quick-GELU' measured
-    // 5 % slower blocked (its A panel is then fetched three times, beside the 455 MB of pre-activations it already streams)
+    // 5 % slower blocked (its A panel is then fetched three times, beside the 455 MB of pre-activations it already streams), and so did the
+    // WHOLE-batch fc1 inside the model (289 row panels: 0.387 -> 0.363 ms per launch row-major, old / new library alternated in bench.py
+    // --encoder-streams 1; the stand-alone tool had it neutral) -- blocked only up to 160 row panels there (the sub-batch launches).
     p.nsplit = p.tiles_n;
-    if (EPI == EPI_BIAS_BF16 || EPI == EPI_QGELU_BF16)
+    if ((EPI == EPI_BIAS_BF16 || EPI == EPI_QGELU_BF16) && !(EPI == EPI_QGELU_BF16 && p.tiles_m > 160))
         for (int d = 4; d >= 1; d--)
             if (p.tiles_n % d == 0) { p.nsplit = d; break; }
     const int nitems = p.tiles_m * p.tiles_n;
