@@ -8,6 +8,7 @@ FLAGS="--offload-arch=${ARCH} -O3 -std=c++17 -fPIC -Wno-unused-value"
 if [ "${OWL_TUNING:-0}" = "1" ]; then FLAGS="$FLAGS -DOWL_TUNING"; fi
 mkdir -p build
 objs=""
+pids=""
 for f in *.hip; do
   o=build/${f%.hip}.o
   stale=0
@@ -20,11 +21,15 @@ for f in *.hip; do
       # (MI355X_MICROARCH.md; measured -1.7 % on the backward pair): no SLP packing in the attention kernels
       attention_bwd.hip|attention_fwd.hip) extra="-fno-slp-vectorize";;
     esac
+    rm -f "$o"                                   # a failed compile must not leave the previous object for the link step
     hipcc $FLAGS $extra -c "$f" -o "$o" &
+    pids="$pids $!"
   fi
   objs="$objs $o"
 done
-wait
+fail=0
+for pid in $pids; do wait $pid || fail=1; done
+if [ $fail = 1 ]; then echo "build.sh: a HIP source failed to compile" >&2; exit 1; fi
 g++ -O2 -fPIC -std=c++17 -ffp-contract=off -c runtime.cpp -o build/runtime.o
 hipcc --offload-arch=${ARCH} -shared -fPIC -o ../libowlhip.so $objs build/runtime.o
 echo "built $(cd .. && pwd)/libowlhip.so"
