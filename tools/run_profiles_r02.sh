@@ -14,7 +14,12 @@ timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r2_prof_b16 -o rf 
 timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r2_prof_l14 -o rf -- python $R/bench.py --no-cpu-baseline --no-compare --encoder-streams 1 --arch owlvit-large-patch14 --batch 16 --steps 4 --warmup 2 > $R/gpurun_out/r2_prof_l14.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/r2_pmc_fetch -o p -f csv -- python $R/bench.py --no-cpu-baseline --no-compare --no-kernel-events --encoder-streams 1 --steps 2 --warmup 1 > $R/gpurun_out/r2_pmc_fetch.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/r2_pmc_write -o p -f csv -- python $R/bench.py --no-cpu-baseline --no-compare --no-kernel-events --encoder-streams 1 --steps 2 --warmup 1 > $R/gpurun_out/r2_pmc_write.log 2>&1
+#   4. steady-state launches per step: two kernel traces (--steps 4 / --steps 14), differenced by tools/steady_state_counts.py -> r2_steady_state.md
+timeout 300 rocprofv3 --kernel-trace -d $R/gpurun_out/r2_ss4 -o rf -- python $R/bench.py --no-cpu-baseline --no-compare --no-kernel-events --encoder-streams 1 --steps 4 > $R/gpurun_out/r2_ss4.log 2>&1
+timeout 300 rocprofv3 --kernel-trace -d $R/gpurun_out/r2_ss14 -o rf -- python $R/bench.py --no-cpu-baseline --no-compare --no-kernel-events --encoder-streams 1 --steps 14 > $R/gpurun_out/r2_ss14.log 2>&1
 cd $R
+python tools/steady_state_counts.py $(ls gpurun_out/r2_ss4/*.db | head -1) 4 $(ls gpurun_out/r2_ss14/*.db | head -1) 14 > gpurun_out/r2_steady_state.md
+rm -rf gpurun_out/r2_ss4 gpurun_out/r2_ss14
 python tools/prof_summary.py $(ls gpurun_out/r2_prof_b16/*.db | head -1) 60 > gpurun_out/r2_prof_b16_summary.md
 python tools/prof_summary.py $(ls gpurun_out/r2_prof_l14/*.db | head -1) 40 > gpurun_out/r2_prof_l14_summary.md
 python tools/pmc_traffic.py gpurun_out/r2_pmc_fetch gpurun_out/r2_pmc_write --json gpurun_out/r2_traffic.json > gpurun_out/r2_hbm_traffic.md
