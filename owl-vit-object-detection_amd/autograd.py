@@ -98,6 +98,10 @@ def _bws(model, B):
         tAh=torch.zeros(32 if tn_all else max(D, Dt), Mhp, dtype=bf, device=dev),
         tBh=torch.zeros(max(D, Dt), Mhp, dtype=bf, device=dev),
         wT=torch.zeros(wide * max(D, I), dtype=bf, device=dev),
+        # the class head's backward runs beside the box head's on the side stream: its own split-K slab and transposed-weight scratch
+        slab2=torch.zeros(max(_split_k(a, b, 1 << 30) * a * b for a, b in ((Dt, D), (32, Dt))), device=dev),
+        wT2=torch.zeros(Dt * D, dtype=bf, device=dev),
+        tn_all=tn_all,
     )
     model._ws[key] = ws
     return ws
@@ -134,13 +138,13 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
     d_boxes = d_boxes.contiguous().float()
     d_sims = d_sims.contiguous().float()
 
-    def wT(name, rows, cols):
+    def wT(name, rows, cols, buf="wT"):
         """bf16 transpose of a trainable weight [rows, cols] -> [cols, rows] in scratch."""
-        out = bw["wT"][: rows * cols].view(cols, rows)
+        out = bw[buf][: rows * cols].view(cols, rows)
         ops.transpose_bf16(tv(name), out, rows, cols)
         return out
 
-    def dW(dy, x, grad_w, n_out, n_in, rows, rows_pad, grad_b=None, accumulate=1, part="part"):
+    def dW(dy, x, grad_w, n_out, n_in, rows, rows_pad, grad_b=None, accumulate=1, part="part", slab="slab"):
         """grad_w[n_out, n_in] (+)= dy[rows, n_out]^T x[rows, n_in];  grad_b += colsum(dy).
         Token-major operand copies (transposes) -> split-K GEMM into f32 slabs -> deterministic slab reduction.
         Pad columns [rows, rows_pad) of the scratch stay zero: never written, buffers start zeroed."""
@@ -149,8 +153,8 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
             if grad_b is not None:
                 ops.colsum_bf16(dy, grad_b, rows, n_out, partials=bw[part])
             tiles = (n_out // 256) * (n_in // 256)
-            ns = ops.gemm_tn_slab(dy, x, bw["slab"], rows, n_out, n_in, max(1, 256 // tiles))
-            _lib.call("owl_slab_reduce", ops.stream(), bw["slab"], grad_w, n_out * n_in, n_out * n_in, ns, accumulate)
+            ns = ops.gemm_tn_slab(dy, x, bw[slab], rows, n_out, n_in, max(1, 256 // tiles))
+            _lib.call("owl_slab_reduce", ops.stream(), bw[slab], grad_w, n_out * n_in, n_out * n_in, ns, accumulate)
             return
         tA, tB = (bw["tAh"], bw["tBh"]) if rows == Mh else (bw["tA"], bw["tB"])
         ld = tA.shape[1]
@@ -159,16 +163,30 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
         ops.transpose_colsum(x, tB, None, rows, n_in, ld_in=x.shape[-1], ld_out=ld)
         want = _split_k(n_out, n_in, rows_pad)
         ns = _lib.load().owl_gemm_effective_splits(rows_pad, want)
-        ops.gemm(ops.EPI_SLAB_F32, tA, tB, bw["slab"], M=n_out, N=n_in, K=rows_pad, lda=ld, ldw=ld, ldo=n_in,
+        ops.gemm(ops.EPI_SLAB_F32, tA, tB, bw[slab], M=n_out, N=n_in, K=rows_pad, lda=ld, ldw=ld, ldo=n_in,
                  a_rows=n_out, w_rows=n_in, splits=want)
-        _lib.call("owl_slab_reduce", ops.stream(), bw["slab"], grad_w, n_out * n_in, n_out * n_in, ns, accumulate)
+        _lib.call("owl_slab_reduce", ops.stream(), bw[slab], grad_w, n_out * n_in, n_out * n_in, ns, accumulate)
 
+    # The two heads only meet in d(feats): with sub-batch streams on (and every dW on the TN kernel, so that the heads share no transposed-operand
+    # scratch) the class head's backward runs on the side stream with its own slab / reduction / transposed-weight scratch, beside the box
+    # head's on this one; the box head's last GEMM accumulates into d(feats) behind the class head's event.  Same kernels, same order of the
+    # two contributions: same bits.
+    main0 = torch.cuda.current_stream()
+    hs = model._side_stream(1) if (model.head_streams and model.encoder_streams > 1 and len(model._encoder_chunks(B)) > 1 and bw["tn_all"]) else main0
+    ev_h = model._dw_events
+    if hs is not main0:
+        ev_h[0].record(main0)
+        hs.wait_event(ev_h[0])
+    cs, cp, cw = ("slab2", "part2", "wT2") if hs is not main0 else ("slab", "part", "wT")
     # ---- class head ---------------------------------------------------------------------------------
-    ops.class_sims_bwd(d_sims, sims, ws["argmax"], ws["inv_norm"], ws["e"], ws["qhat"], bw["de"], bw["g32"], bw["e_bf"], Mh, Dt, C)
-    dW(bw["g32"], bw["e_bf"], bw["dqhat"], 32, Dt, Mh, Mhp, None, accumulate=0)          # dqhat = G^T e
-    _lib.call("owl_query_normalize_bwd", ops.stream(), bw["dqhat"], P_["queries"], G("queries"), cfg.queries, Dt)
-    dW(bw["de"], ws["feats"], G("class_predictor.dense0.weight"), Dt, D, Mh, Mhp, G("class_predictor.dense0.bias"))
-    ops.gemm(ops.EPI_F32, bw["de"], wT("class_predictor.dense0.weight", Dt, D), bw["dfeats"], M=Mh, N=D, K=Dt)
+    with torch.cuda.stream(hs):
+        ops.class_sims_bwd(d_sims, sims, ws["argmax"], ws["inv_norm"], ws["e"], ws["qhat"], bw["de"], bw["g32"], bw["e_bf"], Mh, Dt, C)
+        dW(bw["g32"], bw["e_bf"], bw["dqhat"], 32, Dt, Mh, Mhp, None, accumulate=0, part=cp, slab=cs)          # dqhat = G^T e
+        _lib.call("owl_query_normalize_bwd", ops.stream(), bw["dqhat"], P_["queries"], G("queries"), cfg.queries, Dt)
+        dW(bw["de"], ws["feats"], G("class_predictor.dense0.weight"), Dt, D, Mh, Mhp, G("class_predictor.dense0.bias"), part=cp, slab=cs)
+        ops.gemm(ops.EPI_F32, bw["de"], wT("class_predictor.dense0.weight", Dt, D, buf=cw), bw["dfeats"], M=Mh, N=D, K=Dt)
+        if hs is not main0:
+            ev_h[1].record(hs)
     # ---- box head -------------------------------------------------------------------------------------
     gw2, gb2 = G("box_head.dense2.weight"), G("box_head.dense2.bias")
     assert gb2.data_ptr() == gw2.data_ptr() + 4 * gw2.numel(), "dense2 weight/bias grads must be adjacent in the flat bucket"
@@ -176,7 +194,10 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
     dW(bw["du1"], ws["hb0"], G("box_head.dense1.weight"), D, D, Mh, Mhp, G("box_head.dense1.bias"))
     ops.gemm(ops.EPI_DGELU_BF16, bw["du1"], wT("box_head.dense1.weight", D, D), bw["du0"], aux=ws["ub0"], M=Mh, N=D, K=D)
     dW(bw["du0"], ws["feats"], G("box_head.dense0.weight"), D, D, Mh, Mhp, G("box_head.dense0.bias"))
-    ops.gemm(ops.EPI_ACC_F32, bw["du0"], wT("box_head.dense0.weight", D, D), bw["dfeats"], M=Mh, N=D, K=D)
+    w0T = wT("box_head.dense0.weight", D, D)
+    if hs is not main0:
+        main0.wait_event(ev_h[1])                 # d(feats) of the class head is in place (and the side stream's scratch is free again)
+    ops.gemm(ops.EPI_ACC_F32, bw["du0"], w0T, bw["dfeats"], M=Mh, N=D, K=D)
     # ---- merge + the two final LayerNorms --------------------------------------------------------------
     ops.merge_ln_bwd(bw["dfeats"], ws["x"], ws["cls_ln"], ws["st_post"], ws["st_pp"], P_["backbone.post_layernorm.weight"],
                      P_["backbone.post_layernorm.bias"], P_["post_post_layernorm.weight"], bw["dx"], bw["dcls"],

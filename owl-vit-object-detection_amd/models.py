@@ -137,6 +137,7 @@ class OwlViT(nn.Module):
         self._bf16_version = None          # flat_param._version the bf16 compute copy was cast from
         self.encoder_streams = int(encoder_streams)     # sub-batches of the encoder forward, one HIP stream each (see _forward_impl); 1 = off
         self._streams, self._join, self._fork_ev = [], {}, None
+        self.head_streams = True          # box head / class head (forward and backward) on two streams when the sub-batch streams are on
         self._dw_events_ = None
         self._param_event = None           # ddp.DataParallel(overlap=True): the deferred all-reduce + AdamW of the previous step
         self._grad_clean = False           # ... which also left flat_grad zeroed for this step
@@ -407,18 +408,28 @@ class OwlViT(nn.Module):
         ops.merge_ln(xs, P_["backbone.post_layernorm.weight"], P_["backbone.post_layernorm.bias"], P_["post_post_layernorm.weight"],
                      P_["post_post_layernorm.bias"], ws["cls_ln"], feats, ws["st_post"], ws["st_pp"], B, P, Tp, D, cfg.ln_eps,
                      delta=pending, x_out=x)
+        # The box head and the class head only share their input: with sub-batch streams on, the class head runs on the side stream beside the
+        # box head (its kernels fill the CUs the box GEMMs' remainder rounds leave idle).  Outputs are allocated before the fork.
+        pred_boxes = torch.empty(B, P, 4, device=self.device_)
+        pred_sims = torch.empty(B, P, C, device=self.device_)
+        side = self._side_stream(1) if (self.head_streams and self.encoder_streams > 1 and len(chunks) > 1) else None
+        if side is not None:
+            self._fork_ev.record(main)
+            side.wait_event(self._fork_ev)
+        # ---- class head (ref src/models.py:24-38) ------------------------------------------------------
+        with torch.cuda.stream(side if side is not None else main):
+            ops.gemm(ops.EPI_F32, feats, tv("class_predictor.dense0.weight"), ws["e"], bias=P_["class_predictor.dense0.bias"], M=Mh, N=Dt, K=D)
+            ops.query_normalize(P_["queries"], ws["qhat"], ws["qnorm"], cfg.queries, Dt)
+            ops.class_sims(ws["e"], ws["qhat"], pred_sims, ws["argmax"], ws["inv_norm"], Mh, Dt, C)
         # ---- box head (HF5:983-999) + bias / sigmoid / corners ---------------------------------------
         ops.gemm(ops.EPI_GELU_BF16, feats, tv("box_head.dense0.weight"), ws["hb0"], bias=P_["box_head.dense0.bias"],
                  aux=ws["ub0"] if save else None, M=Mh, N=D, K=D)
         ops.gemm(ops.EPI_GELU_BF16, ws["hb0"], tv("box_head.dense1.weight"), ws["hb1"], bias=P_["box_head.dense1.bias"],
                  aux=ws["ub1"] if save else None, M=Mh, N=D, K=D)
-        pred_boxes = torch.empty(B, P, 4, device=self.device_)
         ops.box_final(ws["hb1"], P_["box_head.dense2.weight"], P_["box_head.dense2.bias"], self.box_bias, pred_boxes, ws["sig"], Mh, P, D)
-        # ---- class head (ref src/models.py:24-38) ------------------------------------------------------
-        ops.gemm(ops.EPI_F32, feats, tv("class_predictor.dense0.weight"), ws["e"], bias=P_["class_predictor.dense0.bias"], M=Mh, N=Dt, K=D)
-        ops.query_normalize(P_["queries"], ws["qhat"], ws["qnorm"], cfg.queries, Dt)
-        pred_sims = torch.empty(B, P, C, device=self.device_)
-        ops.class_sims(ws["e"], ws["qhat"], pred_sims, ws["argmax"], ws["inv_norm"], Mh, Dt, C)
+        if side is not None:
+            self._join[1].record(side)
+            main.wait_event(self._join[1])
         return pred_boxes, pred_sims
 
     def forward(self, image: torch.Tensor):
