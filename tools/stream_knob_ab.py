@@ -1,5 +1,5 @@
-"""In-process A/B of one of OwlViT's stream-schedule switches (head_streams: box head / class head on two streams, forward and backward; embed_streams:
-per-sub-batch embeddings): same bits (losses, predictions, gradient bucket), alternating timed runs of the full train step on one box.
+"""In-process A/B of one of OwlViT's stream-schedule switches (a boolean attribute of the model; default head_streams: box head / class head on two
+streams, forward and backward): same bits (losses, predictions, gradient bucket), alternating timed runs of the full train step on one box.
 Usage: stream_knob_ab.py [arch batch [attribute]].  Results in profiles/r02_encoder_streams.md."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
