@@ -47,7 +47,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* x, const bf16_
                     const uint2 u2 = ((const uint2*)(delta2 + row * D))[lane + i * 64];
                     v[i].x += bf2f(u2.x & 0xffff); v[i].y += bf2f(u2.x >> 16); v[i].z += bf2f(u2.y & 0xffff); v[i].w += bf2f(u2.y >> 16);
                 }
-                if (x_out) ((float4*)(x_out + row * D))[lane + i * 64] = v[i];
+                if (x_out) {
+                    // The sum is not read again before the next LayerNorm (a QKV GEMM, an attention and an out-proj launch later), while h -- written
+                    // by this same kernel -- is the next GEMM's A operand: the streaming store keeps x from pushing h out of the 256 MB Infinity
+                    // Cache (in-model A/B, old / new library alternated: two-stream step -0.35 %, profiles/r02_encoder_streams.md).
+                    typedef float nt_f4 __attribute__((ext_vector_type(4)));
+                    const nt_f4 t = {v[i].x, v[i].y, v[i].z, v[i].w};
+                    __builtin_nontemporal_store(t, (nt_f4*)(x_out + row * D) + lane + i * 64);
+                }
             }
         }
     float mean, rstd;
