@@ -84,13 +84,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         for (int i = 0; i < LN_MAXV; i++) {
             const int idx = lane + i * 64;
             if (idx < nvec) {
-                const float4 xv = ((const float4*)(x + row * D))[idx];
+                const float4 xv = ld_stream_f4(x + row * D + 4 * idx);          // saved activation, upstream gradient, residual gradient: all dead after this
                 float4 dyv;
                 if constexpr (DY_BF16) {
-                    const uint2 u = ((const uint2*)((const bf16_t*)dy_ + row * D))[idx];
+                    const uint2 u = ld_stream_u2((const uint2*)((const bf16_t*)dy_ + row * D) + idx);
                     dyv = make_float4(bf2f(u.x & 0xffff), bf2f(u.x >> 16), bf2f(u.y & 0xffff), bf2f(u.y >> 16));
                 } else {
-                    dyv = ((const float4*)((const float*)dy_ + row * D))[idx];
+                    dyv = ld_stream_f4((const float*)dy_ + row * D + 4 * idx);
                 }
                 const float4 g = ((const float4*)gamma)[idx];
                 xh[i] = make_float4((xv.x - st.x) * st.y, (xv.y - st.x) * st.y, (xv.z - st.x) * st.y, (xv.w - st.x) * st.y);
@@ -110,10 +110,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                     float4 o = make_float4(st.y * (gd[i].x - s1 - xh[i].x * s2), st.y * (gd[i].y - s1 - xh[i].y * s2),
                                            st.y * (gd[i].z - s1 - xh[i].z * s2), st.y * (gd[i].w - s1 - xh[i].w * s2));
                     if (dres) {
-                        const float4 r = ((const float4*)(dres + row * D))[idx];
+                        const float4 r = ld_stream_f4(dres + row * D + 4 * idx);
                         o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
                     }
-                    ((float4*)(dx + row * D))[idx] = o;
+                    st_stream_f4(dx + row * D + 4 * idx, o);          // f32 gradient stream: next read by the LayerNorm backward two GEMMs later
                     if constexpr (DXSUM) { float4& a = ad[DXSUM ? i : 0]; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
                     if (dx_bf16) {                          // the bf16 copy the next dX GEMM reads (saves a separate cast pass)
                         uint2 ob; ob.x = pack_bf2(o.x, o.y); ob.y = pack_bf2(o.z, o.w);
@@ -205,8 +205,8 @@ __global__ __launch_bounds__(256) void merge_ln_bwd_kernel(const float* __restri
         for (int r = 0; r < MLR; r++) {
             xn[r] = z4; dn[r] = z4;                       // (rows past the end: zero statistics and zero dfeats -> zero contributions, no store)
             if (ok && p0 + r < p_end) {
-                xn[r] = ((const float4*)(x + (b * Tp + 1 + p0 + r) * D))[t];
-                dn[r] = ((const float4*)(dfeats + (b * P + p0 + r) * D))[t];
+                xn[r] = ld_stream_f4(x + (b * Tp + 1 + p0 + r) * D + 4 * t);
+                dn[r] = ld_stream_f4(dfeats + (b * P + p0 + r) * D + 4 * t);
             }
         }
     };
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void merge_ln_bwd_kernel(const float* __restri
             const int64_t xrow = b * Tp + 1 + p0 + r;
             const float4 o = make_float4(r1[r] * (gz[r].x - n1 - xh[r].x * n2), r1[r] * (gz[r].y - n1 - xh[r].y * n2),
                                          r1[r] * (gz[r].z - n1 - xh[r].z * n2), r1[r] * (gz[r].w - n1 - xh[r].w * n2));
-            ((float4*)(dx + xrow * D))[t] = o;
+            st_stream_f4(dx + xrow * D + 4 * t, o);
             if (dx_bf16) {                              // the bf16 copy the first dX GEMM reads (saves a separate cast pass)
                 uint2 ob; ob.x = pack_bf2(o.x, o.y); ob.y = pack_bf2(o.z, o.w);
                 ((uint2*)(dx_bf16 + xrow * D))[t] = ob;
@@ -502,8 +502,8 @@ __global__ __launch_bounds__(256) void box_final_bwd_kernel(const float* __restr
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const int64_t row = r0 + min(rr + j, nr - 1);
-                    hn[j] = *(const uint2*)(h1 + row * D + col);
-                    un[j] = *(const uint2*)(u1 + row * D + col);
+                    hn[j] = ld_stream_u2(h1 + row * D + col);
+                    un[j] = ld_stream_u2(u1 + row * D + col);
                 }
             };
             fetch(0);

@@ -26,6 +26,24 @@ __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));   // ONE v_cvt_pk_bf16_f32
 }
 
+// Streaming (non-temporal) accesses for data that is dead once read, or not read again soon once written: such rows then do not age out what
+// the neighbouring GEMMs re-read through the L2 / Infinity Cache (profiles/r02_encoder_streams.md: the add + LayerNorm kernel alone was worth
+// 1.3 % of the train step and 2.5 % of every GEMM launch).
+typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned nt_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 ld_stream_f4(const float* p) {
+    const nt_f32x4 t = __builtin_nontemporal_load((const nt_f32x4*)p);
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ uint2 ld_stream_u2(const void* p) {
+    const nt_u32x2 t = __builtin_nontemporal_load((const nt_u32x2*)p);
+    return make_uint2(t.x, t.y);
+}
+__device__ __forceinline__ void st_stream_f4(float* p, const float4& v) {
+    const nt_f32x4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, (nt_f32x4*)p);
+}
+
 // d/du [u Phi(u)] = Phi(u) + u phi(u) for the BACKWARD of the erf-GELU (box head): Phi through the Abramowitz-Stegun 7.1.26 rational form of erf
 // (|error| <= 1.5e-7: an f32 ulp of Phi), which shares its exp(-u^2/2) with phi -- one v_exp, one v_rcp and a dozen FMAs instead of libm's
 // branchy erff plus an expf (the kernels that use it are bound by exactly these instructions).  Gradient-only: the forward GELU keeps erff.

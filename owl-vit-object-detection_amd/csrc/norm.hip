@@ -39,30 +39,18 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* x, const bf16_
 #pragma unroll
     for (int i = 0; i < LN_MAXV; i++)
         if (lane + i * 64 < nvec) {
-            {   // x and the branch outputs are dead once this kernel has read them: streaming loads, so that they do not age out the rows
-                // the neighbouring GEMMs re-read through the Infinity Cache (in-model A/B: whole step -1.3 %, every GEMM launch -2.5 %)
-                typedef float ntl_f4 __attribute__((ext_vector_type(4)));
-                const ntl_f4 t = __builtin_nontemporal_load((const ntl_f4*)xr + lane + i * 64);
-                v[i] = make_float4(t.x, t.y, t.z, t.w);
-            }
+            // x and the branch outputs are dead once this kernel has read them: streaming loads (common.h)
+            v[i] = ld_stream_f4((const float*)(xr + lane + i * 64));
             if (delta) {
-                typedef unsigned ntl_u2 __attribute__((ext_vector_type(2)));
-                const ntl_u2 ut = __builtin_nontemporal_load((const ntl_u2*)(delta + row * D) + lane + i * 64);
-                const uint2 u = make_uint2(ut.x, ut.y);
+                const uint2 u = ld_stream_u2((const uint2*)(delta + row * D) + lane + i * 64);
                 v[i].x += bf2f(u.x & 0xffff); v[i].y += bf2f(u.x >> 16); v[i].z += bf2f(u.y & 0xffff); v[i].w += bf2f(u.y >> 16);
                 if (delta2) {                       // (x + delta) + delta2: the two branch outputs of a layer whose first add was not stored
-                    const ntl_u2 ut2 = __builtin_nontemporal_load((const ntl_u2*)(delta2 + row * D) + lane + i * 64);
-                    const uint2 u2 = make_uint2(ut2.x, ut2.y);
+                    const uint2 u2 = ld_stream_u2((const uint2*)(delta2 + row * D) + lane + i * 64);
                     v[i].x += bf2f(u2.x & 0xffff); v[i].y += bf2f(u2.x >> 16); v[i].z += bf2f(u2.y & 0xffff); v[i].w += bf2f(u2.y >> 16);
                 }
-                if (x_out) {
-                    // The sum is not read again before the next LayerNorm (a QKV GEMM, an attention and an out-proj launch later), while h -- written
-                    // by this same kernel -- is the next GEMM's A operand: the streaming store keeps x from pushing h out of the 256 MB Infinity
-                    // Cache (in-model A/B, old / new library alternated: two-stream step -0.35 %, profiles/r02_encoder_streams.md).
-                    typedef float nt_f4 __attribute__((ext_vector_type(4)));
-                    const nt_f4 t = {v[i].x, v[i].y, v[i].z, v[i].w};
-                    __builtin_nontemporal_store(t, (nt_f4*)(x_out + row * D) + lane + i * 64);
-                }
+                // The sum is not read again before the next LayerNorm (a QKV GEMM, an attention and an out-proj launch later), while h -- written
+                // by this same kernel -- is the next GEMM's A operand: streaming store.
+                if (x_out) st_stream_f4(x_out + row * D + 4 * (lane + i * 64), v[i]);
             }
         }
     float mean, rstd;
@@ -149,11 +137,11 @@ __global__ __launch_bounds__(256) void merge_ln_kernel(const float* x, const bf1
 #pragma unroll
     for (int i = 0; i < LN_MAXV; i++)
         if (lane + i * 64 < nvec) {
-            v[i] = xr[lane + i * 64];
+            v[i] = ld_stream_f4((const float*)(xr + lane + i * 64));
             if (delta) {
-                const uint2 u = ((const uint2*)(delta + xrow * D))[lane + i * 64];
+                const uint2 u = ld_stream_u2((const uint2*)(delta + xrow * D) + lane + i * 64);
                 v[i].x += bf2f(u.x & 0xffff); v[i].y += bf2f(u.x >> 16); v[i].z += bf2f(u.y & 0xffff); v[i].w += bf2f(u.y >> 16);
-                ((float4*)(x_out + xrow * D))[lane + i * 64] = v[i];
+                st_stream_f4(x_out + xrow * D + 4 * (lane + i * 64), v[i]);          // (read again by the backward only)
             }
         }
     float mean, rstd;
