@@ -201,7 +201,8 @@ def test_gemm_f32_epilogues_pingpong_matches_tile256_bitwise(N, K, epi):
 def test_encoder_sub_batch_streams_give_the_single_stream_bits(arch, B):
     """The encoder forward runs as two sub-batches on two HIP streams (models.OwlViT.encoder_streams): outputs, losses and the whole
     gradient bucket must be the bits of the single-stream schedule, step after step (kept activations are allocated before the fork;
-    every buffer a sub-batch touches is its own row range)."""
+    every buffer a sub-batch touches is its own row range).  With the streams on, the class head also runs beside the box head (forward; backward
+    where every dW goes through the TN kernel -- the B/16 case here) and the trainable layer's weight gradients beside its dX chain."""
     from owl_vit_object_detection_amd import synth, weights
     from owl_vit_object_detection_amd.config import get_config
     from owl_vit_object_detection_amd.losses import PushPullLoss
