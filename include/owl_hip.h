@@ -174,7 +174,9 @@ int owl_rowreduce_workspace_bytes(int64_t groups, int64_t rows_per_group, int64_
 /* dx_bf16 (optional): bf16 copy of dx, the operand of the next dX GEMM.  dx_colsum (optional, with dgamma / dbeta): += column sums of dx
  * = the bias gradient of the linear layer whose output sits at this residual position (no separate pass over the f32 dx).             */
 int owl_layernorm_bwd(void* stream, const void* dy, int dy_bf16, const float* x, const float* stats, const float* gamma, const float* dres, float* dx, float* dgamma, float* dbeta, int64_t rows, int64_t D, void* dx_bf16, float* partials, int64_t partials_floats, float* dx_colsum);
-int owl_merge_ln_bwd(void* stream, const float* dfeats, const float* x, const float* cls_ln, const float* stats1, const float* stats2, const float* g1, const float* b1, const float* g2, float* dx, float* dcls_ws, float* dg1, float* db1, float* dg2, float* db2, int64_t B, int64_t P, int64_t Tp, int64_t D, float* partials, int64_t partials_floats, void* dx_bf16);
+int owl_merge_ln_bwd(void* stream, const float* dfeats, const float* x, const float* cls_ln, const float* stats1, const float* stats2, const float* g1, const float* b1, const float* g2, float* dx, float* dcls_ws, float* dg1, float* db1, float* dg2, float* db2, int64_t B, int64_t P, int64_t Tp, int64_t D, float* partials, int64_t partials_floats, void* dx_bf16, float* dx_colsum);
+/* (owl_merge_ln_bwd: partials >= 6 D floats per 64-row block and image; dx_colsum (optional): += column sums of dx over every token of the batch,
+ * class-token rows included = the bias gradient of the last encoder layer's fc2)                                                          */
 /* class head backward, row-parallel part: de (bf16 [rows,Dt]), routed upstream G (bf16 [rows,32]) and a bf16 copy of e;
  * dqhat[32,Dt] = G^T e is then a split-K owl_gemm_nt_bf16, and owl_query_normalize_bwd maps it onto dqueries            */
 int owl_class_sims_bwd(void* stream, const float* dsims, const float* sims, const unsigned char* argmax, const float* inv_norm, const float* e, const float* qhat32, void* de_bf16, void* g_bf16, void* e_bf16, int64_t rows, int64_t Dt, int64_t C);

@@ -202,7 +202,8 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
     ops.merge_ln_bwd(bw["dfeats"], ws["x"], ws["cls_ln"], ws["st_post"], ws["st_pp"], P_["backbone.post_layernorm.weight"],
                      P_["backbone.post_layernorm.bias"], P_["post_post_layernorm.weight"], bw["dx"], bw["dcls"],
                      G("backbone.post_layernorm.weight"), G("backbone.post_layernorm.bias"), G("post_post_layernorm.weight"),
-                     G("post_post_layernorm.bias"), B, P, Tp, D, partials=bw["part"], dx_bf16=bw["dxb"])
+                     G("post_post_layernorm.bias"), B, P, Tp, D, partials=bw["part"], dx_bf16=bw["dxb"],
+                     dx_colsum=G(tl + "mlp.fc2.bias") if cfg.trainable_layer() == cfg.layers - 1 else None)     # (dx here = d(output of the last layer))
     scale = cfg.head_dim ** -0.5
     # (bw["dxb"] always holds the bf16 copy of bw["dx"]: every kernel that writes dx writes it too -- no separate cast pass)
     # ---- frozen layers ABOVE the trainable one (literal "layers.11" rule on a deeper model): dX only ----------
@@ -260,7 +261,8 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
             fn()
 
     # MLP
-    ops.colsum_f32(bw["dx"], G(tl + "mlp.fc2.bias"), M, D, partials=bw["part"])
+    if cfg.trainable_layer() != cfg.layers - 1:     # (the last layer's fc2 bias gradient came out of merge_ln_bwd)
+        ops.colsum_f32(bw["dx"], G(tl + "mlp.fc2.bias"), M, D, partials=bw["part"])
     on_side(0, lambda: dW(bw["dxb"], Lt["g"], G(tl + "mlp.fc2.weight"), D, I, M, Mp, part="part2"))
     ops.gemm(ops.EPI_DQGELU_BF16, bw["dxb"], wT(tl + "mlp.fc2.weight", D, I), bw["du"], aux=Lt["u"], M=M, N=I, K=D)
     on_side(1, lambda: dW(bw["du"], Lt["h2"], G(tl + "mlp.fc1.weight"), I, D, M, Mp, G(tl + "mlp.fc1.bias"), part="part2"))

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void merge_ln_bwd_kernel(const float* __restri
     const float4 z4 = make_float4(0, 0, 0, 0);
     float4 ga = z4, be = z4, gb = z4, cv = z4;
     if (ok) { ga = ((const float4*)g1)[t]; be = ((const float4*)b1)[t]; gb = ((const float4*)g2)[t]; cv = ((const float4*)(cls_ln + b * D))[t]; }
-    float4 a_c = z4, a_g1 = z4, a_b1 = z4, a_g2 = z4, a_b2 = z4;
+    float4 a_c = z4, a_g1 = z4, a_b1 = z4, a_g2 = z4, a_b2 = z4, a_dx = z4;      // (a_dx: column sums of dx = the bias gradient of the last fc2)
     const float invD = 1.0f / (float)D;
     const int64_t p_begin = (int64_t)blockIdx.x * rows_per_block, p_end = min(P, p_begin + rows_per_block);
     // the NEXT MLR rows are requested before these are worked on: a workgroup's loads stay in flight through its compute and barrier phases
@@ -265,17 +265,18 @@ __global__ __launch_bounds__(256) void merge_ln_bwd_kernel(const float* __restri
             const float4 o = make_float4(r1[r] * (gz[r].x - n1 - xh[r].x * n2), r1[r] * (gz[r].y - n1 - xh[r].y * n2),
                                          r1[r] * (gz[r].z - n1 - xh[r].z * n2), r1[r] * (gz[r].w - n1 - xh[r].w * n2));
             st_stream_f4(dx + xrow * D + 4 * t, o);
+            a_dx.x += o.x; a_dx.y += o.y; a_dx.z += o.z; a_dx.w += o.w;
             if (dx_bf16) {                              // the bf16 copy the first dX GEMM reads (saves a separate cast pass)
                 uint2 ob; ob.x = pack_bf2(o.x, o.y); ob.y = pack_bf2(o.z, o.w);
                 ((uint2*)(dx_bf16 + xrow * D))[t] = ob;
             }
         }
     }
-    // this workgroup's slab part[b][blockIdx.x][{dcls, dg1, db1, dg2, db2}][D]: every thread owns its columns
+    // this workgroup's slab part[b][blockIdx.x][{dcls, dg1, db1, dg2, db2, sum dx}][D]: every thread owns its columns
     if (ok) {
-        float* mine = part + ((int64_t)b * gridDim.x + blockIdx.x) * 5 * D;
+        float* mine = part + ((int64_t)b * gridDim.x + blockIdx.x) * 6 * D;
         ((float4*)mine)[t] = a_c; ((float4*)(mine + D))[t] = a_g1; ((float4*)(mine + 2 * D))[t] = a_b1;
-        ((float4*)(mine + 3 * D))[t] = a_g2; ((float4*)(mine + 4 * D))[t] = a_b2;
+        ((float4*)(mine + 3 * D))[t] = a_g2; ((float4*)(mine + 4 * D))[t] = a_b2; ((float4*)(mine + 5 * D))[t] = a_dx;
     }
 }
 
@@ -298,9 +299,9 @@ __global__ __launch_bounds__(64) void cls_ln_bwd_kernel(const float* __restrict_
             gd[i] = make_float4(dy.x * g.x, dy.y * g.y, dy.z * g.z, dy.w * g.w);
             s1 += gd[i].x + gd[i].y + gd[i].z + gd[i].w;
             s2 += gd[i].x * xh[i].x + gd[i].y * xh[i].y + gd[i].z * xh[i].z + gd[i].w * xh[i].w;
-            // this image's contribution to (dg1, db1): part[b][{dg1, db1}][D], reduced in image order afterwards
-            ((float4*)(part + b * 2 * D))[idx] = make_float4(dy.x * xh[i].x, dy.y * xh[i].y, dy.z * xh[i].z, dy.w * xh[i].w);
-            ((float4*)(part + b * 2 * D + D))[idx] = dy;
+            // this image's contribution to (dg1, db1) (and, below, its dx row): part[b][{dg1, db1, dx}][D], reduced in image order afterwards
+            ((float4*)(part + b * 3 * D))[idx] = make_float4(dy.x * xh[i].x, dy.y * xh[i].y, dy.z * xh[i].z, dy.w * xh[i].w);
+            ((float4*)(part + b * 3 * D + D))[idx] = dy;
         }
     }
     s1 = wave_sum(s1) / (float)D; s2 = wave_sum(s2) / (float)D;
@@ -311,6 +312,7 @@ __global__ __launch_bounds__(64) void cls_ln_bwd_kernel(const float* __restrict_
             const float4 o = make_float4(st.y * (gd[i].x - s1 - xh[i].x * s2), st.y * (gd[i].y - s1 - xh[i].y * s2),
                                          st.y * (gd[i].z - s1 - xh[i].z * s2), st.y * (gd[i].w - s1 - xh[i].w * s2));
             ((float4*)(dx + row * D))[idx] = o;
+            ((float4*)(part + b * 3 * D + 2 * D))[idx] = o;
             if (dx_bf16) {
                 uint2 ob; ob.x = pack_bf2(o.x, o.y); ob.y = pack_bf2(o.z, o.w);
                 ((uint2*)(dx_bf16 + row * D))[idx] = ob;
@@ -322,28 +324,29 @@ __global__ __launch_bounds__(64) void cls_ln_bwd_kernel(const float* __restrict_
 extern "C" int owl_merge_ln_bwd(void* stream, const float* dfeats, const float* x, const float* cls_ln, const float* stats1,
                                 const float* stats2, const float* g1, const float* b1, const float* g2, float* dx, float* dcls_ws,
                                 float* dg1, float* db1, float* dg2, float* db2, int64_t B, int64_t P, int64_t Tp, int64_t D,
-                                float* partials, int64_t partials_floats, void* dx_bf16) {
+                                float* partials, int64_t partials_floats, void* dx_bf16, float* dx_colsum) {
     OWL_CHECK_ARG(dfeats && x && cls_ln && stats1 && stats2 && g1 && b1 && g2 && dx && dcls_ws && dg1 && db1 && dg2 && db2 && partials, "owl_merge_ln_bwd: null pointer");
     OWL_CHECK_ARG(D % 4 == 0 && D <= 256 * LN_MAXV, "owl_merge_ln_bwd: D must be a multiple of 4 and <= 1024");
     hipStream_t s = (hipStream_t)stream;
     const int rpb = 64;
     const int nbx = (int)((P + rpb - 1) / rpb);
-    OWL_CHECK_ARG(partials_floats >= B * nbx * 5 * D, "owl_merge_ln_bwd: needs %lld floats of partial-sum scratch (owl_rowreduce_workspace_bytes)", (long long)(B * nbx * 5 * D));
+    OWL_CHECK_ARG(partials_floats >= B * nbx * 6 * D, "owl_merge_ln_bwd: needs %lld floats of partial-sum scratch (6 D per 64-row block)", (long long)(B * nbx * 6 * D));
     hipLaunchKernelGGL(merge_ln_bwd_kernel, dim3((unsigned)nbx, (unsigned)B), dim3(256), 0, s, dfeats, x, cls_ln,
                        (const float2*)stats1, (const float2*)stats2, g1, b1, g2, dx, partials, P, Tp, (int)D, rpb, (bf16_t*)dx_bf16);
     OWL_LAUNCH_CHECK();
-    // d(cls_ln)[b] = sum over the image's row blocks (per-image groups); the four LN parameter gradients += sum over all slabs
+    // d(cls_ln)[b] = sum over the image's row blocks (per-image groups); the four LN parameter gradients (and, on request, the column sums of
+    // dx: the bias gradient of the linear layer that produced this residual position) += sum over all slabs
     ReduceOuts oc{}; oc.o[0] = dcls_ws;
-    int rc = partials_reduce(s, partials, oc, 1, (int)D, 5 * D, nbx, (int)B, (int64_t)nbx * 5 * D, D, 0);
+    int rc = partials_reduce(s, partials, oc, 1, (int)D, 6 * D, nbx, (int)B, (int64_t)nbx * 6 * D, D, 0);
     if (rc) return rc;
-    ReduceOuts op{}; op.o[0] = dg1; op.o[1] = db1; op.o[2] = dg2; op.o[3] = db2;
-    rc = partials_reduce(s, partials + D, op, 4, (int)D, 5 * D, (int)(B * nbx), 1, 0, 0, 1);
+    ReduceOuts op{}; op.o[0] = dg1; op.o[1] = db1; op.o[2] = dg2; op.o[3] = db2; op.o[4] = dx_colsum;
+    rc = partials_reduce(s, partials + D, op, dx_colsum ? 5 : 4, (int)D, 6 * D, (int)(B * nbx), 1, 0, 0, 1);
     if (rc) return rc;
-    // class-token rows: the slabs above have been consumed (stream order), so the scratch is reused for part[b][{dg1, db1}][D]
+    // class-token rows: the slabs above have been consumed (stream order), so the scratch is reused for part[b][{dg1, db1, dx}][D]
     hipLaunchKernelGGL(cls_ln_bwd_kernel, dim3((unsigned)B), dim3(64), 0, s, dcls_ws, x, (const float2*)stats1, g1, dx, partials, Tp, (int)D, (bf16_t*)dx_bf16);
     OWL_LAUNCH_CHECK();
-    ReduceOuts o2{}; o2.o[0] = dg1; o2.o[1] = db1;
-    return partials_reduce(s, partials, o2, 2, (int)D, 2 * D, (int)B, 1, 0, 0, 1);
+    ReduceOuts o2{}; o2.o[0] = dg1; o2.o[1] = db1; o2.o[2] = dx_colsum;
+    return partials_reduce(s, partials, o2, dx_colsum ? 3 : 2, (int)D, 3 * D, (int)B, 1, 0, 0, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------

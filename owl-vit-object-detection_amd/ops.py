@@ -144,7 +144,7 @@ def _part(partials, rows, C, device):
     """The caller's scratch, or (stand-alone use: tests, tools) a cached per-device buffer grown on demand."""
     if partials is not None:
         return partials
-    need = ((int(rows) + 63) // 64 + 1) * 5 * max(int(C), 4)
+    need = ((int(rows) + 63) // 64 + 1) * 6 * max(int(C), 4)
     buf = _partials.get(device)
     if buf is None or buf.numel() < need:
         buf = torch.empty(need, dtype=torch.float32, device=device)
@@ -161,11 +161,12 @@ def layernorm_bwd(dy, x, stats, gamma, dres, dx, dgamma, dbeta, rows, D, dx_bf16
               dgamma, dbeta, rows, D, dx_bf16, part, part.numel() if part is not None else 0, dx_colsum)
 
 
-def merge_ln_bwd(dfeats, x, cls_ln, st1, st2, g1, b1, g2, dx, dcls_ws, dg1, db1, dg2, db2, B, P, Tp, D, partials=None, dx_bf16=None):
+def merge_ln_bwd(dfeats, x, cls_ln, st1, st2, g1, b1, g2, dx, dcls_ws, dg1, db1, dg2, db2, B, P, Tp, D, partials=None, dx_bf16=None, dx_colsum=None):
+    """dx_colsum (optional): += column sums of dx over all tokens (the bias gradient of the last layer's fc2) in the same pass."""
     part = partials if partials is not None else _part(None, B * ((P + 63) // 64) * 64, D, x.device)
-    _chk(dx_bf16, torch.bfloat16, "dx_bf16")
+    _chk(dx_bf16, torch.bfloat16, "dx_bf16"); _chk(dx_colsum, torch.float32, "dx_colsum")
     _lib.call("owl_merge_ln_bwd", stream(), dfeats, x, cls_ln, st1, st2, g1, b1, g2, dx, dcls_ws, dg1, db1, dg2, db2, B, P, Tp, D,
-              part, part.numel(), dx_bf16)
+              part, part.numel(), dx_bf16, dx_colsum)
 
 
 def class_sims_bwd(dsims, sims, argmax, inv_norm, e, qhat32, de, g32, e_bf16, rows, Dt, C):

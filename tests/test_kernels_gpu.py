@@ -201,15 +201,19 @@ def test_merge_ln_bwd_matches_torch_autograd(B, P, D):
     F.layer_norm(y[:, 1:] * y[:, :1], (D,), G2, B2, 1e-5).backward(dfeats.view(B, P, D))
     dx = torch.zeros(B * Tp, D, device=DEV); dxb = torch.zeros(B * Tp, D, device=DEV, dtype=torch.bfloat16); dcls = torch.zeros(B, D, device=DEV)
     grads = [torch.ones(D, device=DEV) for _ in range(4)]              # accumulated onto (the bucket is not zero in general)
-    ops.merge_ln_bwd(dfeats, x, cls_ln, s1, s2, g1, b1, g2, dx, dcls, *grads, B, P, Tp, D, dx_bf16=dxb)
+    colsum = torch.ones(D, device=DEV)                                 # += column sums of dx over every token (the last fc2's bias gradient)
+    ops.merge_ln_bwd(dfeats, x, cls_ln, s1, s2, g1, b1, g2, dx, dcls, *grads, B, P, Tp, D, dx_bf16=dxb, dx_colsum=colsum)
     scale = float(xr.grad.abs().max())
+    ref_cs = xr.grad.sum((0, 1))
+    report("dx column sums", colsum - 1.0, ref_cs, 1e-4 * float(ref_cs.abs().max()) + 2e-5 * scale * (B * T) ** 0.5, 1e-4)
     report("dx", dx.view(B, Tp, D)[:, :T], xr.grad, 2e-5 * scale, 1e-4)
     assert torch.equal(dxb.view(B, Tp, D)[:, :T], dx.view(B, Tp, D)[:, :T].bfloat16())
     for name, got, ref in zip(("dg1", "db1", "dg2", "db2"), grads, (G1.grad, B1.grad, G2.grad, B2.grad)):
         report(name, got - 1.0, ref, 1e-4 * float(ref.abs().max()) + 1e-5, 1e-4)
     dx2 = torch.zeros_like(dx); grads2 = [torch.ones(D, device=DEV) for _ in range(4)]
-    ops.merge_ln_bwd(dfeats, x, cls_ln, s1, s2, g1, b1, g2, dx2, dcls, *grads2, B, P, Tp, D, dx_bf16=dxb)
-    assert torch.equal(dx, dx2) and all(torch.equal(a, b) for a, b in zip(grads, grads2))      # fixed-order sums
+    colsum2 = torch.ones(D, device=DEV)
+    ops.merge_ln_bwd(dfeats, x, cls_ln, s1, s2, g1, b1, g2, dx2, dcls, *grads2, B, P, Tp, D, dx_bf16=dxb, dx_colsum=colsum2)
+    assert torch.equal(dx, dx2) and torch.equal(colsum, colsum2) and all(torch.equal(a, b) for a, b in zip(grads, grads2))      # fixed-order sums
 
 
 def _attn_case(B, H, T, seed):
