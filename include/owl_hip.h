@@ -181,9 +181,10 @@ int owl_merge_ln_bwd(void* stream, const float* dfeats, const float* x, const fl
  * dqhat[32,Dt] = G^T e is then a split-K owl_gemm_nt_bf16, and owl_query_normalize_bwd maps it onto dqueries            */
 int owl_class_sims_bwd(void* stream, const float* dsims, const float* sims, const unsigned char* argmax, const float* inv_norm, const float* e, const float* qhat32, void* de_bf16, void* g_bf16, void* e_bf16, int64_t rows, int64_t Dt, int64_t C);
 int owl_query_normalize_bwd(void* stream, const float* dqhat, const float* queries, float* dqueries, int64_t nq, int64_t Dt);
-/* dw2 [4,D] and db2 [4] must be contiguous (dw2 then db2); partials = f32 [owl_box_final_bwd_blocks(rows)][4*D+4] */
+/* dw2 [4,D] and db2 [4] must be contiguous (dw2 then db2); partials = f32 [owl_box_final_bwd_blocks(rows)][5*D+4];
+ * du1_colsum (optional, [D]): += column sums of du1 = dense1's bias gradient, from the same pass */
 int owl_box_final_bwd_blocks(int64_t rows);
-int owl_box_final_bwd(void* stream, const float* dboxes, const float* sig, const void* h1_bf16, const void* u1_bf16, const float* w2, void* du1_bf16, float* partials, float* dw2_db2, int64_t rows, int64_t D);
+int owl_box_final_bwd(void* stream, const float* dboxes, const float* sig, const void* h1_bf16, const void* u1_bf16, const float* w2, void* du1_bf16, float* partials, float* dw2_db2, int64_t rows, int64_t D, float* du1_colsum);
 int owl_transpose_colsum_bf16(void* stream, const void* in, int64_t ld_in, void* out_t, int64_t ld_out, float* colsum, int64_t R, int64_t C, float* partials, int64_t partials_floats);
 int owl_colsum_f32(void* stream, const float* in, float* colsum, int64_t R, int64_t C, float* partials, int64_t partials_floats);
 

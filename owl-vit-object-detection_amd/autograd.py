@@ -78,7 +78,7 @@ def _bws(model, B):
     ws = dict(
         de=z(Mh, Dt, bf, dev), dqhat=torch.zeros(32, Dt, device=dev), du1=z(Mh, D, bf, dev), du0=z(Mh, D, bf, dev),
         g32=z(Mh, 32, bf, dev), e_bf=z(Mh, Dt, bf, dev),
-        box_part=torch.zeros(_lib.load().owl_box_final_bwd_blocks(Mh), 4 * D + 4, device=dev),
+        box_part=torch.zeros(_lib.load().owl_box_final_bwd_blocks(Mh), 5 * D + 4, device=dev),
         slab=torch.zeros(_slab_elems(cfg), device=dev),
         dfeats=z(Mh, D, f32, dev), dcls=torch.zeros(B, D, device=dev),
         dx=z(M, D, f32, dev), dxb=z(M, D, bf, dev), du=z(M, I, bf, dev), dh=z(M, D, bf, dev), dxm=z(M, D, f32, dev),
@@ -190,8 +190,9 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
     # ---- box head -------------------------------------------------------------------------------------
     gw2, gb2 = G("box_head.dense2.weight"), G("box_head.dense2.bias")
     assert gb2.data_ptr() == gw2.data_ptr() + 4 * gw2.numel(), "dense2 weight/bias grads must be adjacent in the flat bucket"
-    ops.box_final_bwd(d_boxes, ws["sig"], ws["hb1"], ws["ub1"], P_["box_head.dense2.weight"], bw["du1"], bw["box_part"], gw2, Mh, D)
-    dW(bw["du1"], ws["hb0"], G("box_head.dense1.weight"), D, D, Mh, Mhp, G("box_head.dense1.bias"))
+    ops.box_final_bwd(d_boxes, ws["sig"], ws["hb1"], ws["ub1"], P_["box_head.dense2.weight"], bw["du1"], bw["box_part"], gw2, Mh, D,
+                      du1_colsum=G("box_head.dense1.bias"))          # (dense1's bias gradient from the same pass: no column-sum launch over du1)
+    dW(bw["du1"], ws["hb0"], G("box_head.dense1.weight"), D, D, Mh, Mhp, None)
     ops.gemm(ops.EPI_DGELU_BF16, bw["du1"], wT("box_head.dense1.weight", D, D), bw["du0"], aux=ws["ub0"], M=Mh, N=D, K=D)
     dW(bw["du0"], ws["feats"], G("box_head.dense0.weight"), D, D, Mh, Mhp, G("box_head.dense0.bias"))
     w0T = wT("box_head.dense0.weight", D, D)

@@ -485,6 +485,7 @@ __global__ __launch_bounds__(256) void box_final_bwd_kernel(const float* __restr
 #pragma unroll
         for (int k = 0; k < 4; k++) wk[k] = *(const float4*)(w2 + (int64_t)k * D + col);
     }
+    float accu[4] = {0.f, 0.f, 0.f, 0.f};     // column sums of du1 (f32, before the bf16 rounding): dense1's bias gradient
     float4 accb = make_float4(0, 0, 0, 0);
     for (int64_t r0 = r_begin; r0 < r_end; r0 += 256) {
         const int64_t r = r0 + t;
@@ -528,6 +529,7 @@ __global__ __launch_bounds__(256) void box_final_bwd_kernel(const float* __restr
                     for (int c = 0; c < 4; c++) {
                         const float dh1 = d.x * w0[c] + d.y * w1[c] + d.z * w2r[c] + d.w * w3[c];
                         o[c] = dh1 * dgelu_erf_f(uv[c]);
+                        accu[c] += o[c];
                         accw[0][c] += d.x * hv[c]; accw[1][c] += d.y * hv[c]; accw[2][c] += d.z * hv[c]; accw[3][c] += d.w * hv[c];
                     }
                     uint2 ov; ov.x = pack_bf2(o[0], o[1]); ov.y = pack_bf2(o[2], o[3]);
@@ -536,11 +538,12 @@ __global__ __launch_bounds__(256) void box_final_bwd_kernel(const float* __restr
             }
         }
     }
-    // per-workgroup partials [nblk][4*D + 4] (reduced deterministically by owl_slab_reduce)
-    float* mypart = part + (int64_t)blockIdx.x * (4 * D + 4);
+    // per-workgroup partials [nblk][{dW2 (4 D), db2 (4), sum du1 (D)}] (reduced deterministically by owl_slab_reduce)
+    float* mypart = part + (int64_t)blockIdx.x * (5 * D + 4);
     if (col_ok) {
 #pragma unroll
         for (int k = 0; k < 4; k++) *(float4*)(mypart + (int64_t)k * D + col) = make_float4(accw[k][0], accw[k][1], accw[k][2], accw[k][3]);
+        *(float4*)(mypart + 4 * D + 4 + col) = make_float4(accu[0], accu[1], accu[2], accu[3]);
     }
     __shared__ float4 redb[4];
     accb.x = wave_sum(accb.x); accb.y = wave_sum(accb.y); accb.z = wave_sum(accb.z); accb.w = wave_sum(accb.w);
@@ -552,8 +555,9 @@ __global__ __launch_bounds__(256) void box_final_bwd_kernel(const float* __restr
     }
 }
 
-// partials: f32 workspace [owl_box_final_bwd_blocks(rows)][4*D + 4]; dw2 [4,D] and db2 [4] must be CONTIGUOUS
-// (dw2 followed by db2, as in the flat gradient bucket) -- they are accumulated by one deterministic reduce.
+// partials: f32 workspace [owl_box_final_bwd_blocks(rows)][5*D + 4]; dw2 [4,D] and db2 [4] must be CONTIGUOUS
+// (dw2 followed by db2, as in the flat gradient bucket) -- they are accumulated by one deterministic reduce.  du1_colsum (optional, [D]):
+// += column sums of du1 (dense1's bias gradient) from the same pass.
 // rows per workgroup: 64 at large batch, down to 8 when that would leave most CUs idle (batch 1: 2304 rows)
 static int box_bwd_rpb(int64_t rows) {
     int64_t r = (rows + 511) / 512;
@@ -562,7 +566,7 @@ static int box_bwd_rpb(int64_t rows) {
 extern "C" int owl_box_final_bwd_blocks(int64_t rows) { const int rpb = box_bwd_rpb(rows); return (int)((rows + rpb - 1) / rpb); }
 
 extern "C" int owl_box_final_bwd(void* stream, const float* dboxes, const float* sig, const void* h1_bf16, const void* u1_bf16,
-                                 const float* w2, void* du1_bf16, float* partials, float* dw2_db2, int64_t rows, int64_t D) {
+                                 const float* w2, void* du1_bf16, float* partials, float* dw2_db2, int64_t rows, int64_t D, float* du1_colsum) {
     OWL_CHECK_ARG(dboxes && sig && h1_bf16 && u1_bf16 && w2 && du1_bf16 && partials && dw2_db2, "owl_box_final_bwd: null pointer");
     OWL_CHECK_ARG(D <= 1024 && D % 4 == 0, "owl_box_final_bwd: D <= 1024, D %% 4");
     const int rpb = box_bwd_rpb(rows);
@@ -571,7 +575,9 @@ extern "C" int owl_box_final_bwd(void* stream, const float* dboxes, const float*
     hipLaunchKernelGGL(box_final_bwd_kernel, dim3((unsigned)nblk), dim3(256), 0, s, dboxes, sig, (const bf16_t*)h1_bf16,
                        (const bf16_t*)u1_bf16, w2, (bf16_t*)du1_bf16, partials, rows, (int)D, rpb);
     OWL_LAUNCH_CHECK();
-    return owl_slab_reduce_impl(s, partials, dw2_db2, 4 * D + 4, 4 * D + 4, nblk, 1);
+    int rc = owl_slab_reduce_impl(s, partials, dw2_db2, 4 * D + 4, 5 * D + 4, nblk, 1);
+    if (rc || !du1_colsum) return rc;
+    return owl_slab_reduce_impl(s, partials + 4 * D + 4, du1_colsum, D, 5 * D + 4, nblk, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------

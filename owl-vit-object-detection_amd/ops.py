@@ -173,8 +173,12 @@ def class_sims_bwd(dsims, sims, argmax, inv_norm, e, qhat32, de, g32, e_bf16, ro
     _lib.call("owl_class_sims_bwd", stream(), dsims, sims, argmax, inv_norm, e, qhat32, de, g32, e_bf16, rows, Dt, C)
 
 
-def box_final_bwd(dboxes, sig, h1, u1, w2, du1, partials, dw2_db2, rows, D):
-    _lib.call("owl_box_final_bwd", stream(), dboxes, sig, h1, u1, w2, du1, partials, dw2_db2, rows, D)
+def box_final_bwd(dboxes, sig, h1, u1, w2, du1, partials, dw2_db2, rows, D, du1_colsum=None):
+    """partials: f32 [owl_box_final_bwd_blocks(rows), 5 * D + 4]; du1_colsum (optional): += column sums of du1 (dense1's bias gradient)."""
+    if partials.numel() < _lib.load().owl_box_final_bwd_blocks(int(rows)) * (5 * int(D) + 4):
+        raise ValueError("box_final_bwd: partials must hold owl_box_final_bwd_blocks(rows) x (5 D + 4) floats")
+    _chk(du1_colsum, torch.float32, "du1_colsum")
+    _lib.call("owl_box_final_bwd", stream(), dboxes, sig, h1, u1, w2, du1, partials, dw2_db2, rows, D, du1_colsum)
 
 
 def transpose_colsum(src, dst, colsum, R, C, ld_in=None, ld_out=None, partials=None):

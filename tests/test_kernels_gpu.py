@@ -314,15 +314,18 @@ def test_box_final_bwd_matches_torch_autograd(rows, D):
     sig = s.detach().contiguous()
     du1 = torch.zeros(rows, D, device=DEV, dtype=torch.bfloat16)
     nblk = _lib.load().owl_box_final_bwd_blocks(rows)
-    part = torch.zeros(nblk, 4 * D + 4, device=DEV)
+    part = torch.zeros(nblk, 5 * D + 4, device=DEV)
     g = torch.ones(4 * D + 4, device=DEV)                    # dW2 followed by db2, as in the flat bucket; accumulated onto
-    ops.box_final_bwd(dboxes, sig, h1, u1, w2, du1, part, g, rows, D)
+    cs = torch.ones(D, device=DEV)                           # += column sums of du1 (dense1's bias gradient)
+    ops.box_final_bwd(dboxes, sig, h1, u1, w2, du1, part, g, rows, D, du1_colsum=cs)
     report("du1", du1.float(), u.grad, 1e-3, 4e-3)
     report("dW2", g[:4 * D].view(4, D) - 1.0, W.grad, 1e-2 * float(W.grad.abs().max()), 1e-3)
     report("db2", g[4 * D:] - 1.0, bb.grad, 1e-3 * max(1.0, float(bb.grad.abs().max())), 1e-3)
-    g2 = torch.ones(4 * D + 4, device=DEV); du2 = torch.zeros_like(du1)
-    ops.box_final_bwd(dboxes, sig, h1, u1, w2, du2, part, g2, rows, D)
-    assert torch.equal(du1, du2) and torch.equal(g, g2)     # fixed-order partial sums
+    ref_cs = u.grad.sum(0)
+    report("du1 column sums", cs - 1.0, ref_cs, 1e-3 * float(ref_cs.abs().max()) + 1e-4, 1e-3)
+    g2 = torch.ones(4 * D + 4, device=DEV); du2 = torch.zeros_like(du1); cs2 = torch.ones(D, device=DEV)
+    ops.box_final_bwd(dboxes, sig, h1, u1, w2, du2, part, g2, rows, D, du1_colsum=cs2)
+    assert torch.equal(du1, du2) and torch.equal(g, g2) and torch.equal(cs, cs2)     # fixed-order partial sums
 
 
 def test_cast_and_transpose():

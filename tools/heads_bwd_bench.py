@@ -8,7 +8,7 @@ g = torch.Generator(device="cuda").manual_seed(0)
 u1 = torch.randn(rows, D, device="cuda", generator=g).bfloat16(); h1 = torch.nn.functional.gelu(u1.float()).bfloat16()
 w2 = torch.randn(4, D, device="cuda", generator=g) * 0.1; sig = torch.rand(rows, 4, device="cuda", generator=g); db = torch.randn(rows, 4, device="cuda", generator=g)
 du1 = torch.zeros(rows, D, device="cuda", dtype=torch.bfloat16)
-part = torch.zeros(_lib.load().owl_box_final_bwd_blocks(rows), 4 * D + 4, device="cuda"); gr = torch.zeros(4 * D + 4, device="cuda")
+part = torch.zeros(_lib.load().owl_box_final_bwd_blocks(rows), 5 * D + 4, device="cuda"); gr = torch.zeros(4 * D + 4, device="cuda")
 for _ in range(5): ops.box_final_bwd(db, sig, h1, u1, w2, du1, part, gr, rows, D)
 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
 for _ in range(50): ops.box_final_bwd(db, sig, h1, u1, w2, du1, part, gr, rows, D)
