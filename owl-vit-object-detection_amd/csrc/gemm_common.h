@@ -34,7 +34,7 @@ struct GemmP {
     int ps_log2;
     const float* pos;      // [T, N]
     int64_t slab_stride;   // EPI_SLAB: elements per split slab
-    int dbg;               // tuning experiments only: bit 1 = stores wrapped into a cache-resident window, bit 2 = non-temporal bf16 stores
+    int dbg;               // read by the kernels of an OWL_TUNING build only: bit 1 = stores wrapped into a cache-resident window, bit 2 = non-temporal bf16 stores
 };
 
 __device__ __forceinline__ float sigmoid1702_f(float u) {   // 1 / (1 + exp(-1.702 u)) with v_exp / v_rcp
@@ -334,11 +334,15 @@ __device__ __forceinline__ void epi_store_chunk(const GemmP& p, const uint4& ch,
     } else {
         int64_t m = m_tile + (lane & 31), n = n_tile + 16 * c + 8 * hi;
         if (GUARD && (m >= p.M || n >= p.N)) return;
+#ifdef OWL_TUNING        // (tuning build only: stores wrapped into a cache-resident window)
         if (p.dbg & 2) { m = (int64_t)(blockIdx.x & 255) * 256 + (m & 255); n &= 255; }
+#endif
         typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
         u32x4_t* dst = (u32x4_t*)((bf16_t*)p.out + m * p.ldo + n);
         const u32x4_t val = {ch.x, ch.y, ch.z, ch.w};
-        if (p.dbg & 4) __builtin_nontemporal_store(val, dst);
-        else *dst = val;
+#ifdef OWL_TUNING        // (tuning build only: non-temporal output stores -- measured neutral, profiles/r02_gemm_two_phase.md)
+        if (p.dbg & 4) { __builtin_nontemporal_store(val, dst); return; }
+#endif
+        *dst = val;
     }
 }
