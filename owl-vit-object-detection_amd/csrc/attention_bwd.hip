@@ -448,12 +448,11 @@ extern "C" int owl_attention_bwd_bf16(void* stream, const void* qkv, const void*
     p.B = (int)B; p.T = (int)T; p.Tp = (int)Tp; p.H = (int)H;
     p.scale = scale; p.scale_log2e = scale * 1.4426950408889634f;
     hipStream_t s = (hipStream_t)stream;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned long long attr_done = 0;
+    OWL_ONCE_PER_DEVICE(attr_done, {
         (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BWD1_STAGE);
         (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BWD2_STAGE);
-        attr_done = true;
-    }
+    });
     const int64_t nd = B * Tp * (H * 8);                       // one thread per 16-byte chunk
     hipLaunchKernelGGL(attn_dvec_kernel, dim3((unsigned)((nd + 255) / 256), 1, 1), dim3(256), 0, s, p);
     OWL_LAUNCH_CHECK();

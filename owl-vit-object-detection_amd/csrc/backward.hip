@@ -440,8 +440,8 @@ extern "C" int owl_class_sims_bwd(void* stream, const float* dsims, const float*
     OWL_CHECK_ARG(3 * C <= 32 && Dt % 4 == 0, "owl_class_sims_bwd: 3*C <= 32, Dt %% 4");
     const size_t shmem = (size_t)32 * Dt * sizeof(float);
     OWL_CHECK_ARG(shmem <= 150 * 1024, "owl_class_sims_bwd: Dt too large for LDS");
-    static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute((const void*)class_sims_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_done = true; }
+    static unsigned long long attr_done = 0;
+    OWL_ONCE_PER_DEVICE(attr_done, (void)hipFuncSetAttribute((const void*)class_sims_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     int rpw = (int)((rows + 8 * 512 - 1) / (8 * 512));           // aim at >= 512 workgroups ...
     rpw = rpw < 2 ? 2 : (rpw > 18 ? 18 : rpw);                   // ... with 16..144 rows each
     hipLaunchKernelGGL(class_sims_bwd_kernel, dim3((unsigned)((rows + 8 * rpw - 1) / (8 * rpw))), dim3(512), shmem, (hipStream_t)stream, dsims, sims, argmax,

@@ -26,6 +26,20 @@ __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));   // ONE v_cvt_pk_bf16_f32
 }
 
+// Host side: run a statement once per (call site, device) -- the hipFuncSetAttribute calls that raise a kernel's dynamic-LDS limit.  The limit is a
+// per-device property of the function: a process that drives several GPUs (not this repo's one-process-per-GPU launchers, but a caller of the C ABI
+// may) has to raise it on each.  The device's bit is set AFTER the statement, so a second thread never launches ahead of the attribute.
+#define OWL_ONCE_PER_DEVICE(mask, ...)                                                                   \
+    do {                                                                                                 \
+        int owl_dev_ = 0;                                                                                \
+        (void)hipGetDevice(&owl_dev_);                                                                   \
+        const unsigned long long owl_bit_ = 1ull << (owl_dev_ & 63);                                     \
+        if (!(__atomic_load_n(&(mask), __ATOMIC_ACQUIRE) & owl_bit_)) {                                  \
+            __VA_ARGS__;                                                                                 \
+            __atomic_fetch_or(&(mask), owl_bit_, __ATOMIC_RELEASE);                                      \
+        }                                                                                                \
+    } while (0)
+
 // Streaming (non-temporal) accesses for data that is dead once read, or not read again soon once written: such rows then do not age out what
 // the neighbouring GEMMs re-read through the L2 / Infinity Cache (profiles/r02_encoder_streams.md: the add + LayerNorm kernel alone was worth
 // 1.3 % of the train step and 2.5 % of every GEMM launch).

@@ -279,11 +279,10 @@ template <int EPI, int BM, int BN, int WM, int WN>
 static int launch_cfg(hipStream_t s, GemmP p, int splits) {
     constexpr int threads = (BM / WM) * (BN / WN) * 64;
     constexpr int lds_bytes = 2 * (BM + BN) * BK * 2 + 2 * BN * 4;   // 2 stages + 2 bias slices
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned long long attr_done = 0;
+    OWL_ONCE_PER_DEVICE(attr_done, {
         (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        attr_done = true;
-    }
+    });
     p.tiles_m = (int)((p.M + BM - 1) / BM); p.tiles_n = (int)((p.N + BN - 1) / BN);
     p.nsplit = splits;
     if (g_debug_nostore == 1) p.M = 0;

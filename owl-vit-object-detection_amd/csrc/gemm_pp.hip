@@ -337,11 +337,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
 
 template <int EPI>
 static int launch_pp(hipStream_t s, GemmP p, int slots_override, int persistent_on, int nostore) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned long long attr_done = 0;
+    OWL_ONCE_PER_DEVICE(attr_done, {
         (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
-        attr_done = true;
-    }
+    });
     p.tiles_m = (int)((p.M + PBM - 1) / PBM); p.tiles_n = (int)((p.N + PBN - 1) / PBN);
     p.nsplit = 1;
     if (nostore == 1) p.M = 0;

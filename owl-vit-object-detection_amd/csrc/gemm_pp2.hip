@@ -274,11 +274,10 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
 
 template <int EPI>
 static int launch_pp2(hipStream_t s, GemmP p) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned long long attr_done = 0;
+    OWL_ONCE_PER_DEVICE(attr_done, {
         (void)hipFuncSetAttribute((const void*)gemm_pp2_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
-        attr_done = true;
-    }
+    });
     p.tiles_m = (int)((p.M + QBM - 1) / QBM); p.tiles_n = (int)((p.N + QBN - 1) / QBN);
     p.dbg = 0;
     // column-block width of the tile order (see `decode`): the largest divisor of tiles_n up to 4 for the forward epilogues (same-process A/B at

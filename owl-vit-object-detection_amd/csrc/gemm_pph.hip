@@ -191,11 +191,10 @@ __global__ __launch_bounds__(512) void gemm_pph_kernel(GemmP p) {
 
 template <int EPI>
 static int launch_pph(hipStream_t s, GemmP p) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned long long attr_done = 0;
+    OWL_ONCE_PER_DEVICE(attr_done, {
         (void)hipFuncSetAttribute((const void*)gemm_pph_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS);
-        attr_done = true;
-    }
+    });
     p.tiles_m = (int)((p.M + HBM - 1) / HBM); p.tiles_n = (int)((p.N + HBN - 1) / HBN);
     p.nsplit = 1; p.persistent = 0; p.dbg = 0;
     const int nitems = p.tiles_m * p.tiles_n;

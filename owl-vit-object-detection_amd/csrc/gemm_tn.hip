@@ -368,19 +368,17 @@ extern "C" int owl_gemm_tn_slab_bf16(void* stream, const void* dY, int64_t ldy, 
     p.kt_per_split = (nk + splits - 1) / splits;
     p.nsplit = (nk + p.kt_per_split - 1) / p.kt_per_split;
     *splits_used = p.nsplit;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned long long attr_done = 0;
+    OWL_ONCE_PER_DEVICE(attr_done, {
         (void)hipFuncSetAttribute((const void*)gemm_tn_slab_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
-        attr_done = true;
-    }
+    });
     OWL_CHECK_ARG(variant == 0 || variant == 1 || variant == 2, "owl_gemm_tn_slab_bf16: variant must be 0 (automatic), 1 (single-phase) or 2 (ping-pong)");
     const int nitems = p.tiles_n * p.tiles_k * p.nsplit;
     if (variant != 1) {
-        static bool attr2_done = false;
-        if (!attr2_done) {
+        static unsigned long long attr2_done = 0;
+        OWL_ONCE_PER_DEVICE(attr2_done, {
             (void)hipFuncSetAttribute((const void*)gemm_tn_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
-            attr2_done = true;
-        }
+        });
         hipLaunchKernelGGL(gemm_tn_pp_kernel, dim3(nitems), dim3(512), T_LDS, (hipStream_t)stream, p);
         OWL_LAUNCH_CHECK();
         return 0;

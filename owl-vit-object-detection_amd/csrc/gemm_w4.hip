@@ -202,11 +202,10 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmP p) {
 
 template <int EPI>
 static int launch_w4(hipStream_t s, GemmP p) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned long long attr_done = 0;
+    OWL_ONCE_PER_DEVICE(attr_done, {
         (void)hipFuncSetAttribute((const void*)gemm_w4_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS);
-        attr_done = true;
-    }
+    });
     p.tiles_m = (int)((p.M + 255) / 256); p.tiles_n = (int)((p.N + 255) / 256);
     p.nsplit = 1; p.dbg = 0;
     const int nitems = p.tiles_m * p.tiles_n;

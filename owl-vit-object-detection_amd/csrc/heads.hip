@@ -100,8 +100,8 @@ extern "C" int owl_class_sims_fwd(void* stream, const float* e, const float* qha
     OWL_CHECK_ARG(e && qhat32 && sims, "owl_class_sims_fwd: null pointer");
     OWL_CHECK_ARG(Dt % 64 == 0 && 3 * C <= 32 && C >= 1, "owl_class_sims_fwd: Dt %% 64 == 0 and 3*C <= 32 required (Dt=%lld C=%lld)", (long long)Dt, (long long)C);
     const size_t shmem = (size_t)(32 * (Dt + 4) + 128) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute((const void*)class_sims_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
+    static unsigned long long attr_done = 0;
+    OWL_ONCE_PER_DEVICE(attr_done, (void)hipFuncSetAttribute((const void*)class_sims_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL(class_sims_kernel, dim3((unsigned)((rows + 127) / 128)), dim3(256), shmem, (hipStream_t)stream, e, qhat32, sims, argmax, inv_norm, rows, (int)Dt, (int)C);
     OWL_LAUNCH_CHECK();
     return 0;

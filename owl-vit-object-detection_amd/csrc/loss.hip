@@ -433,8 +433,8 @@ extern "C" int owl_hungarian(void* stream, const float* costT, const int64_t* la
     size_t sh = (size_t)P * (8 + 8 + 4 + 4 + 4 + 1) + (size_t)Nmax * (8 + 4 + 1) + 64;
     sh = (sh + 15) / 16 * 16;
     OWL_CHECK_ARG(sh <= 160 * 1024, "owl_hungarian: P=%lld too large for the LDS-resident solver", (long long)P);
-    static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute((const void*)hungarian_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); attr_done = true; }
+    static unsigned long long attr_done = 0;
+    OWL_ONCE_PER_DEVICE(attr_done, (void)hipFuncSetAttribute((const void*)hungarian_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     hipLaunchKernelGGL(hungarian_kernel, dim3((unsigned)B), dim3(512), sh, (hipStream_t)stream, costT, labels, counts, pred_idx,
                        tgt_idx, target_classes, (int)P, (int)Nmax, (int)bg);
     OWL_LAUNCH_CHECK();
@@ -445,8 +445,8 @@ extern "C" int owl_spread_labels(void* stream, const float* boxes, int64_t* targ
     OWL_CHECK_ARG(boxes && target_classes, "owl_spread_labels: null pointer");
     const size_t sh = (size_t)P * 20;
     OWL_CHECK_ARG(sh <= 156 * 1024 && P <= 8192, "owl_spread_labels: P too large");
-    static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute((const void*)spread_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024); attr_done = true; }
+    static unsigned long long attr_done = 0;
+    OWL_ONCE_PER_DEVICE(attr_done, (void)hipFuncSetAttribute((const void*)spread_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     hipLaunchKernelGGL(spread_kernel, dim3((unsigned)B), dim3(1024), sh, (hipStream_t)stream, boxes, target_classes, (int)P, (int)bg, thr);
     OWL_LAUNCH_CHECK();
     return 0;
