@@ -44,13 +44,34 @@ import torch.distributed as dist  # noqa: E402
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
 # HBM bytes per launch of the timed kernels for the default workload (B/16, batch 32): PMC passes over this very command
 # (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE in separate passes, FETCH x2 per MI355X_MICROARCH.md "HBM"); None elsewhere
-TRAFFIC_SOURCE = "profiles/r02_hbm_traffic.md"
+# The JSON carries the digest of the kernel sources it was measured on (tools/pmc_traffic.py); a figure taken on other sources is
+# refused (traffic = null) rather than quoted: a kernel edit must not silently keep an old number.
+TRAFFIC_FILE = "profiles/r03_traffic.json"
+TRAFFIC_SOURCE = "profiles/r03_hbm_traffic.md"
 TRAFFIC = {"gemm_pp2_kernel<bias>": None, "gemm_pp2_kernel<qgelu>": None, "attn_fwd_kernel<VROW>": None}
+TRAFFIC_NOTE = None
+
+
+def kernel_source_digest():
+    """sha256 over the HIP / C++ sources libowlhip.so is built from (names + contents, sorted)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "owl-vit-object-detection_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".h", ".cpp")):
+            h.update(fn.encode()); h.update(open(os.path.join(d, fn), "rb").read())
+    return h.hexdigest()[:16]
+
+
 try:
-    with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as _f:
-        TRAFFIC.update(json.load(_f))
+    with open(os.path.join(ROOT, TRAFFIC_FILE)) as _f:
+        _t = json.load(_f)
+    if _t.get("kernel_source_digest") == kernel_source_digest():
+        TRAFFIC.update({k: v for k, v in _t.items() if k in TRAFFIC})
+    else:
+        TRAFFIC_NOTE = f"{TRAFFIC_FILE} was measured on other kernel sources (digest {_t.get('kernel_source_digest')}): not quoted"
 except (OSError, ValueError):
-    pass
+    TRAFFIC_NOTE = f"{TRAFFIC_FILE} missing"
 
 
 def parse():
@@ -93,16 +114,14 @@ def self_launch(args):
 
 
 def synth_batches(cfg, B, device, rank, n_batches=2, seed=1234):
-    """CLIP-normalised uniform-u8 pixels (f32, as the reference's DataLoader yields) + 1..16 boxes/image, already on the device."""
+    """CLIP-normalised uniform-u8 pixels (f32, as the reference's DataLoader yields) + 1..16 boxes/image, already on the device.
+    Images, targets and weights all come from the repo's counter-based RNG (bit-identical on every box; seed + rank
+    for the data, identical weights on every rank)."""
     from owl_vit_object_detection_amd import synth
     from owl_vit_object_detection_amd.matcher import PackedTargets
-    g = torch.Generator(device=device).manual_seed(seed + rank)
-    mean = torch.tensor(synth.CLIP_MEAN, dtype=torch.float32, device=device).view(1, 3, 1, 1)
-    std = torch.tensor(synth.CLIP_STD, dtype=torch.float32, device=device).view(1, 3, 1, 1)
     out = []
     for k in range(n_batches):
-        u8 = torch.randint(0, 256, (B, 3, cfg.image_size, cfg.image_size), generator=g, device=device, dtype=torch.int32)
-        img = ((u8.float() / 255.0) - mean) / std
+        img = torch.from_numpy(synth.make_images(cfg, B, seed + rank, first=k * B)).to(device)
         labels, boxes = synth.make_targets(cfg, B, seed, first=(rank * n_batches + k) * B, max_boxes=16)
         lab_l = [torch.from_numpy(l).to(device) for l in labels]          # ref main.py:78-79: labels.to(device), boxes.to(device)
         box_l = [torch.from_numpy(b).to(device) for b in boxes]
@@ -193,7 +212,8 @@ class KernelTimer:
         mean_ms = float(np.mean(ms))
         achieved = flops / (mean_ms * 1e-3) / 1e12
         return {"bound": "mfma", "kernel": label, "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": TRAFFIC.get(label), "traffic_source": TRAFFIC_SOURCE if TRAFFIC.get(label) else None,
+                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": TRAFFIC.get(label),
+                "traffic_source": TRAFFIC_SOURCE if TRAFFIC.get(label) else TRAFFIC_NOTE,
                 "launches_timed": len(ev), "ms_per_launch": round(mean_ms, 4), "gflop_per_launch": round(flops / 1e9, 2),
                 "ms_total_per_step": None}
 

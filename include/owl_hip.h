@@ -31,6 +31,10 @@ extern "C" {
 #endif
 
 /* ---- runtime ---------------------------------------------------------------------------------- */
+/* Bumped whenever a prototype, an argument's meaning or a caller-provided scratch layout changes (1 = round 1; 2 = round 2: per-call `tile` /
+ * `variant` arguments, partial-sum scratch of the row reductions, 5D+4 box_final_bwd partials; 3 = round 3).  owl_abi_version() returns the value
+ * the library was BUILT with: a binding compares it with the header it was generated from and refuses a mismatch (_lib.load() does). */
+#define OWL_ABI_VERSION 3
 const char* owl_last_error(void);
 int owl_abi_version(void);
 

@@ -26,9 +26,18 @@ _CTYPES = {
 _RET = {"int": ctypes.c_int, "const char*": ctypes.c_char_p}
 
 
-def parse_header(path: str = HEADER):
+def header_abi_version(path: str = None) -> int:
+    """`#define OWL_ABI_VERSION n` of the header the signatures below are generated from."""
+    path = path or HEADER
+    m = re.search(r"^\s*#\s*define\s+OWL_ABI_VERSION\s+(\d+)", open(path).read(), flags=re.M)
+    if not m:
+        raise OwlLibError(f"{path} does not define OWL_ABI_VERSION")
+    return int(m.group(1))
+
+
+def parse_header(path: str = None):
     """-> {name: (restype, [(ctype_name, arg_name), ...])} for every prototype in the header."""
-    src = open(path).read()
+    src = open(path or HEADER).read()
     src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
     src = re.sub(r"//[^\n]*", " ", src)
     protos = {}
@@ -72,6 +81,12 @@ def load():
             raise OwlLibError(f"libowlhip.so does not export `{name}` declared in include/owl_hip.h") from e
         fn.restype = _RET[ret]
         fn.argtypes = [_CTYPES[t] for t, _ in args]
+    # a stale libowlhip.so behind a newer header (or the reverse) would take garbage trailing arguments or an undersized scratch buffer
+    # without any diagnostic: refuse it here
+    built, want = int(lib.owl_abi_version()), header_abi_version()
+    if built != want:
+        raise OwlLibError(f"{LIB_PATH} was built with OWL_ABI_VERSION {built} but include/owl_hip.h declares {want}: rebuild it "
+                          "(owl-vit-object-detection_amd/csrc/build.sh)")
     _lib = lib
     return lib
 

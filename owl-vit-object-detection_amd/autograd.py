@@ -58,7 +58,8 @@ class OwlViTFunction(torch.autograd.Function):
             # size has overwritten them (e.g. two forwards, then (l1 + l2).backward())
             raise RuntimeError(
                 f"OwlViT backward: the activations of this forward (batch size {B}) were overwritten by a later gradient-recording "
-                "forward at the same batch size; call backward() before the next training forward (no-grad / eval forwards are fine)")
+                "forward at the same batch size (or evicted: only the model's `max_cached_batch_sizes` most recent batch sizes keep their "
+                "workspaces); call backward() before the next training forward (no-grad / eval forwards are fine)")
         backward_impl(model, B, d_boxes, d_sims, ctx.sims)
         return (None, None) + (None,) * len(model.flat_offsets)
 

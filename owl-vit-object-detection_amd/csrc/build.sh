@@ -5,12 +5,15 @@ cd "$(dirname "$0")"
 ARCH=${OWL_ARCH:-gfx950}
 FLAGS="--offload-arch=${ARCH} -O3 -std=c++17 -fPIC -Wno-unused-value"
 # OWL_TUNING=1: also export the process-global tuning switches of include/owl_hip_tuning.h (tools/ only; never the shipped build)
-if [ "${OWL_TUNING:-0}" = "1" ]; then FLAGS="$FLAGS -DOWL_TUNING"; fi
-mkdir -p build
+# Objects of a tuning build and of the shipped build live in different directories: staleness is judged by file times alone, so one shared
+# directory would let a default build re-use -DOWL_TUNING objects (and ship the process-global setters), or the reverse.
+BUILD=build
+if [ "${OWL_TUNING:-0}" = "1" ]; then FLAGS="$FLAGS -DOWL_TUNING"; BUILD=build_tuning; fi
+mkdir -p $BUILD
 objs=""
 pids=""
 for f in *.hip; do
-  o=build/${f%.hip}.o
+  o=$BUILD/${f%.hip}.o
   stale=0
   for h in *.h; do [ "$h" -nt "$o" ] && stale=1; done
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ $stale = 1 ]; then
@@ -30,6 +33,6 @@ done
 fail=0
 for pid in $pids; do wait $pid || fail=1; done
 if [ $fail = 1 ]; then echo "build.sh: a HIP source failed to compile" >&2; exit 1; fi
-g++ -O2 -fPIC -std=c++17 -ffp-contract=off -c runtime.cpp -o build/runtime.o
-hipcc --offload-arch=${ARCH} -shared -fPIC -o ../libowlhip.so $objs build/runtime.o
+g++ -O2 -fPIC -std=c++17 -ffp-contract=off -c runtime.cpp -o $BUILD/runtime.o
+hipcc --offload-arch=${ARCH} -shared -fPIC -o ../libowlhip.so $objs $BUILD/runtime.o
 echo "built $(cd .. && pwd)/libowlhip.so"

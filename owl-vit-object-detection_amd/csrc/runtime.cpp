@@ -1,6 +1,7 @@
 // Thread-local error string + version for libowlhip's C ABI (include/owl_hip.h).
 #include <stdarg.h>
 #include <stdio.h>
+#include "../../include/owl_hip.h"
 
 static thread_local char g_err[512] = "";
 
@@ -12,7 +13,7 @@ void owl_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* owl_last_error(void) { return g_err; }
-extern "C" int owl_abi_version(void) { return 1; }
+extern "C" int owl_abi_version(void) { return OWL_ABI_VERSION; }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Host side of the device input pipeline (ref src/dataset.py:69-71 -> HF OwlViTImageProcessor

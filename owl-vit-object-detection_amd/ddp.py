@@ -14,7 +14,11 @@ Two schedules:
     starts at once -- embeddings and encoder layers 0..10 are frozen (ref src/models.py:173-184), so nothing
     before the trainable layer depends on the update; the compute stream waits for the side stream exactly
     where the first trainable tensor is read (models.OwlViT._wait_params).  Same arithmetic, same order:
-    parameters are bitwise equal to the in-line schedule (tests/test_ddp_overlap_gpu.py).
+    parameters are bitwise equal to the in-line schedule (tests/test_autograd_contract_gpu.py::test_overlapped_optimizer_schedule_is_bitwise_the_inline_schedule,
+    tests/test_ddp_rccl_gpu.py).  Until the side stream is done the bucket is being reduced, read and then ZEROED there: the model's
+    forward / backward / zero_grad and `state_dict()` order themselves behind it; anything else that reads parameters or gradients
+    (logging a gradient norm from `p.grad`, cloning `flat_param`) must call `finish()` first -- and reads zeros from the gradients
+    afterwards (inspect them with the in-line schedule).
 The same code runs on CPU tensors with the gloo backend (tests/test_ddp_cpu.py; in-line schedule).
 """
 import os

@@ -78,9 +78,11 @@ class PackedTargets:
                 hb[b, : sizes[b]] = bx
                 hc[b] = sizes[b]
             dev = torch.empty(nl + nb + 4 * B, dtype=torch.uint8, device=device)
-            dev.copy_(host[: nl + nb + 4 * B], non_blocking=True)
-            slot["event"] = torch.cuda.Event()
-            slot["event"].record()
+            # (copy and event on `device`'s current stream -- which need not be the current device's)
+            with torch.cuda.device(device):
+                dev.copy_(host[: nl + nb + 4 * B], non_blocking=True)
+                slot["event"] = torch.cuda.Event()
+                slot["event"].record()
             self.labels = dev[:nl].view(torch.int64).view(B, Nmax)
             self.boxes = dev[nl: nl + nb].view(torch.float32).view(B, Nmax, 4)
             self.counts = dev[nl + nb:].view(torch.int32)
@@ -96,9 +98,10 @@ class PackedTargets:
             acc += n
         ho[B] = acc
         offsets = torch.empty(B + 1, dtype=torch.int32, device=device)
-        offsets.copy_(ho, non_blocking=True)
-        slot["event"] = torch.cuda.Event()
-        slot["event"].record()
+        with torch.cuda.device(device):
+            offsets.copy_(ho, non_blocking=True)
+            slot["event"] = torch.cuda.Event()
+            slot["event"].record()
         self.labels = torch.empty(B, Nmax, dtype=torch.int64, device=device)
         self.boxes = torch.empty(B, Nmax, 4, dtype=torch.float32, device=device)
         self.counts = torch.empty(B, dtype=torch.int32, device=device)

@@ -133,8 +133,15 @@ class OwlViT(nn.Module):
                         self._fz[f"{i}.{k}T"] = self._fz[f"{i}.{k}"].t().contiguous()
         self.box_bias = box_bias_table(cfg.grid).to(self.device_)
         self._ws = {}
+        self._ws_lru = []                  # batch sizes, most recent first: workspaces of all but the newest `max_cached_batch_sizes` are dropped
+        self.max_cached_batch_sizes = 2    # (a DataLoader's ragged last batch + the regular one; every further size would pin its own activations)
         self._saved = None
-        self._bf16_version = None          # flat_param._version the bf16 compute copy was cast from
+        # The bf16 compute copy of the trainable bucket is re-cast by EVERY forward -- one pass over 8.7 M elements -- unless the fused AdamW has
+        # just written it in its own pass: FusedAdamW.step leaves a ONE-SHOT token (this flag + the bucket's version counter) that the next
+        # forward consumes.  Nothing else can set it, so writes the version counter does not see (`p.data.mul_()`, raw-pointer kernels) are picked
+        # up by the next forward at the latest one forward after an optimizer step (see refresh_compute_weights for the remaining window).
+        self._bf16_current = False
+        self._bf16_version = None          # flat_param._version at the fused step that set the token
         self.encoder_streams = int(encoder_streams)     # sub-batches of the encoder forward, one HIP stream each (see _forward_impl); 1 = off
         self._streams, self._join, self._fork_ev = [], {}, None
         self.head_streams = True          # box head / class head (forward and backward) on two streams when the sub-batch streams are on
@@ -142,6 +149,9 @@ class OwlViT(nn.Module):
         self._param_event = None           # ddp.DataParallel(overlap=True): the deferred all-reduce + AdamW of the previous step
         self._grad_clean = False           # ... which also left flat_grad zeroed for this step
         self._trainable = frozenset(order)
+        # checkpointing while a deferred optimizer step (ddp.DataParallel(overlap=True)) is still running on its side stream: order the
+        # current stream behind it before any parameter is read
+        self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module._wait_params())
 
     # -- module-tree plumbing -----------------------------------------------------------------------
     def _attach(self, dotted: str, p: nn.Parameter):
@@ -182,10 +192,26 @@ class OwlViT(nn.Module):
                     g2=P_[pre + "layer_norm2.weight"], be2=P_[pre + "layer_norm2.bias"])
 
     # -- workspaces -----------------------------------------------------------------------------------
+    def _touch_batch(self, B: int):
+        """Workspaces are cached per batch size; only the `max_cached_batch_sizes` most recently used sizes are kept (a third size evicts the
+        least recently used one's activations, saved layers and backward scratch -- the caching allocator reuses the memory).  A backward
+        still pending for an evicted size finds a fresh workspace whose generation does not match and raises (autograd.OwlViTFunction)."""
+        lru = self._ws_lru
+        if lru and lru[0] == B:
+            return
+        if B in lru:
+            lru.remove(B)
+        lru.insert(0, B)
+        while len(lru) > max(1, int(self.max_cached_batch_sizes)):
+            old = lru.pop()
+            for k in [k for k in self._ws if (k if isinstance(k, int) else k[1]) == old]:
+                del self._ws[k]
+
     def _workspace(self, B: int, train: bool = True):
         """Activation workspace of batch size B.  Gradient-recording forwards and no-grad (eval) forwards use SEPARATE sets, so an
         eval forward between a training forward and its backward cannot overwrite what that backward reads; two recording forwards
         at the same batch size do share one set -- the autograd node checks `gen` and refuses to run on overwritten activations."""
+        self._touch_batch(B)
         key = B if train else ("eval", B)
         if key in self._ws:
             return self._ws[key]
@@ -228,14 +254,30 @@ class OwlViT(nn.Module):
         self._ws[key] = L
         return L
 
-    def refresh_compute_weights(self, force: bool = False):
-        """bf16 copies of the trainable tensors (one cast over the flat bucket) -- skipped while the copy is current: the fused AdamW
-        refreshes it in its own pass (optim.FusedAdamW.step) and leaves the version counter alone; every torch-level write to a
-        parameter (torch.optim.AdamW, copy_, load_state_dict ...) bumps the counter the views share with the bucket."""
-        v = self.flat_param._version
-        if force or self._bf16_version != v:
-            ops.cast_bf16(self.flat_param, self.flat_bf16)
-            self._bf16_version = v
+    def refresh_compute_weights(self, force: bool = True):
+        """bf16 copies of the trainable tensors: one cast over the flat bucket.  Every forward calls it, except the first forward after a
+        fused AdamW step (whose kernel writes the copy itself and leaves a one-shot token, see __init__).  The only window left: a write
+        that bypasses the version counter (`p.data.copy_()`, a raw-pointer kernel) BETWEEN FusedAdamW.step() and the next forward -- call
+        this method after such a write."""
+        ops.cast_bf16(self.flat_param, self.flat_bf16)
+        self._bf16_current = False
+
+    def _mark_bf16_current(self):
+        """optim.FusedAdamW.step only: its kernel has just rewritten flat_bf16 from the updated flat_param."""
+        self._bf16_current = True
+        self._bf16_version = self.flat_param._version
+
+    def _apply(self, fn, recurse=True):
+        """`.to()` / `.cuda()` / `.half()` / `.float()` / `.cpu()` replace every `param.data`, which would silently detach the 29 trainable
+        tensors from the flat parameter / gradient / bf16 buckets the kernels read.  The model is built on its device in f32 (the reference's
+        `.to(device)`, src/models.py:191, is done by construction): a call that changes nothing is accepted, anything else raises."""
+        probe = torch.empty(0, dtype=torch.float32, device=self.device_)
+        out = fn(probe)
+        if out.dtype != probe.dtype or out.device != probe.device:
+            raise RuntimeError(
+                f"OwlViT lives on {self.device_} in float32 (trainable tensors are views of one flat bucket; compute is bf16 inside the kernels): "
+                f"moving / casting the module to {out.device} / {out.dtype} is not supported -- build it with load_model(labelmap, device)")
+        return self
 
     def _wait_params(self):
         """Order the compute stream behind a deferred optimizer step (ddp.DataParallel(overlap=True)): called right before the
@@ -345,7 +387,9 @@ class OwlViT(nn.Module):
         ws["gen"] += 1
         M, Mh = B * Tp, B * P
         P_ = self._byname
-        if self._bf16_version != self.flat_param._version:
+        if self._bf16_current and self._bf16_version == self.flat_param._version:
+            self._bf16_current = False          # one-shot: the fused AdamW's own bf16 pass covers exactly this forward
+        else:
             self._wait_params()
             self.refresh_compute_weights()
 

@@ -37,6 +37,7 @@ class FusedAdamW:
         _lib.call("owl_adamw_step", ops.stream(), m.flat_param, m.flat_grad, self.exp_avg, self.exp_avg_sq, m.flat_bf16,
                   m.flat_numel, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count,
                   float(self.grad_scale))
+        m._mark_bf16_current()          # one-shot token for the next forward (models.OwlViT.__init__)
 
     def state_dict(self):
         return dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, lr=self.lr, betas=self.betas,

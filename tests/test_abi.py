@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(built):
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in _lib.parse_header():
         assert hasattr(lib, name), f"{name} declared in include/owl_hip.h but not exported"
-    assert built.owl_abi_version() >= 1
+    assert built.owl_abi_version() == _lib.header_abi_version() >= 3
 
 
 def test_no_process_global_setters_in_the_product_abi(built):
@@ -67,6 +67,17 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         L.load()
     with pytest.raises(L.OwlLibError):
         L.call("owl_abi_version")
+
+
+def test_abi_version_mismatch_is_refused(built, monkeypatch, tmp_path):
+    """A binding generated from a header of another ABI version must not drive the library (changed argument lists / scratch layouts)."""
+    from owl_vit_object_detection_amd import _lib as L
+    hdr = tmp_path / "owl_hip.h"
+    hdr.write_text(open(L.HEADER).read().replace(f"#define OWL_ABI_VERSION {L.header_abi_version()}", "#define OWL_ABI_VERSION 9999"))
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "HEADER", str(hdr))
+    with pytest.raises(L.OwlLibError, match="OWL_ABI_VERSION"):
+        L.load()
 
 
 def test_product_package_never_imports_the_oracle():

@@ -34,10 +34,12 @@ def qgelu(x):
     return x * torch.sigmoid(1.702 * x)
 
 
-@pytest.fixture(params=[128, 256, 8], ids=["tile128", "tile256", "pingpong"])
+@pytest.fixture(params=[128, 256, 8, 7, 0], ids=["tile128", "tile256", "pingpong", "pingpong2", "auto"])
 def gemm_tile(request):
-    """Run the GEMM tests on every kernel: 128x128 4-wave, 256x256 8-wave, and the 256x256 ping-pong schedule
-    (gemm_pp.hip; it takes the bf16-output epilogues with K >= 128 and falls through to tile256 otherwise)."""
+    """Run the GEMM tests on every kernel: 128x128 4-wave, 256x256 8-wave, the 256x256 four-phase ping-pong schedule (gemm_pp.hip; it
+    takes the bf16-output epilogues with K >= 128 and falls through to tile256 otherwise), the two-phase ping-pong kernel on the whole
+    problem (gemm_pp2.hip: what the model runs) and the library's automatic choice (two-phase + half-height remainder tiles, gemm_pph.hip)
+    -- each against `A @ W.T` in fp32, including the odd shapes (M = 777, N = 264 / 328) where clamped loads and store guards live."""
     from owl_vit_object_detection_amd import _lib
     ops.GEMM_TILE = request.param
     yield request.param

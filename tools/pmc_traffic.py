@@ -35,4 +35,7 @@ if "--json" in sys.argv:
         elif k.startswith("void gemm_pp2_kernel<1>"): out["gemm_pp2_kernel<qgelu>"] = round(rd + wr)
         elif k.startswith("void attn_fwd_kernel<true, true>"): out["attn_fwd_kernel<VROW>"] = round(rd + wr)        # (class token peeled: what T = 1 + 64 n runs)
         elif k.startswith("void attn_fwd_kernel<true, false>") and "attn_fwd_kernel<VROW>" not in out: out["attn_fwd_kernel<VROW>"] = round(rd + wr)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_source_digest            # bench.py quotes these figures only for the sources they were measured on
+    out["kernel_source_digest"] = kernel_source_digest()
     json.dump(out, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
