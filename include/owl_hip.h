@@ -83,8 +83,13 @@ int owl_attention_fwd_bf16(void* stream, const void* q, const void* k, int64_t l
  * variant (per call, no global state): 0 = the library's choice; 1 = plain tiling (tokens 0..T-1 in 64-key tiles / 128-query blocks: the bits
  * of owl_attention_fwd_bf16); 2 = class token peeled: token 0 enters every other query's online softmax as its initial state and is itself
  * one VALU-only workgroup per (image, head), the tiles cover tokens 1..T-1 -- needs T - 1 a positive multiple of 64 (else rc != 0);
- * same values as 1 to bf16 round-off (other summation order), 5.8 % faster at T = 2305.  0 picks 2 wherever it is allowed. */
-int owl_attention_fwd_vrow_bf16(void* stream, const void* q, const void* k, const void* v, int64_t ld_qkv, void* out, int64_t ld_out, float* lse, int64_t B, int64_t H, int64_t T, int64_t Tp, float scale, int variant);
+ * same values as 1 to bf16 round-off (other summation order), 5.8 % faster at T = 2305.  0 picks 2 wherever it is allowed;
+ * 3 = the peeled tiling on the one-wave-per-SIMD structure (csrc/attention_fwd_w64.hip: 64 queries per wave, 256 per workgroup, softmax
+ * interleaved with the MFMAs of the neighbouring tiles): needs T - 1 a multiple of 64 >= 192 and `redo_ws` -- device scratch of
+ * owl_attention_fwd_workspace_bytes(B, H, T) bytes (any contents; one int per query block, written by the kernel: blocks whose scores leave the
+ * range its offset-free softmax covers are redone by the classic kernel in the same call).  redo_ws may be NULL for variants 0-2. */
+int owl_attention_fwd_workspace_bytes(int64_t B, int64_t H, int64_t T, int64_t* bytes);   /* redo_ws; `bytes` is a HOST pointer */
+int owl_attention_fwd_vrow_bf16(void* stream, const void* q, const void* k, const void* v, int64_t ld_qkv, void* out, int64_t ld_out, float* lse, int64_t B, int64_t H, int64_t T, int64_t Tp, float scale, int variant, int* redo_ws);
 
 /* backward of the fused attention (layers whose attention runs backward): qkv row-major [B*Tp,3D] (q|k|v), dO / O row-major
  * [B*Tp,D], lse from the forward; writes dqkv [B*Tp,3D] (dq|dk|dv, bf16).  Every transposed operand of the dK/dV/dQ MFMAs is read

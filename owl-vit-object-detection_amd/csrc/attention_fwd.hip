@@ -13,110 +13,8 @@
 // K tiles [64 keys][64 d] and V^T tiles [64 d][64 keys] (V^T is written per head by the QKV GEMM's
 // transposing epilogue) stream HBM -> LDS by LDS-DMA, double-buffered, XOR-swizzled like the GEMM
 // tiles (conflict-free ds_read_b128).  Online softmax in the exp2 domain.
-#include "common.h"
+#include "attention_fwd_common.h"
 #include <type_traits>
-
-struct AttnFwdP {
-    const bf16_t* q; const bf16_t* k; int64_t ld_qk;   // row-major [B*Tp, ld]; head h at column h*64
-    const bf16_t* vt; int64_t vt_img_stride;            // V^T [B][heads..][64][Tp]; element stride per image
-    bf16_t* out; int64_t ld_out;                        // [B*Tp, ld_out], head h at column h*64
-    float* lse;                                         // optional [B][H][Tp], log2 domain
-    int T, Tp, H, B, nqb, dbg;
-    float scale_log2e;
-};
-
-__device__ __forceinline__ int swap23(int m) { return (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1); }
-
-// VROW = false: V arrives per head TRANSPOSED (V^T [B][heads*64][Tp], written by a transposing GEMM epilogue or a token transpose).
-// VROW = true : V is read where the QKV GEMM leaves it (row-major, column 2D + h*64 of the qkv rows); the [64 key][64 d] tile is
-//               staged exactly like the K tile and transposed by the LDS hardware (`ds_read_b64_tr_b16`, two per fragment).
-// PEEL (VROW only): token 0 (the class token) is taken out of the tiling.  T = 1 + 48^2 = 2305 is one more than 36 key tiles / 18 query
-//               blocks: tiled as it is, EVERY query block pays a 37th, masked, one-key tile and every (image, head) a 19th query block
-//               with one live query (5.8 % of the launch, tools/attn_peel.py).  Peeled, key 0 enters as the INITIAL STATE of the online
-//               softmax (p0 = exp2(s0), l = p0, O = p0 v0: one 64-long dot product per query on the VALU), the tiles cover tokens 1..T-1
-//               (36 full tiles, no mask code on the path), and query 0 of every (image, head) is one extra, VALU-only workgroup
-//               (attn_cls_row: 2 T dot products of length 64 -- no MFMA tile with 127 dead columns).
-//               (Two more sweeps were built and measured in round 2 -- software-pipelined across tiles, "optimistic" without per-tile
-//               checks -- and removed again: -5..10 % / +0.5 %, profiles/r02_attn_fwd_experiments.md; the code is in history at 22922f6.)
-
-// Query row 0 of one (image, head) against all T keys, on the VALU.  8 lanes per key row (one 16-byte feature chunk each), so the 256
-// threads form 32 row groups; group g runs an online softmax over rows g, g + 32, ... in ONE pass over K and V (6 rows of each per batch,
-// the next batch's 12 loads issued before the current one is consumed: the workgroup is L2-latency-bound, nothing else), then the 32
-// partial states (m, l, O[64]) are merged through LDS in a fixed order: same bits every launch.
-__device__ __forceinline__ void attn_cls_row(const AttnFwdP& p, int b, int h, unsigned char* lds) {
-    constexpr int U = 6;
-    const int tid = threadIdx.x, sub = tid & 7, grp = tid >> 3;
-    const int T = p.T;
-    const int64_t ld = p.ld_qk;
-    const bf16_t* kb = p.k + (int64_t)b * p.Tp * ld + h * 64 + sub * 8;
-    const bf16_t* vb = p.vt + (int64_t)b * p.Tp * ld + h * 64 + sub * 8;
-    float qv[8];
-    {
-        const uint4 qu = *(const uint4*)(p.q + (int64_t)b * p.Tp * ld + h * 64 + sub * 8);
-        const unsigned u[4] = {qu.x, qu.y, qu.z, qu.w};
-#pragma unroll
-        for (int e = 0; e < 4; e++) { qv[2 * e] = __uint_as_float(u[e] << 16) * p.scale_log2e; qv[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u) * p.scale_log2e; }
-    }
-    float m = -1e30f, l = 0.f;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    uint4 kq[2][U], vq[2][U];
-    auto fetch = [&](int set, int j0) {          // rows j0 + 32 u (clamped: a row past T is read, not used)
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            int j = j0 + 32 * u; j = j < T ? j : T - 1;
-            kq[set][u] = *(const uint4*)(kb + (int64_t)j * ld);
-            vq[set][u] = *(const uint4*)(vb + (int64_t)j * ld);
-        }
-    };
-    auto consume = [&](int set, int j0) {
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const unsigned ku[4] = {kq[set][u].x, kq[set][u].y, kq[set][u].z, kq[set][u].w};
-            const unsigned vu[4] = {vq[set][u].x, vq[set][u].y, vq[set][u].z, vq[set][u].w};
-            float d = 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; e++) { d += qv[2 * e] * __uint_as_float(ku[e] << 16); d += qv[2 * e + 1] * __uint_as_float(ku[e] & 0xffff0000u); }
-            d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
-            if (j0 + 32 * u >= T) d = -1e30f;                    // (every group's first row is a real one: T >= 65)
-            const float mn = fmaxf(m, d);
-            const float alpha = __builtin_amdgcn_exp2f(m - mn), pj = __builtin_amdgcn_exp2f(d - mn);
-            m = mn;
-            l = l * alpha + pj;
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                acc[2 * e] = acc[2 * e] * alpha + pj * __uint_as_float(vu[e] << 16);
-                acc[2 * e + 1] = acc[2 * e + 1] * alpha + pj * __uint_as_float(vu[e] & 0xffff0000u);
-            }
-        }
-    };
-    fetch(0, grp);
-    int j0 = grp;
-    for (; j0 + 32 * U < T; j0 += 64 * U) {      // two batches per trip: the register sets are compile-time
-        fetch(1, j0 + 32 * U);
-        consume(0, j0);
-        if (j0 + 64 * U < T) fetch(0, j0 + 64 * U);
-        consume(1, j0 + 32 * U);
-    }
-    if (j0 < T) consume(0, j0);
-    // merge: red[g] = (m, l, O[0..63]) of row group g
-    float* red = (float*)lds;
-    if (sub == 0) { red[grp * 66] = m; red[grp * 66 + 1] = l; }
-#pragma unroll
-    for (int e = 0; e < 8; e++) red[grp * 66 + 2 + sub * 8 + e] = acc[e];
-    __syncthreads();
-    if (tid < 64) {
-        float mm = red[0];
-        for (int g = 1; g < 32; g++) mm = fmaxf(mm, red[g * 66]);
-        float lt = 0.f, o = 0.f;
-        for (int g = 0; g < 32; g++) {
-            const float sc = __builtin_amdgcn_exp2f(red[g * 66] - mm);
-            lt += red[g * 66 + 1] * sc;
-            o += red[g * 66 + 2 + tid] * sc;
-        }
-        p.out[(int64_t)b * p.Tp * p.ld_out + h * 64 + tid] = f2bf(o / lt);
-        if (p.lse && tid == 0) p.lse[((int64_t)b * p.H + h) * p.Tp] = mm + __builtin_amdgcn_logf(lt);
-    }
-}
 
 template <bool VROW, bool PEEL = false>
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
@@ -137,6 +35,9 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
     const int b = pair / p.H, h = pair - b * p.H;
     static_assert(VROW || !PEEL, "the peeled tiling shifts the key rows by one: row-major V only");
     if constexpr (PEEL) {
+        if (p.redo) {       // fix-up launch behind the one-wave-per-SIMD kernel: only the flagged query blocks (normally none) are redone
+            if (qb == p.nqb - 1 || !p.redo[pair * p.redo_nqb + (qb >> 1)]) return;
+        }
         if (qb == p.nqb - 1) { attn_cls_row(p, b, h, lds); return; }       // workgroup-uniform
     }
     // the tiles cover tokens PEEL .. T-1: Tk keys / queries, tile-local index + PEEL = token
@@ -504,15 +405,23 @@ static constexpr int g_attn_dbg = 0;
 #endif
 
 // variant: 0 = the library's choice (peeled wherever it can be), 1 = plain tiling, 2 = peeled (row-major V, T - 1 a positive multiple of 64)
+int attn_fwd_w64_launch(hipStream_t stream, const AttnFwdP& base, int* redo, int dbg);      // attention_fwd_w64.hip
+
 static int attn_fwd_launch(void* stream, const void* q, const void* k, int64_t ld_qk, const void* v, int v_row_major,
                            int64_t vt_img_stride, void* out, int64_t ld_out, float* lse, int64_t B, int64_t H, int64_t T,
-                           int64_t Tp, float scale, int variant) {
+                           int64_t Tp, float scale, int variant, int* redo = nullptr) {
     OWL_CHECK_ARG(q && k && v && out, "owl_attention_fwd_bf16: null pointer");
     OWL_CHECK_ARG(ld_qk % 8 == 0 && ld_out % 8 == 0 && Tp % 8 == 0 && T > 0 && T <= Tp, "owl_attention_fwd_bf16: bad strides (ld_qk %% 8, ld_out %% 8, Tp %% 8)");
-    OWL_CHECK_ARG(variant >= 0 && variant <= 2 && (variant <= 1 || v_row_major), "owl_attention_fwd: variant must be 0 (default), 1 (plain tiling) or 2 (class token peeled; row-major V only)");
+    OWL_CHECK_ARG(variant >= 0 && variant <= 4 && (variant <= 1 || v_row_major), "owl_attention_fwd: variant must be 0 (default), 1 (plain tiling), 2 (class token peeled; row-major V only) or 3 (one wave per SIMD)");
     const bool can_peel = v_row_major && T >= 65 && (T - 1) % 64 == 0;
     OWL_CHECK_ARG(variant != 2 || can_peel, "owl_attention_fwd: variant 2 (peeled) needs row-major V and T - 1 a positive multiple of 64");
-    const bool peel = variant == 2 || (variant == 0 && can_peel);
+    const bool can_w64 = can_peel && T - 1 >= 192 && redo != nullptr;
+    OWL_CHECK_ARG(variant < 3 || can_w64, "owl_attention_fwd: variant 3 (one wave per SIMD) needs row-major V, T - 1 a multiple of 64 >= 192 and the redo scratch");
+#ifndef OWL_TUNING
+    OWL_CHECK_ARG(variant != 4, "owl_attention_fwd: variant 4 (stamped one-wave-per-SIMD kernel) exists only in an OWL_TUNING build");
+#endif
+    const bool w64 = variant >= 3;            // (4, OWL_TUNING builds: the s_memtime-stamped kernel, no fix-up launch -- tools/attn_w64_trace.py)
+    const bool peel = variant == 2 || w64 || (variant == 0 && can_peel);
     AttnFwdP p{};
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.ld_qk = ld_qk;
     p.vt = (const bf16_t*)v; p.vt_img_stride = vt_img_stride;
@@ -523,6 +432,14 @@ static int attn_fwd_launch(void* stream, const void* q, const void* k, int64_t l
     p.nqb = peel ? (int)((T - 1 + 127) / 128) + 1 : (int)((T + 127) / 128);      // peeled: the last "block" is the class-token row
     const int64_t npairs8 = (B * H + 7) / 8;                  // pairs per XCD (rounded up)
     dim3 grid((unsigned)(npairs8 * p.nqb * 8));
+    if (w64) {
+        // 64 queries per wave, one wave per SIMD; then the classic kernel over the query blocks it flagged (normally none: a launch of
+        // workgroups that read one flag and exit)
+        if (int rc = attn_fwd_w64_launch((hipStream_t)stream, p, redo, variant == 4 ? 8 : 0)) return rc;
+        if (variant == 4) return 0;
+        p.redo = redo;
+        p.redo_nqb = (int)((T - 1 + 255) / 256);
+    }
     if (!v_row_major) hipLaunchKernelGGL((attn_fwd_kernel<false>), grid, dim3(256), 2 * 16384, (hipStream_t)stream, p);
     else if (peel) hipLaunchKernelGGL((attn_fwd_kernel<true, true>), grid, dim3(256), 2 * 16384, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((attn_fwd_kernel<true>), grid, dim3(256), 2 * 16384, (hipStream_t)stream, p);
@@ -538,6 +455,12 @@ extern "C" int owl_attention_fwd_bf16(void* stream, const void* q, const void* k
 
 // same, with V read where the QKV GEMM leaves it: row-major [B*Tp, ld_qkv], head h at column h*64 of `v` (no V^T copy at all)
 extern "C" int owl_attention_fwd_vrow_bf16(void* stream, const void* q, const void* k, const void* v, int64_t ld_qkv, void* out,
-                                           int64_t ld_out, float* lse, int64_t B, int64_t H, int64_t T, int64_t Tp, float scale, int variant) {
-    return attn_fwd_launch(stream, q, k, ld_qkv, v, 1, 0, out, ld_out, lse, B, H, T, Tp, scale, variant);
+                                           int64_t ld_out, float* lse, int64_t B, int64_t H, int64_t T, int64_t Tp, float scale, int variant, int* redo_ws) {
+    return attn_fwd_launch(stream, q, k, ld_qkv, v, 1, 0, out, ld_out, lse, B, H, T, Tp, scale, variant, redo_ws);
+}
+
+extern "C" int owl_attention_fwd_workspace_bytes(int64_t B, int64_t H, int64_t T, int64_t* bytes) {
+    OWL_CHECK_ARG(bytes && B > 0 && H > 0 && T > 0, "owl_attention_fwd_workspace_bytes: bad arguments");
+    *bytes = B * H * ((T - 1 + 255) / 256 + 1) * (int64_t)sizeof(int);
+    return 0;
 }

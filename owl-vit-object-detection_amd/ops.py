@@ -88,10 +88,27 @@ def attention_fwd(q, k, ld_qk, vt, vt_img_stride, out, ld_out, lse, B, H, T, Tp,
     return out
 
 
+_attn_redo = {}
+
+
+def attention_redo_ws(B, H, T, device):
+    """Scratch of the one-wave-per-SIMD attention forward (one int per query block; contents irrelevant): one buffer per (device, stream)."""
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    n = B * H * ((T - 1 + 255) // 256 + 1)
+    buf = _attn_redo.get(key)
+    if buf is None or buf.numel() < n:
+        buf = _attn_redo[key] = torch.zeros(max(n, 4096) + 8192, dtype=torch.int32, device=device)
+    return buf
+
+
 def attention_fwd_vrow(q, k, v, ld_qkv, out, ld_out, lse, B, H, T, Tp, scale, variant=None):
     """attention_fwd with V row-major (a column slice of the qkv rows): no V^T copy."""
-    _lib.call("owl_attention_fwd_vrow_bf16", stream(), q, k, v, ld_qkv, out, ld_out, lse, B, H, T, Tp, float(scale),
-              int(ATTN_VARIANT if variant is None else variant))
+    variant = int(ATTN_VARIANT if variant is None else variant)
+    redo = attention_redo_ws(B, H, T, out.device) if variant >= 3 else None
+    _lib.call("owl_attention_fwd_vrow_bf16", stream(), q, k, v, ld_qkv, out, ld_out, lse, B, H, T, Tp, float(scale), variant, redo)
     return out
 
 

@@ -132,3 +132,64 @@ def test_data_parallel_scales_for_a_non_fused_optimizer(monkeypatch):
     model.flat_grad.fill_(8.0)
     dp.sync_and_step()
     assert float(model.flat_grad[0]) == 2.0
+
+
+def test_module_moves_and_casts_are_refused():
+    """`.to()` / `.half()` / `.cpu()` would replace param.data and detach the trainable tensors from the flat buckets (VERDICT r02 missing #4);
+    a call that changes nothing (the reference's `.to(device)`, src/models.py:191) is accepted and leaves the views in place."""
+    cfg, model, img, lab, box, crit = _setup()
+    ptr = model.p("queries").data_ptr()
+    assert model.to(DEV) is model and model.float() is model and model.cuda() is model
+    assert model.p("queries").data_ptr() == ptr == model.flat_param.data_ptr() + 4 * model.flat_offsets["queries"]
+    for move in (lambda: model.half(), lambda: model.to(torch.bfloat16), lambda: model.cpu(), lambda: model.double()):
+        with pytest.raises(RuntimeError, match="not supported"):
+            move()
+    assert model.p("queries").data_ptr() == ptr
+
+
+def test_data_writes_reach_the_bf16_compute_copy():
+    """A write through `.data` does not bump the version counter the bucket shares with its views; the forward re-casts the compute copy
+    anyway: only the forward right after a FusedAdamW.step() trusts the copy that step wrote."""
+    cfg, model, img, lab, box, crit = _setup()
+    with torch.no_grad():
+        ref0 = model(img)[2].clone()
+        q = model.p("queries")
+        q.data.mul_(-1.0)                                  # version counter untouched
+        flipped = model(img)[2].clone()
+        assert not torch.equal(flipped, ref0)
+        q.data.mul_(-1.0)
+        assert torch.equal(model(img)[2], ref0)
+    # the one-shot token: step -> forward uses the optimizer's own bf16 pass, and is consumed by that forward
+    opt = FusedAdamW(model, lr=1e-3)
+    opt.zero_grad()
+    pb, _, ps, _ = model(img)
+    _loss(crit, ps, lab, pb, box).backward()
+    opt.step()
+    assert model._bf16_current
+    ref_bf16 = model.flat_bf16.clone()
+    assert torch.equal(ref_bf16, model.flat_param.to(torch.bfloat16))
+    with torch.no_grad():
+        model(img)
+    assert not model._bf16_current
+    model.p("queries").data.mul_(2.0)
+    with torch.no_grad():
+        model(img)
+    assert torch.equal(model.flat_bf16, model.flat_param.to(torch.bfloat16)) and not torch.equal(model.flat_bf16, ref_bf16)
+
+
+def test_workspace_cache_keeps_the_two_latest_batch_sizes():
+    cfg, model, img, lab, box, crit = _setup(B=3)
+    sizes = lambda: sorted({(k if isinstance(k, int) else k[1]) for k in model._ws})
+    with torch.no_grad():
+        model(img[:1]); model(img[:2])
+        assert sizes() == [1, 2]
+        model(img[:3])
+        assert sizes() == [2, 3]
+        model(img[:2]); model(img[:1])
+        assert sizes() == [1, 2]
+    # a backward whose workspace was evicted raises instead of reading another batch's activations
+    pb, _, ps, _ = model(img[:1])
+    with torch.no_grad():
+        model(img[:2]); model(img[:3])
+    with pytest.raises(RuntimeError, match="evicted"):
+        _loss(crit, ps, lab[:1], pb, box[:1]).backward()
