@@ -145,15 +145,17 @@ def cpu_baseline(cfg, steps):
     bwd; the 11 ms AdamW is left out as in BASELINE.md's breakdown) at batch 1 and batch 8, median after 2 warm-ups."""
     from oracle import owl_oracle as O
     from owl_vit_object_detection_amd import synth, weights
-    # a few hundred host threads on these op sizes is slower than a few dozen (oversubscription): use
-    # at most 32 and report the number actually used
+    # SURVEY.md section 8(d)(ii) names os.cpu_count() threads; measured on the GPU box's 256 logical cores (profiles/r03_cpu_threads.md) the
+    # step takes 2.23 s with 32 threads, 2.93 s with 64, 5.5 s with 128 and 58.7 s with 256: the FASTEST setting is used (the most
+    # favourable one for the CPU) and the number actually used is reported
     total = os.cpu_count() or 1
     cores = min(total, 32)
     torch.set_num_threads(cores)
     w = {k: torch.from_numpy(v) for k, v in weights.make_weights(cfg).items()}
     res = {}
-    # batch 8 costs ~20 s per step on a 64-core host: by default it gets 1 warm-up + 2 timed steps (the batch-1 leg keeps the
-    # full 2 + `steps`); --cpu-steps >= 8 asks for the full protocol on both
+    # batch 8 costs ~20 s per step: by default it gets 1 warm-up + 2 timed steps (the batch-1 leg keeps the full 2 + `steps`) so that the
+    # default run stays inside the bench contract's "10-30 s of CPU work, a few minutes in all"; --cpu-steps >= 8 runs the full protocol on
+    # both legs.  The oracle gains nothing from batching, so `value` is the batch-1 figure either way (profiles/r03_cpu_threads.md)
     for B, n_warm, n_steps in ((1, 2, steps), (8, 2 if steps >= 8 else 1, steps if steps >= 8 else 2)):
         img = torch.from_numpy(synth.make_images(cfg, B))
         labels, boxes = synth.make_targets(cfg, B, max_boxes=16)

@@ -49,7 +49,7 @@ int owl_abi_version(void);
  * tile: kernel choice, per call (no global state): 0 = automatic (large shapes: 256x256x64 tiles on the two-phase ping-pong schedule, 8 waves,
  *       gemm_pp2.hip -- for narrow outputs with the remainder round on half-height 128x256 tiles --; 128x128x64 otherwise); tests and tools pin one
  *       kernel with 128 | 256 (single-phase) | 8 (four-phase ping-pong, never split) | 9 (four-phase ping-pong + half-height remainder wherever it
- *       fits) | 7 (two-phase ping-pong on the whole problem) | 4 (experimental four-wave).  All give identical bits.                           */
+ *       fits) | 7 (two-phase ping-pong on the whole problem) | 4 (experimental four-wave; OWL_TUNING builds only).  All give identical bits.                           */
 int owl_gemm_nt_bf16(void* stream, int epi, const void* A, int64_t lda, int64_t a_rows, const void* W, int64_t ldw, int64_t w_rows, const float* bias, void* out, int64_t ldo, const float* resid, void* aux, int64_t ld_aux, int64_t M, int64_t N, int64_t K, float alpha, int splits, int64_t Tp, int tile);
 /* epi 11 = split-K partial slabs out[split][M][ldo] (f32, no atomics); reduce them with owl_slab_reduce */
 int owl_gemm_effective_splits(int64_t K, int splits);
@@ -132,11 +132,15 @@ int owl_push_pull_loss_bwd(void* stream, const float* g4, const int64_t* target_
  * main.py:114-117).  Per image: score = max_c sims, class = first arg-max, keep score > conf_thr, class-aware NMS
  * (torchvision.ops.batched_nms semantics: same class, IoU > iou_thr, lower score suppressed), results ordered by
  * descending score (ties: ascending patch index), at most max_out per image.
+ * route: which of torchvision's two batched_nms routes -- 0 per class on the raw coordinates (_batched_nms_vanilla), 1 coordinate
+ * offset boxes + class * (max + 1) then one class-agnostic NMS (_batched_nms_coordinate_trick), 2 / 3 torchvision's own choice for a
+ * GPU / CPU tensor (coordinate trick up to 20 000 / 4 000 coordinates past the threshold).  They differ only where the f32 rounding of
+ * the shifted coordinates moves an IoU across the threshold.
  * boxes [B,P,4] f32 xyxy, sims [B,P,C] f32 -> out_boxes [B,max_out,4], out_scores [B,max_out], out_classes [B,max_out] i64,
  * out_patch [B,max_out] i64 (source patch index), out_count [B] i32; entries beyond the count are left untouched.
  * workspace: device scratch of owl_postprocess_workspace() bytes (16-byte aligned); `bytes` is a HOST pointer.     */
 int owl_postprocess_workspace(int64_t B, int64_t P, int64_t* bytes);
-int owl_postprocess(void* stream, const float* boxes, const float* sims, void* workspace, int64_t ws_bytes, float* out_boxes, float* out_scores, int64_t* out_classes, int64_t* out_patch, int* out_count, int64_t B, int64_t P, int64_t C, int64_t max_out, float conf_thr, float iou_thr);
+int owl_postprocess(void* stream, const float* boxes, const float* sims, void* workspace, int64_t ws_bytes, float* out_boxes, float* out_scores, int64_t* out_classes, int64_t* out_patch, int* out_count, int64_t B, int64_t P, int64_t C, int64_t max_out, float conf_thr, float iou_thr, int route);
 
 /* ---- device input pipeline (ref src/dataset.py:69-71: HF OwlViTImageProcessor = PIL bicubic resize -> x(1/255) ->
  * (x-mean)/std).  owl_bicubic_coeffs is HOST-side (all pointers host): Pillow's Resample.c tap tables for one axis,

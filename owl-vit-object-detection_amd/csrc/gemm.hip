@@ -338,10 +338,14 @@ extern "C" int owl_gemm_nt_bf16(void* stream, int epi, const void* A, int64_t ld
     const bool split_ok = (epi == EPI_ATOMIC_F32 || epi == EPI_SLAB_F32);
     OWL_CHECK_ARG(splits == 1 || split_ok, "owl_gemm_nt_bf16: split-K needs the atomic or slab epilogue");
     // bf16-output epilogues on big problems run the ping-pong schedule (gemm_pp.hip): 13-26 % faster, bit-identical
-    if (g_force_tile == 4 && K >= 128) {                 // experimental four-wave kernel (tuning A/B only)
+#ifdef OWL_TUNING
+    if (g_force_tile == 4 && K >= 128) {                 // experimental four-wave kernel (tuning builds only)
         const int rc = owl_gemm_w4_launch(s, epi, p);
         if (rc <= 0) return rc;
     }
+#else
+    OWL_CHECK_ARG(tile != 4, "owl_gemm_nt_bf16: tile 4 (experimental four-wave kernel) exists only in an OWL_TUNING build");
+#endif
     if (g_force_tile == 7 && K >= 128) {                 // two-phase ping-pong kernel on the whole problem (A/B; falls through for other epilogues)
         const int rc = owl_gemm_pp2_launch(s, epi, p);
         if (rc <= 0) return rc;

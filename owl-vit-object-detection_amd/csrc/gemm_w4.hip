@@ -16,6 +16,7 @@
 // 910 / 1000 / 930 / 1096 for out-proj / QK / fc1 / fc2.  Staggering the pieces per wave (wave w issues after the (w+1)-th
 // MFMA of every group of four, one scalar branch per MFMA) measured WORSE (1088 at 8192^3).  NOT the default; kept as the starting point for round 2
 // (stagger the pieces per wave, a leaner epilogue, 3 LDS stages of BK = 32).
+#ifdef OWL_TUNING   // experimental kernel: part of tuning builds only (tools/w4_bench.py); the shipped library does not carry it
 #include "gemm_common.h"
 #include <type_traits>
 
@@ -223,3 +224,5 @@ int owl_gemm_w4_launch(hipStream_t s, int epi, const GemmP& p) {
         default: return 1;
     }
 }
+
+#endif  // OWL_TUNING

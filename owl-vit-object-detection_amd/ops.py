@@ -217,7 +217,10 @@ def attention_bwd(qkv, dO, O, lse, dvec, dqkv, B, H, T, Tp, scale):
 _pp_ws = {}
 
 
-def postprocess(boxes, sims, max_out, conf_thr, iou_thr):
+NMS_ROUTES = {"per_class": 0, "coordinate_offset": 1, "torchvision_gpu": 2, "torchvision_cpu": 3}
+
+
+def postprocess(boxes, sims, max_out, conf_thr, iou_thr, route="torchvision_gpu"):
     """owl_postprocess: boxes [B,P,4] f32, sims [B,P,C] f32 -> (boxes [B,K,4], classes [B,K] i64 (-1 pad), scores [B,K]
     (0 pad), patch [B,K] i64 (-1 pad), counts [B] i32) with K = max_out.  ref src/models.py:127-146."""
     B, P, C = sims.shape
@@ -234,7 +237,7 @@ def postprocess(boxes, sims, max_out, conf_thr, iou_thr):
     out_patch = torch.full((B, max_out), -1, dtype=torch.int64, device=dev)
     counts = torch.zeros(B, dtype=torch.int32, device=dev)
     _lib.call("owl_postprocess", stream(), boxes, sims, ws, ws.numel(), out_boxes, out_scores, out_classes, out_patch, counts,
-              B, P, C, max_out, conf_thr, iou_thr)
+              B, P, C, max_out, conf_thr, iou_thr, NMS_ROUTES[route])
     return out_boxes, out_classes, out_scores, out_patch, counts
 
 

@@ -9,6 +9,14 @@ score, as ``torchvision.ops.batched_nms`` returns them).  Additions are keyword-
 * batch > 1 -- returns padded ``[B, Kmax, ...]`` tensors (classes padded with -1, scores with 0) and leaves the
   per-image counts in ``self.last_counts`` (device i32) -- with ``top_k`` given there is NO host sync at all.
 
+* ``nms_route`` (constructor) -- ``torchvision.ops.batched_nms`` has two routes and picks by tensor size and device
+  (torchvision/ops/boxes.py): per class on the raw coordinates, or all classes at once on ``boxes + class * (max + 1)``.
+  The default ``"torchvision_gpu"`` does what torchvision does for a tensor on a GPU -- where the reference's eval loop
+  runs (main.py:30,105-111): the coordinate trick up to 20 000 box coordinates past the threshold, i.e. always for
+  OWL-ViT's <= 3600 boxes; ``"torchvision_cpu"`` mirrors the CPU path (per class above 1000 boxes); ``"per_class"`` /
+  ``"coordinate_offset"`` pin one.  The routes only differ where the f32 rounding of the shifted coordinates moves an
+  IoU across the threshold.
+
 All arithmetic runs in ``owl_postprocess`` (csrc/postprocess.hip): one sort launch, one pair-mask launch, one scan
 launch.  No CPU fallback.
 """
@@ -18,9 +26,12 @@ from . import ops
 
 
 class PostProcess:
-    def __init__(self, confidence_threshold=0.75, iou_threshold=0.3):   # ref models.py:123-125 (same defaults)
+    def __init__(self, confidence_threshold=0.75, iou_threshold=0.3, *, nms_route="torchvision_gpu"):   # ref models.py:123-125 (same defaults)
+        if nms_route not in ops.NMS_ROUTES:
+            raise ValueError(f"PostProcess: nms_route must be one of {sorted(ops.NMS_ROUTES)}")
         self.confidence_threshold = confidence_threshold
         self.iou_threshold = iou_threshold
+        self.nms_route = nms_route
         self.last_counts = None
         self.last_patch_idx = None
 
@@ -34,7 +45,7 @@ class PostProcess:
         max_out = int(top_k) if top_k is not None else P
         boxes, classes, scores, patch, counts = ops.postprocess(
             all_pred_boxes.detach().float().contiguous(), pred_classes.detach().float().contiguous(),
-            max_out, float(self.confidence_threshold), float(self.iou_threshold))
+            max_out, float(self.confidence_threshold), float(self.iou_threshold), self.nms_route)
         self.last_counts, self.last_patch_idx = counts, patch
         if B == 1:                                  # the reference's contract: variable-length, one host read-back
             k = int(counts[0].item())

@@ -34,12 +34,22 @@ tv_ops.box_area = lambda b: (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
 tv_ops.nms = None
 
 
+_NMS_ROUTE = ["per_class"]        # f6 runs the reference once per torchvision route
+
+
 def _stub_batched_nms(boxes, scores, idxs, iou_threshold):
-    """torchvision.ops.batched_nms is absent here; its published algorithm (per class: greedy NMS by descending
-    score on raw coordinates, suppress IoU > thr; result ordered by descending score) restated in plain torch so
-    that the reference's PostProcess (src/models.py:122-146) can run for fixture F6.  The NMS arithmetic in F6 is
-    therefore NOT torchvision's own ("parity unpinned" for that dependency); what F6 pins is everything the
-    reference itself does around it: the max / threshold / indexing / ordering / output shapes."""
+    """torchvision.ops.batched_nms is absent here; its published algorithm (torchvision/ops/boxes.py) restated in plain
+    torch so that the reference's PostProcess (src/models.py:122-146) can run for fixture F6 -- both routes torchvision
+    has: `_batched_nms_vanilla` (per class: greedy NMS by descending score on raw coordinates, suppress IoU > thr) and
+    `_batched_nms_coordinate_trick` (boxes + class * (boxes.max() + 1), one class-agnostic NMS); result ordered by
+    descending score.  The NMS arithmetic in F6 is therefore NOT torchvision's own ("parity unpinned" for that
+    dependency); what F6 pins is everything the reference itself does around it: the max / threshold / indexing /
+    ordering / output shapes -- and, between the two routes, how many keep decisions the shifted coordinates flip."""
+    if _NMS_ROUTE[0] == "coordinate_offset" and boxes.numel() > 0:
+        max_coordinate = boxes.max()
+        offsets = idxs.to(boxes) * (max_coordinate + torch.tensor(1).to(boxes))
+        boxes = boxes + offsets[:, None]
+        idxs = torch.zeros_like(idxs)
     n = boxes.shape[0]
     keep_mask = torch.zeros(n, dtype=torch.bool)
     area = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
@@ -360,13 +370,27 @@ def f6():
     with torch.no_grad():
         pb, _, ps, _ = model(torch.from_numpy(synth.make_images(cfg, 1, 3)))
     cases.append((pb[0].numpy().copy(), ps[0].numpy().copy(), 0.01, 0.6))
+    # near-ties for the coordinate-offset route: pairs of same-class boxes whose IoU sits within a few f32 ulps of the threshold
+    nt_b, nt_s = synth_case(2304, 10, False)
+    thr = np.float32(0.6)
+    for q in range(0, 2300, 2):
+        x1, y1, x2, y2 = nt_b[q]
+        w = x2 - x1
+        # second box = the first shifted right by d: IoU = (w - d) / (w + d) = thr (+- rounding)  ->  d = w (1 - thr) / (1 + thr)
+        d = np.float32(w * (np.float32(1) - thr) / (np.float32(1) + thr)) * np.float32(1 + (rng_.integers(-3, 4)) * 2.0 ** -22)
+        nt_b[q + 1] = [x1 + d, y1, x2 + d, y2]
+        nt_s[q + 1] = nt_s[q] - np.float32(1e-3)
+    cases.append((nt_b, nt_s, 0.01, 0.6))
     for k, (boxes, sims, conf, iou) in enumerate(cases):
-        pp = RefPostProcess(confidence_threshold=conf, iou_threshold=iou)
-        ob, oc, os_ = pp(torch.from_numpy(boxes)[None].clone(), torch.from_numpy(sims)[None].clone())
         res[f"boxes_{k}"] = boxes; res[f"sims_{k}"] = sims
         res[f"conf_{k}"] = np.float32(conf); res[f"iou_{k}"] = np.float32(iou)
-        res[f"out_boxes_{k}"] = ob.numpy(); res[f"out_classes_{k}"] = oc.numpy(); res[f"out_scores_{k}"] = os_.numpy()
-        print("f6 case", k, "kept", ob.shape[1], "of", boxes.shape[0])
+        for route, tag in (("per_class", "out"), ("coordinate_offset", "off_out")):
+            _NMS_ROUTE[0] = route
+            pp = RefPostProcess(confidence_threshold=conf, iou_threshold=iou)
+            ob, oc, os_ = pp(torch.from_numpy(boxes)[None].clone(), torch.from_numpy(sims)[None].clone())
+            res[f"{tag}_boxes_{k}"] = ob.numpy(); res[f"{tag}_classes_{k}"] = oc.numpy(); res[f"{tag}_scores_{k}"] = os_.numpy()
+            print("f6 case", k, route, "kept", ob.shape[1], "of", boxes.shape[0])
+    _NMS_ROUTE[0] = "per_class"
     res["n_cases"] = np.int64(len(cases))
     np.savez_compressed(os.path.join(HERE, "f6_postprocess.npz"), **res)
 

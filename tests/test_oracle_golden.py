@@ -170,9 +170,14 @@ def test_trainable_set_matches_freeze_rule():
 def test_postprocess_oracle_vs_reference_f6(golden_dir):
     """oracle.post_process vs the reference's PostProcess outputs (ref src/models.py:122-146), fixture F6."""
     z = np.load(os.path.join(golden_dir, "f6_postprocess.npz"))
+    flips = []
     for k in range(int(z["n_cases"])):
-        eb, ec, es, _ = O.post_process(z[f"boxes_{k}"], z[f"sims_{k}"], float(z[f"conf_{k}"]), float(z[f"iou_{k}"]))
-        assert z[f"out_boxes_{k}"].shape == (1, len(es), 4) and z[f"out_classes_{k}"].shape == (1, len(es))
-        assert np.array_equal(ec, z[f"out_classes_{k}"][0])
-        assert np.array_equal(es, z[f"out_scores_{k}"][0])
-        assert np.array_equal(eb, z[f"out_boxes_{k}"][0])
+        for route, tag in (("per_class", "out"), ("coordinate_offset", "off_out")):      # torchvision's two batched_nms routes
+            eb, ec, es, _ = O.post_process(z[f"boxes_{k}"], z[f"sims_{k}"], float(z[f"conf_{k}"]), float(z[f"iou_{k}"]), route=route)
+            assert z[f"{tag}_boxes_{k}"].shape == (1, len(es), 4) and z[f"{tag}_classes_{k}"].shape == (1, len(es))
+            assert np.array_equal(ec, z[f"{tag}_classes_{k}"][0])
+            assert np.array_equal(es, z[f"{tag}_scores_{k}"][0])
+            assert np.array_equal(eb, z[f"{tag}_boxes_{k}"][0])
+        flips.append(abs(z[f"out_scores_{k}"].shape[1] - z[f"off_out_scores_{k}"].shape[1]))
+    # ordinary cases: the two routes keep the same boxes; the near-tie case (pairs within a few ulps of the IoU threshold) is where they part
+    assert flips[:-1] == [0] * (len(flips) - 1) and flips[-1] > 0
