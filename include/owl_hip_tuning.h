@@ -16,6 +16,16 @@ int owl_gemm_debug_nostore(int on);
 int owl_gemm_debug_slots(int n);
 /* attention forward: bit 0 always rescale, bit 1 plain block mapping, bit 2 the first tile always sets the softmax offset */
 int owl_attention_debug(int flags);
+/* two-phase ping-pong GEMM: device buffer of 128 x u64 -- while set, bias-epilogue launches run the s_memtime-stamped kernel (tools/pp2_trace.py); NULL = off */
+/* two-phase ping-pong GEMM: persistent grid size (default 256 = one workgroup per CU; multiples of 8) */
+int owl_gemm_pp2_slots(int n);
+/* ... 1: skip every epilogue store of that kernel (tools/gemm_nostore_ab.py) */
+int owl_gemm_pp2_nostore(int on);
+int owl_gemm_pp2_trace(void* buf);
+/* ... which of workgroup 0's tiles is stamped (0 = its first; later tiles see the sustained clock and warm queues) */
+int owl_gemm_pp2_trace_tile(int n);
+/* ... and which K-tile of it (default 4; 0-2 show the refill behind the previous tile's epilogue) */
+int owl_gemm_pp2_trace_ktile(int n);
 #ifdef __cplusplus
 }
 #endif

@@ -31,7 +31,8 @@ __device__ __forceinline__ void q_bar() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int EPI>
+// TRACE (OWL_TUNING builds, tools/pp2_trace.py): workgroup 0 stamps s_memtime at every LOAD / wait / barrier / MFMA boundary of K-tile 4 of its first tile
+template <int EPI, bool TRACE = false>
 __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63;
@@ -156,6 +157,11 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
     q_bar();
 
     int cur = 0, tile_parity = 0;
+    const bool tr_wg = TRACE && blockIdx.x == 0;
+    bool tr_first = false;          // armed at the workgroup's (p.dbg >> 8)-th tile: the first tile of a launch runs at boost clock with cold queues
+    int tr_tile = 0;
+    if (TRACE && (p.dbg >> 8) == 0) tr_first = true;
+    unsigned long long tr_ts[12] = {};
     bool a_early = false;            // the A pieces of the next tile's K-tile 1 went out before this tile's epilogue stores
     int pending_stores = 0;          // epilogue stores issued after them (known counts only; otherwise the epilogue is followed by a full wait)
     // Store-bound epilogue (bias): group 1 runs ONE barrier interval behind group 0 for the WHOLE persistent loop -- the epilogue is just
@@ -165,7 +171,15 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
     // re-synchronised at every tile as in gemm_pp.hip -- group 0 waits for group 1's last MFMA phase, both run their epilogues in one interval.
     constexpr bool STAGGERED_EPI = (EPI == EPI_BIAS_BF16 || EPI == EPI_F32 || EPI == EPI_ACC_F32 || EPI == EPI_PATCH_F32 || EPI == EPI_PATCHM_F32);
     if (STAGGERED_EPI && grp == 1) q_bar();
+    unsigned long long wg_t0 = 0;
+    unsigned long long wg_r0 = 0;          // s_memrealtime: 100 MHz, one counter for the chip -- comparable across workgroups
+    if constexpr (TRACE) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(wg_t0), "=s"(wg_r0) :: "memory");
+    unsigned long long tile_ts[5] = {};
+    auto tile_stamp = [&](int i) {
+        if constexpr (TRACE) { if (tr_wg && tr_first) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tile_ts[i]) :: "memory"); }
+    };
     while (true) {
+        tile_stamp(0);
         f32x16 acc[4][2];
 #pragma unroll
         for (int i = 0; i < 4; i++)
@@ -176,8 +190,20 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
         int tm, tn; decode(item, tm, tn);
         const int64_t cm0 = (int64_t)tm * QBM, cn0 = (int64_t)tn * QBN;
         if (!STAGGERED_EPI && grp == 1) q_bar();     // (re-)create the one-barrier offset
+        tile_stamp(1);
         for (int kt = 0; kt < nk; kt++) {
             const unsigned char* tb = lds + cur * Q_STAGE;
+            auto stamp = [&](int idx) {               // (issued without waiting for the result: a waited stamp costs ~140 cycles)
+                if constexpr (TRACE) {
+                    if (tr_wg && tr_first && kt == ((p.dbg >> 4) & 15)) {
+                        // (stamps 0 / 2 / 7 / 10 sit where no LDS read is in flight and are waited for: the un-waited result of a stamp in front of the
+                        //  staging code is lost when hipcc moves its SGPR pair before the value has landed; 1 and 6 are not recorded)
+                        if (idx == 1 || idx == 6) return;
+                        if (idx == 0 || idx == 2 || idx == 7 || idx >= 10) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr_ts[idx]));
+                        else asm volatile("s_memtime %0" : "=s"(tr_ts[idx]));
+                    }
+                }
+            };
             bf16x8 fa[2][4], fb[2][4];                // [row tile of the phase][kc], [j][kc]
             auto ld_a = [&](int ih) {
 #pragma unroll
@@ -198,6 +224,7 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
                 __builtin_amdgcn_s_setprio(0);
             };
             // ---- phase A ----
+            stamp(0);
 #pragma unroll
             for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -205,14 +232,20 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
             ld_a(0);
             if (a_early) a_early = false;             // (requested ahead of the previous tile's epilogue)
             else if (a_item < item_end) stage_A();    // A rows of the OTHER buffer: released by both groups' LOAD B of the previous K-tile
+            stamp(1);
             q_wait_lgkm();
+            stamp(2);
             q_bar();
+            stamp(3);
             mma(0);
+            stamp(4);
             q_bar();
+            stamp(5);
             // ---- phase B ----
             ld_a(1);
             int n_new = 0;
             if (b_item < item_end) n_new = stage_B();   // B rows of THIS buffer: both groups have run LOAD A
+            stamp(6);
             // K-tile kt+1 complete: all but the pieces just requested -- and, in a tile's first K-tile, the previous tile's epilogue stores, which
             // are younger than the A pieces of K-tile 1 (vmcnt is one in-order counter for loads and stores)
             switch (n_new + pending_stores) {
@@ -223,11 +256,22 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
                 default: q_wait<0>(); break;
             }
             pending_stores = 0;
+            stamp(7);
             q_bar();
+            stamp(8);
             mma(1);
+            stamp(9);
             q_bar();
+            stamp(10);
+            if constexpr (TRACE) {
+                if (tr_wg && tr_first && kt == ((p.dbg >> 4) & 15) && lane == 0) {
+#pragma unroll
+                    for (int i = 0; i < 11; i++) ((unsigned long long*)(lds + Q_LDS))[w * 16 + i] = tr_ts[i];
+                }
+            }
             cur ^= 1;
         }
+        tile_stamp(2);
         if (!STAGGERED_EPI && grp == 0) q_bar();     // let group 1 finish its last MFMA phase: epilogues run together
         const bool inner = (cm0 + QBM <= p.M) && (cn0 + QBN <= p.N);
         // The next tile's K-tile 1 goes into the buffer the last K-tile just left (its A rows: both groups are past LOAD B).  Its A pieces are
@@ -264,13 +308,44 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
                 }
         };
         if (inner) run(std::false_type{}); else run(std::true_type{});
+        tile_stamp(4);                               // (conversion done, every store of the tile issued)
         if (STAGGERED_EPI) q_bar();                  // the epilogue interval
+        tile_stamp(3);
+        if constexpr (TRACE) {
+            if (tr_wg && tr_first) {
+                if (lane == 0) {
+#pragma unroll
+                    for (int i = 0; i < 5; i++) ((unsigned long long*)(lds + Q_LDS))[w * 16 + 11 + i] = tile_ts[i];
+                }
+                __syncthreads();
+                if (threadIdx.x < 128) ((unsigned long long*)p.aux)[threadIdx.x] = ((unsigned long long*)(lds + Q_LDS))[threadIdx.x];
+                tr_first = false;
+            }
+            if (tr_wg && ++tr_tile == (p.dbg >> 8) && !tr_first) tr_first = true;
+        }
         item += item_step;
         if (item >= item_end) break;
         tile_parity ^= 1;
     }
     if (STAGGERED_EPI && grp == 0) q_bar();          // group 1's last interval
+    if constexpr (TRACE) {          // every workgroup: ticks from its first instruction to its last, and when it started
+        unsigned long long wg_t1, wg_r1;
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(wg_t1), "=s"(wg_r1) :: "memory");
+        if (threadIdx.x == 0) {
+            ((unsigned long long*)p.aux)[128 + blockIdx.x] = wg_t1 - wg_t0; ((unsigned long long*)p.aux)[128 + 256 + blockIdx.x] = wg_r0;
+            ((unsigned long long*)p.aux)[128 + 512 + blockIdx.x] = wg_r1;
+        }
+    }
 }
+
+#ifdef OWL_TUNING
+static int g_pp2_nostore = 0;            // 1: every epilogue store skipped (upper bound on what the store path costs)
+extern "C" int owl_gemm_pp2_nostore(int on) { g_pp2_nostore = on; return 0; }
+static int g_pp2_slots = 256;            // persistent grid size (tools/: does a GEMM on half the CUs beside the other stream's kernel pay?)
+extern "C" int owl_gemm_pp2_slots(int n) { g_pp2_slots = n; return 0; }
+#else
+static constexpr int g_pp2_slots = 256;
+#endif
 
 template <int EPI>
 static int launch_pp2(hipStream_t s, GemmP p) {
@@ -290,14 +365,39 @@ static int launch_pp2(hipStream_t s, GemmP p) {
         for (int d = 4; d >= 1; d--)
             if (p.tiles_n % d == 0) { p.nsplit = d; break; }
     const int nitems = p.tiles_m * p.tiles_n;
-    p.persistent = nitems > 256 ? 1 : 0;
-    hipLaunchKernelGGL((gemm_pp2_kernel<EPI>), dim3(p.persistent ? 256 : nitems), dim3(512), Q_LDS, s, p);
+#ifdef OWL_TUNING
+    if (g_pp2_nostore) p.M = 0;             // (after the tile counts: every store fails its row guard)
+#endif
+    p.persistent = nitems > g_pp2_slots ? 1 : 0;
+    hipLaunchKernelGGL((gemm_pp2_kernel<EPI>), dim3(p.persistent ? g_pp2_slots : nitems), dim3(512), Q_LDS, s, p);
     OWL_LAUNCH_CHECK();
     return 0;
 }
 
+#ifdef OWL_TUNING
+static void* g_pp2_trace = nullptr;      // device buffer of 128 x u64: the next bias-epilogue launch runs the stamped kernel (tools/pp2_trace.py)
+static int g_pp2_trace_tile = 0, g_pp2_trace_kt = 4;
+extern "C" int owl_gemm_pp2_trace(void* buf) { g_pp2_trace = buf; return 0; }
+extern "C" int owl_gemm_pp2_trace_tile(int n) { g_pp2_trace_tile = n; return 0; }
+extern "C" int owl_gemm_pp2_trace_ktile(int n) { g_pp2_trace_kt = n; return 0; }
+#endif
+
 // called from gemm.hip's dispatcher; returns 1 if this variant does not handle `epi`
 int owl_gemm_pp2_launch(hipStream_t s, int epi, const GemmP& p) {
+#ifdef OWL_TUNING
+    if (g_pp2_trace && epi == EPI_BIAS_BF16) {
+        GemmP q = p;
+        q.aux = nullptr;
+        (void)hipFuncSetAttribute((const void*)gemm_pp2_kernel<EPI_BIAS_BF16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS + 2048);
+        q.tiles_m = (int)((q.M + QBM - 1) / QBM); q.tiles_n = (int)((q.N + QBN - 1) / QBN); q.dbg = (g_pp2_trace_tile << 8) | ((g_pp2_trace_kt & 15) << 4); q.nsplit = q.tiles_n;
+        for (int d = 4; d >= 1; d--) if (q.tiles_n % d == 0) { q.nsplit = d; break; }
+        const int nitems = q.tiles_m * q.tiles_n;
+        q.persistent = nitems > 256 ? 1 : 0;
+        GemmP qq = q; qq.aux = g_pp2_trace;           // (the bias epilogue never reads aux; PLAIN_EPI's early A staging is off with aux set -- fine for a trace)
+        hipLaunchKernelGGL((gemm_pp2_kernel<EPI_BIAS_BF16, true>), dim3(q.persistent ? 256 : nitems), dim3(512), Q_LDS + 2048, s, qq);
+        return 0;
+    }
+#endif
     switch (epi) {
         case EPI_BIAS_BF16: return launch_pp2<EPI_BIAS_BF16>(s, p);
         case EPI_QGELU_BF16: return launch_pp2<EPI_QGELU_BF16>(s, p);
