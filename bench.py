@@ -88,8 +88,8 @@ def parse():
                     help="lists = per-image label/box lists through PushPullLoss.__call__ as ref main.py:77-83 (headline); "
                          "packed = targets padded once outside the timed region (diagnostic)")
     ap.add_argument("--no-compare", action="store_true", help="skip the second (other --targets mode) measurement")
-    ap.add_argument("--overlap", action="store_true", help="all-reduce + AdamW on a side stream under the next step's frozen prefix "
-                                                           "(default with more than one rank: it hides the ring time; bitwise the in-line result)")
+    ap.add_argument("--overlap", action="store_true", help="backward + all-reduce + AdamW on the model's tail stream under the next step's frozen prefix "
+                                                           "(models.OwlViT.overlap_tail; bitwise the in-line result)")
     ap.add_argument("--no-overlap", action="store_true", help="in-line all-reduce + AdamW even with more than one rank")
     ap.add_argument("--no-kernel-events", action="store_true", help="no HIP events around the GEMM / attention launches (overhead A/B)")
     ap.add_argument("--encoder-streams", type=int, default=2,
@@ -311,8 +311,13 @@ def main():
             # event-to-event time is not the kernel's own duration.
             kt.on = record and (i % EVENT_EVERY == 0)
             model.encoder_streams = 1 if kt.on else args.encoder_streams
+            if dp.overlap:                   # ... and in-line, behind the previous step's deferred tail, for the same reason
+                model.overlap_tail = not kt.on
+                if kt.on:
+                    model.finish()
             step(warmup + i, mode)
         model.encoder_streams = args.encoder_streams
+        model.overlap_tail = dp.overlap
         dp.finish()
         torch.cuda.synchronize()
         if world > 1:
@@ -347,7 +352,7 @@ def main():
                        "global_batch": B * world, "tokens": cfg.tokens, "parallelism": f"dp{world}",
                        "targets": args.targets + (" (per-image label/box lists through PushPullLoss.__call__, ref main.py:77-83)" if args.targets == "lists" else " (pre-padded)"),
                        "encoder_streams": args.encoder_streams,
-                       "optimizer_schedule": "side-stream all-reduce + AdamW under the next step's frozen prefix" if dp.overlap else "in-line",
+                       "optimizer_schedule": "backward + all-reduce + AdamW on the tail stream under the next step's frozen prefix (bitwise the in-line schedule)" if dp.overlap else "in-line",
                        "gflop_per_image": round(flops_img / 1e9, 1),
                        "step_mfma_frac": round(flops_img * value / world / 1e12 / PEAK_BF16_TFLOPS, 4)},
             "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,

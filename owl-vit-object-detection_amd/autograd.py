@@ -60,7 +60,20 @@ class OwlViTFunction(torch.autograd.Function):
                 f"OwlViT backward: the activations of this forward (batch size {B}) were overwritten by a later gradient-recording "
                 "forward at the same batch size (or evicted: only the model's `max_cached_batch_sizes` most recent batch sizes keep their "
                 "workspaces); call backward() before the next training forward (no-grad / eval forwards are fine)")
-        backward_impl(model, B, d_boxes, d_sims, ctx.sims)
+        if getattr(model, "overlap_tail", False) and d_boxes.is_cuda:
+            # deferred tail (models.OwlViT.overlap_tail): the whole backward goes to the tail stream; the compute stream carries on with whatever
+            # the caller enqueues next (the next forward's frozen prefix) and waits for the event where it touches a trainable tensor
+            main, ts = torch.cuda.current_stream(), model._tail_stream
+            ts.wait_stream(main)
+            for t in (d_boxes, d_sims, ctx.sims):
+                t.record_stream(ts)               # (allocated on the compute stream, read on the tail stream)
+            with torch.cuda.stream(ts):
+                backward_impl(model, B, d_boxes, d_sims, ctx.sims)
+                ev = torch.cuda.Event()
+                ev.record(ts)
+            model._param_event = ev
+        else:
+            backward_impl(model, B, d_boxes, d_sims, ctx.sims)
         return (None, None) + (None,) * len(model.flat_offsets)
 
 
@@ -172,8 +185,11 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
     # scratch) the class head's backward runs on the side stream with its own slab / reduction / transposed-weight scratch, beside the box
     # head's on this one; the box head's last GEMM accumulates into d(feats) behind the class head's event.  Same kernels, same order of the
     # two contributions: same bits.
+    # (streams: in-line, the backward shares the forward's side streams; as a deferred tail -- models.OwlViT.overlap_tail -- it has side streams
+    #  and fork / join events of its own, because the next forward is using the model's while this runs)
+    S, J, fork = model._bwd_streams()
     main0 = torch.cuda.current_stream()
-    hs = model._side_stream(1) if (model.head_streams and model.encoder_streams > 1 and len(model._encoder_chunks(B)) > 1 and bw["tn_all"]) else main0
+    hs = S(1) if (model.head_streams and model.encoder_streams > 1 and len(model._encoder_chunks(B)) > 1 and bw["tn_all"]) else main0
     ev_h = model._dw_events
     if hs is not main0:
         ev_h[0].record(main0)
@@ -201,7 +217,7 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
         main0.wait_event(ev_h[1])                 # d(feats) of the class head is in place (and the side stream's scratch is free again)
     ops.gemm(ops.EPI_ACC_F32, bw["du0"], w0T, bw["dfeats"], M=Mh, N=D, K=D)
     # ---- merge + the two final LayerNorms --------------------------------------------------------------
-    ops.merge_ln_bwd(bw["dfeats"], ws["x"], ws["cls_ln"], ws["st_post"], ws["st_pp"], P_["backbone.post_layernorm.weight"],
+    ops.merge_ln_bwd(bw["dfeats"], ws["x_fin"], ws["cls_ln"], ws["st_post"], ws["st_pp"], P_["backbone.post_layernorm.weight"],
                      P_["backbone.post_layernorm.bias"], P_["post_post_layernorm.weight"], bw["dx"], bw["dcls"],
                      G("backbone.post_layernorm.weight"), G("backbone.post_layernorm.bias"), G("post_post_layernorm.weight"),
                      G("post_post_layernorm.bias"), B, P, Tp, D, partials=bw["part"], dx_bf16=bw["dxb"],
@@ -215,11 +231,11 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
     if len(upper) > 0:
         chunks = model._encoder_chunks(B)
         main = torch.cuda.current_stream()
-        streams = [main] + [model._side_stream(c) for c in range(1, len(chunks))]
+        streams = [main] + [S(c) for c in range(1, len(chunks))]
         if len(chunks) > 1:
-            model._fork_ev.record(main)
+            fork.record(main)
             for s_ in streams[1:]:
-                s_.wait_event(model._fork_ev)
+                s_.wait_event(fork)
         for i in upper:
             Ls, fz = model._layer_ws(B, i), model._fz
             pre = f"backbone.encoder.layers.{i}."
@@ -240,8 +256,8 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
                                       Mc, D, dx_bf16=R(bw["dxb"]))
         for c, s_ in enumerate(streams):
             if c > 0:
-                model._join[c].record(s_)
-                main.wait_event(model._join[c])
+                J(c).record(s_)
+                main.wait_event(J(c))
     Lt = model._layer_ws(B, cfg.trainable_layer())
     # ---- trainable encoder layer ------------------------------------------------------------------------------
     # Two chains: dX (this stream) and the four weight gradients.  A weight gradient feeds nothing downstream -- it only has to be in the
@@ -250,7 +266,7 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
     # idle, and vice versa.  Same kernels on the same operands: same bits.  The side stream owns the split-K slab from here on and has its
     # own reduction scratch; the second bf16 dx goes to its own buffer because dW(fc2) may still be reading the first.
     main = torch.cuda.current_stream()
-    side = model._side_stream(1) if model.encoder_streams > 1 else main
+    side = S(1) if model.encoder_streams > 1 else main
     evs = model._dw_events
 
     def on_side(k, fn):

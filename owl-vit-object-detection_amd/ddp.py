@@ -93,7 +93,9 @@ class DataParallel:
             if hasattr(model, "refresh_compute_weights"):
                 model.refresh_compute_weights(force=True)
         self.overlap = bool(overlap) and model.flat_grad.is_cuda and self.fused
-        self.side = torch.cuda.Stream(device=model.flat_grad.device) if self.overlap else None
+        if self.overlap:
+            model.overlap_tail = True                   # backward, all-reduce and AdamW all run on the model's tail stream
+        self.side = model._tail_stream if self.overlap else None
         self._checked_batch = False
 
     def check_equal_batches(self, batch_size: int):
@@ -116,14 +118,10 @@ class DataParallel:
             self._step()
             return
         main = torch.cuda.current_stream()
-        self.side.wait_stream(main)                     # backward finished writing the bucket
+        self.side.wait_stream(main)                     # (the backward itself already runs on the tail stream: models.OwlViT.overlap_tail)
         with torch.cuda.stream(self.side):
-            self._step()                                # RCCL + fused AdamW are enqueued on the side stream
-            self.model.flat_grad.zero_()                # next step's zero_grad(), done where nothing races with the reads above
-            ev = torch.cuda.Event()
-            ev.record(self.side)
-        self.model._param_event = ev                    # compute stream waits where the first trainable tensor is read
-        self.model._grad_clean = True
+            allreduce_flat(self.model.flat_grad, self.group)     # RCCL on the tail stream, behind the backward
+        self.optimizer.step()                           # FusedAdamW: update + bucket zeroing on the tail stream, event for the next forward
 
     def finish(self):
         """Make the current stream wait for a deferred step (before reading parameters outside the model's forward)."""

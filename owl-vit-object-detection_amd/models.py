@@ -143,11 +143,19 @@ class OwlViT(nn.Module):
         self._bf16_current = False
         self._bf16_version = None          # flat_param._version at the fused step that set the token
         self.encoder_streams = int(encoder_streams)     # sub-batches of the encoder forward, one HIP stream each (see _forward_impl); 1 = off
-        self._streams, self._join, self._fork_ev = [], {}, None
+        self._streams, self._join, self._fork_ev, self._fork_ev_tail = [], {}, None, None
         self.head_streams = True          # box head / class head (forward and backward) on two streams when the sub-batch streams are on
         self._dw_events_ = None
-        self._param_event = None           # ddp.DataParallel(overlap=True): the deferred all-reduce + AdamW of the previous step
+        self._param_event = None           # the deferred tail of the previous step (backward / all-reduce / AdamW on the tail stream): see overlap_tail
         self._grad_clean = False           # ... which also left flat_grad zeroed for this step
+        # overlap_tail (optim.FusedAdamW(..., overlap=True) / ddp.DataParallel(overlap=True) switch it on): the hand-written backward, the gradient
+        # all-reduce and the fused AdamW of step i run on ONE side stream ("tail stream") while the compute stream already runs the forward of step
+        # i+1 -- embeddings and encoder layers below the trainable one are frozen (ref src/models.py:173-184), so nothing before the trainable layer
+        # depends on the tail; the compute stream waits for it exactly where the first trainable tensor / kept activation is touched (_wait_params).
+        # The tail's small kernels (loss backward, head backward, reductions, transposes: ~1 ms at 32 workgroups or fewer) then run beside the next
+        # forward's GEMMs instead of alone.  Same kernels, same operands, same order per buffer: bitwise the in-line schedule.
+        self.overlap_tail = False
+        self._tail_stream_ = None
         self._trainable = frozenset(order)
         # checkpointing while a deferred optimizer step (ddp.DataParallel(overlap=True)) is still running on its side stream: order the
         # current stream behind it before any parameter is read
@@ -221,7 +229,7 @@ class OwlViT(nn.Module):
         bf, f32 = torch.bfloat16, torch.float32
         z = ops.zeros_rows
         ws = dict(
-            x=z(M, D, f32, dev), h=z(M, D, bf, dev), qkv=z(M, 3 * D, bf, dev),
+            x=z(M, D, f32, dev), x_fin=z(M, D, f32, dev) if train else None, h=z(M, D, bf, dev), qkv=z(M, 3 * D, bf, dev),
             att=z(M, D, bf, dev), g=z(M, I, bf, dev), d1=z(M, D, bf, dev), d2=z(M, D, bf, dev),
             im2row=None if self._patch_fused else z(Mh, self._patch_kpad, bf, dev),
             # heads
@@ -279,6 +287,17 @@ class OwlViT(nn.Module):
                 f"moving / casting the module to {out.device} / {out.dtype} is not supported -- build it with load_model(labelmap, device)")
         return self
 
+    @property
+    def _tail_stream(self):
+        if self._tail_stream_ is None:
+            self._tail_stream_ = torch.cuda.Stream(device=self.device_)
+        return self._tail_stream_
+
+    def finish(self):
+        """Order the current stream behind a deferred tail (overlap_tail): call before reading parameters or gradients outside the model's own
+        forward / backward / zero_grad / state_dict, which do it themselves."""
+        self._wait_params()
+
     def _wait_params(self):
         """Order the compute stream behind a deferred optimizer step (ddp.DataParallel(overlap=True)): called right before the
         first trainable tensor is read, i.e. after the frozen prefix (embeddings + encoder layers below the trainable one)."""
@@ -323,6 +342,17 @@ class OwlViT(nn.Module):
             self._streams.append(torch.cuda.Stream(device=self.device_))
             self._join[len(self._streams)] = torch.cuda.Event()
         return self._streams[c - 1]
+
+    def _bwd_streams(self):
+        """(side stream c, join event c, fork event) as the backward uses them: the forward's own in-line, a disjoint set as a deferred tail."""
+        off = max(self.encoder_streams - 1, 1) if self.overlap_tail else 0
+        if off and self._fork_ev_tail is None:
+            self._fork_ev_tail = torch.cuda.Event()
+        if not off and self._fork_ev is None:
+            self._fork_ev = torch.cuda.Event()
+        S = lambda c: self._side_stream(c + off)
+        J = lambda c: (self._side_stream(c + off), self._join[c + off])[1]
+        return S, J, (self._fork_ev_tail if off else self._fork_ev)
 
     def _encoder_layer(self, i: int, ws, B: int, save: bool, st):
         """Encoder layer i (HF5:478-511) for the sub-batch `st` (images [b0, b0 + nb) = rows [b0 Tp, (b0 + nb) Tp) of every buffer), on the
@@ -449,9 +479,11 @@ class OwlViT(nn.Module):
         #      (ref src/models.py:80-86); the final residual stream is materialised in `x` for the backward
         feats = ws["feats"]
         tv = lambda n: self._tview(n)
+        # (the backward reads the final residual stream; it gets a buffer of its own because with overlap_tail the NEXT forward's patch embedding
+        #  rewrites `x` while this step's backward may still be running)
         ops.merge_ln(xs, P_["backbone.post_layernorm.weight"], P_["backbone.post_layernorm.bias"], P_["post_post_layernorm.weight"],
                      P_["post_post_layernorm.bias"], ws["cls_ln"], feats, ws["st_post"], ws["st_pp"], B, P, Tp, D, cfg.ln_eps,
-                     delta=pending, x_out=x)
+                     delta=pending, x_out=ws["x_fin"] if save else x)
         # The box head and the class head only share their input: with sub-batch streams on, the class head runs on the side stream beside the
         # box head (its kernels fill the CUs the box GEMMs' remainder rounds leave idle).  Outputs are allocated before the fork.
         pred_boxes = torch.empty(B, P, 4, device=self.device_)

@@ -13,8 +13,14 @@ from .autograd import _attach_grads
 
 
 class FusedAdamW:
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, *, overlap: bool = False):
+        """overlap=True (keyword-only addition): backward + this step run on the model's tail stream under the NEXT forward's frozen prefix
+        (models.OwlViT.overlap_tail) -- bitwise the in-line schedule.  The model's own forward / backward / zero_grad / state_dict order
+        themselves behind the deferred tail; anything else that reads `p.grad` or the parameters calls `model.finish()` first (and finds the
+        gradient bucket already zeroed after a step: the zeroing of the next `zero_grad()` is part of the tail)."""
         self.model = model
+        if overlap:
+            model.overlap_tail = True
         self.lr, self.betas, self.eps, self.weight_decay = float(lr), betas, float(eps), float(weight_decay)
         self.exp_avg = torch.zeros_like(model.flat_param)
         self.exp_avg_sq = torch.zeros_like(model.flat_param)
@@ -34,10 +40,27 @@ class FusedAdamW:
         _attach_grads(m)
         m._grad_clean = False
         self.step_count += 1
+        deferred = getattr(m, "overlap_tail", False) and m.flat_param.is_cuda and torch.cuda.current_stream() != m._tail_stream
+        if deferred:
+            # the backward of this step is (or may be) still running on the tail stream: the update and the zeroing of the bucket follow it there
+            ts = m._tail_stream
+            ts.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(ts):
+                self._launch()
+                m.flat_grad.zero_()               # the next zero_grad(), done where nothing races with the reads above
+                ev = torch.cuda.Event()
+                ev.record(ts)
+            m._param_event = ev
+            m._grad_clean = True
+        else:
+            self._launch()
+        m._mark_bf16_current()          # one-shot token for the next forward (models.OwlViT.__init__)
+
+    def _launch(self):
+        m = self.model
         _lib.call("owl_adamw_step", ops.stream(), m.flat_param, m.flat_grad, self.exp_avg, self.exp_avg_sq, m.flat_bf16,
                   m.flat_numel, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count,
                   float(self.grad_scale))
-        m._mark_bf16_current()          # one-shot token for the next forward (models.OwlViT.__init__)
 
     def state_dict(self):
         return dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, lr=self.lr, betas=self.betas,

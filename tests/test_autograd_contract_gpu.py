@@ -121,6 +121,39 @@ def test_overlapped_optimizer_schedule_is_bitwise_the_inline_schedule(cname, B):
     assert float(h0[-1]) < float(h0[0])
 
 
+@pytest.mark.parametrize("cname,B,accumulate", [("tiny", 2, 1), ("small", 2, 1), ("small", 4, 2)])
+def test_deferred_tail_is_bitwise_the_inline_schedule(cname, B, accumulate):
+    """FusedAdamW(overlap=True): backward + AdamW + bucket zeroing on the tail stream, under the next forward's frozen prefix
+    (models.OwlViT.overlap_tail).  Different images every step (the next forward rewrites the residual-stream buffer while the tail may still
+    be running), gradient accumulation (two backwards per step, the second one behind a deferred first), state_dict() in the middle."""
+    def train(overlap, steps=5):
+        cfg, model, img, lab, box, crit = _setup(cname, B)
+        opt = FusedAdamW(model, lr=1e-3, weight_decay=0.1, overlap=overlap)
+        assert model.overlap_tail == overlap
+        g = torch.Generator(device="cpu").manual_seed(7)
+        imgs = [img] + [torch.randn(img.shape, generator=g).to(img.device, img.dtype) for _ in range(steps * accumulate)]
+        hist, k, sd = [], 0, None
+        for s in range(steps):
+            opt.zero_grad()
+            for _ in range(accumulate):
+                pb, _, ps, _ = model(imgs[k]); k += 1
+                loss = _loss(crit, ps, lab, pb, box)
+                loss.backward()
+                hist.append(loss.detach())
+            opt.step()
+            if s == 2:
+                sd = {n: t.clone() for n, t in model.state_dict().items() if n.endswith("queries")}
+        model.finish()
+        torch.cuda.synchronize()
+        return model.flat_param.clone(), torch.stack(hist).cpu(), opt.exp_avg.clone(), sd, model.flat_grad.clone()
+
+    p0, h0, m0, s0, g0 = train(False)
+    p1, h1, m1, s1, g1 = train(True)
+    assert torch.equal(h0, h1) and torch.equal(m0, m1) and torch.equal(p0, p1)
+    assert s0.keys() == s1.keys() and all(torch.equal(s0[n], s1[n]) for n in s0)
+    assert float(g1.abs().max()) == 0.0 and float(g0.abs().max()) > 0.0        # the deferred step leaves the bucket zeroed; in-line leaves the gradient
+
+
 def test_data_parallel_scales_for_a_non_fused_optimizer(monkeypatch):
     """With torch.optim.AdamW (no grad_scale attribute) the summed bucket must be averaged explicitly."""
     cfg, model, img, lab, box, crit = _setup()
