@@ -271,6 +271,98 @@ __device__ __forceinline__ void epi_tile_bf16(const GemmP& p, const f32x16& acc,
     chunk1 = make_uint4(x[2], x[3], y[2], y[3]);
 }
 
+// ---- register-resident bf16 epilogue of ONE ROW BLOCK (32 rows x the wave's 64 columns) with quad-contiguous stores ----------------------
+// The CU's store path takes the lanes of a store instruction four at a time: four CONSECUTIVE lanes writing 64 contiguous bytes cost one step,
+// four lanes on four different rows four steps (tools/probe/store_pattern.hip: 1.5 us against 4.3 us per 128-KiB tile and CU; pairs 2.9 us; which
+// lines an instruction covers does not matter, only what consecutive lanes cover).  The accumulator layout puts a row's data in lanes r and r + 32,
+// so epi_tile_bf16's stores are the four-step kind.  Here:
+//   * the caller stages the W tile with its rows permuted inside every 64-row group (gemm_pp2.hip, LINES): the accumulator register (j, qd, e) of
+//     half-wave hi then holds column 32 hi + 16 j + 4 qd + e of the wave's 64 -- a lane owns 64 CONTIGUOUS bytes of its row (no v_permlane32_swap);
+//   * the lane's four 16-byte pieces are transposed against the four lanes of its quad (two butterfly stages of v_cndmask + DPP quad_perm, 12
+//     VALU instructions per four words): lane 4k + i then holds piece i of rows 4k .. 4k + 3, and store instruction t writes row 4k + t with the
+//     quad's 64 bytes contiguous.
+// Same values as epi_tile_bf16 (same operations per element in the same order), same number of store instructions.
+__device__ __forceinline__ unsigned dpp_lane_xor1(unsigned v) { return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); }   // quad_perm [1,0,3,2]
+__device__ __forceinline__ unsigned dpp_lane_xor2(unsigned v) { return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true); }   // quad_perm [2,3,0,1]
+
+template <int EPI, bool GUARD>
+__device__ __forceinline__ void epi_lines_bf16(const GemmP& p, const f32x16& acc0, const f32x16& acc1, int64_t m_tile, int64_t n_wave, int lane,
+                                               const float* lds_bias) {
+    static_assert(EPI == EPI_BIAS_BF16 || EPI == EPI_QGELU_BF16 || EPI == EPI_GELU_BF16, "quad-contiguous epilogue: forward bf16 epilogues only");
+    const int hi = lane >> 5;
+    const int64_t m = m_tile + (lane & 31);
+    const float* bias_p = lds_bias + 32 * hi;
+    unsigned d[16], a[16];
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int qd = 0; qd < 4; qd++) {
+            const f32x16& acc = j ? acc1 : acc0;
+            float v[4];
+            const f32x2_t al = {p.alpha, p.alpha};
+            f32x2_t b01 = {0.f, 0.f}, b23 = {0.f, 0.f};
+            if (p.bias) {                                  // wave-uniform
+                const f32x4 b4 = lds_read_f4(bias_p + 16 * j + 4 * qd);
+                b01 = (f32x2_t){b4[0], b4[1]}; b23 = (f32x2_t){b4[2], b4[3]};
+            }
+            const f32x2_t v01 = __builtin_elementwise_fma((f32x2_t){acc[qd * 4 + 0], acc[qd * 4 + 1]}, al, b01);
+            const f32x2_t v23 = __builtin_elementwise_fma((f32x2_t){acc[qd * 4 + 2], acc[qd * 4 + 3]}, al, b23);
+            v[0] = v01.x; v[1] = v01.y; v[2] = v23.x; v[3] = v23.y;
+            if constexpr (EPI == EPI_QGELU_BF16 || EPI == EPI_GELU_BF16) {
+                if (p.aux) { a[8 * j + 2 * qd] = pack_bf2(v[0], v[1]); a[8 * j + 2 * qd + 1] = pack_bf2(v[2], v[3]); }
+                if constexpr (EPI == EPI_QGELU_BF16) {
+#pragma unroll
+                    for (int e = 0; e < 4; e += 2) {
+                        const f32x2_t u = {v[e], v[e + 1]};
+                        const f32x2_t t = u * -2.4554669595930156f;
+                        const f32x2_t dd = (f32x2_t){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + 1.0f;
+                        const f32x2_t o = u * (f32x2_t){__builtin_amdgcn_rcpf(dd.x), __builtin_amdgcn_rcpf(dd.y)};
+                        v[e] = o.x; v[e + 1] = o.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = gelu_f(v[e]);
+                }
+            }
+            d[8 * j + 2 * qd] = pack_bf2(v[0], v[1]);
+            d[8 * j + 2 * qd + 1] = pack_bf2(v[2], v[3]);
+        }
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+    if constexpr (EPI == EPI_QGELU_BF16 || EPI == EPI_GELU_BF16) {
+        if (p.aux) {                                       // wave-uniform; pre-activation save (trainable layer only): the lane's own 64 bytes
+            bf16_t* aux_row = (bf16_t*)p.aux + m * p.ld_aux + n_wave + 32 * hi;
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                if (!GUARD || (m < p.M && n_wave + 32 * hi + 8 * t < p.N))
+                    *(u32x4_t*)(aux_row + 8 * t) = (u32x4_t){a[4 * t], a[4 * t + 1], a[4 * t + 2], a[4 * t + 3]};
+        }
+    }
+    // 4 x 4 transposition of the 16-byte pieces d[4t .. 4t+3] against the quad's lanes
+    const bool o1 = lane & 1, o2 = lane & 2;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+#pragma unroll
+        for (int g = 0; g < 2; g++) {                      // stage 1: lanes l ^ 1, pieces (0,1) and (2,3)
+            unsigned& x = d[8 * g + c]; unsigned& y = d[8 * g + 4 + c];
+            const unsigned u = dpp_lane_xor1(o1 ? x : y);
+            if (o1) x = u; else y = u;
+        }
+#pragma unroll
+        for (int g = 0; g < 2; g++) {                      // stage 2: lanes l ^ 2, pieces (0,2) and (1,3)
+            unsigned& x = d[4 * g + c]; unsigned& y = d[4 * g + 8 + c];
+            const unsigned u = dpp_lane_xor2(o2 ? x : y);
+            if (o2) x = u; else y = u;
+        }
+    }
+    const int64_t row0 = m_tile + (lane & 28), n = n_wave + 32 * hi + 8 * (lane & 3);
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int64_t row = row0 + t;
+        if (GUARD && (row >= p.M || n >= p.N)) continue;
+        *(u32x4_t*)((bf16_t*)p.out + row * p.ldo + n) = (u32x4_t){d[4 * t], d[4 * t + 1], d[4 * t + 2], d[4 * t + 3]};
+    }
+}
+
 // ---- register-resident f32 epilogue of ONE 32x32 accumulator tile (swapped operands: lane owns output row m) ------------
 // out f32 = alpha*acc (+ bias)  [EPI_F32]   |   out f32 += alpha*acc  [EPI_ACC_F32]; four 16-byte accesses per lane and tile at columns
 // n_tile + 8*qd + 4*hi.  Same operations in the same order as epi_quad (alpha, then bias, then the residual): identical bits to the

@@ -32,7 +32,9 @@ __device__ __forceinline__ void q_bar() {
 }
 
 // TRACE (OWL_TUNING builds, tools/pp2_trace.py): workgroup 0 stamps s_memtime at every LOAD / wait / barrier / MFMA boundary of K-tile 4 of its first tile
-template <int EPI, bool TRACE = false>
+// LINES: the W tile is staged with its rows permuted inside every 64-row group so that a lane's accumulators are 64 contiguous output bytes, and the
+// epilogue stores quad-contiguous (gemm_common.h, epi_lines_bf16): forward bf16 epilogues.
+template <int EPI, bool TRACE = false, bool LINES = false>
 __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63;
@@ -121,7 +123,9 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
                 for (int q = 0; q < 2; q++) {
                     const int r = h * 128 + (w * 2 + q) * 8 + (lane >> 3);
                     const int c = (lane & 7) ^ ((r >> 1) & 7);
-                    int64_t wn = n0 + r; if (wn >= p.w_rows) wn = p.w_rows - 1;
+                    // LINES: LDS row (j, qd, hi, e) of a 64-row group <- W row 32 hi + 16 j + 4 qd + e of the group (the XOR key stays the LDS row's)
+                    const int rs = LINES ? ((r & ~63) | (((r >> 2) & 1) << 5) | (((r >> 5) & 1) << 4) | (((r >> 3) & 3) << 2) | (r & 3)) : r;
+                    int64_t wn = n0 + rs; if (wn >= p.w_rows) wn = p.w_rows - 1;
                     w_voff[h][q] = (unsigned)(((wn - n0) * p.ldw + c * 8) * 2);
                 }
             if (has_bias) {
@@ -290,6 +294,10 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
 #pragma unroll
                     for (int j = 0; j < 2; j++) epi_aux_load<G>(p, cm0 + grp * 128 + i * 32, cn0 + wc * 64 + j * 32, lane, auxr[i][j]);
             }
+            if constexpr (LINES) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) epi_lines_bf16<EPI, G>(p, acc[i][0], acc[i][1], cm0 + grp * 128 + i * 32, cn0 + wc * 64, lane, lbias);
+            } else
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -343,6 +351,8 @@ static int g_pp2_nostore = 0;            // 1: every epilogue store skipped (upp
 extern "C" int owl_gemm_pp2_nostore(int on) { g_pp2_nostore = on; return 0; }
 static int g_pp2_slots = 256;            // persistent grid size (tools/: does a GEMM on half the CUs beside the other stream's kernel pay?)
 extern "C" int owl_gemm_pp2_slots(int n) { g_pp2_slots = n; return 0; }
+static int g_pp2_lines = 0;              // 1: forward bf16 epilogues with quad-contiguous stores (A/B; loses)
+extern "C" int owl_gemm_pp2_lines(int on) { g_pp2_lines = on; return 0; }
 #else
 static constexpr int g_pp2_slots = 256;
 #endif
@@ -369,6 +379,21 @@ static int launch_pp2(hipStream_t s, GemmP p) {
     if (g_pp2_nostore) p.M = 0;             // (after the tile counts: every store fails its row guard)
 #endif
     p.persistent = nitems > g_pp2_slots ? 1 : 0;
+#ifdef OWL_TUNING
+    // Quad-contiguous stores (tools/gemm_lines_ab.py; measured +1 ... +2.5 % per GEMM, bit-identical: profiles/r03_gemm_anatomy.md section 2b) -- tuning
+    // builds only.  (Not the erf-GELU epilogue of the box head: its polynomial + the transposition do not fit the register file, 76 spilled registers.)
+    if constexpr (EPI == EPI_BIAS_BF16 || EPI == EPI_QGELU_BF16) {
+        if (g_pp2_lines && p.N % 8 == 0) {                // quad-contiguous stores (16-byte pieces: whole pieces inside N)
+            static unsigned long long attr_done_l = 0;
+            OWL_ONCE_PER_DEVICE(attr_done_l, {
+                (void)hipFuncSetAttribute((const void*)gemm_pp2_kernel<EPI, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
+            });
+            hipLaunchKernelGGL((gemm_pp2_kernel<EPI, false, true>), dim3(p.persistent ? g_pp2_slots : nitems), dim3(512), Q_LDS, s, p);
+            OWL_LAUNCH_CHECK();
+            return 0;
+        }
+    }
+#endif
     hipLaunchKernelGGL((gemm_pp2_kernel<EPI>), dim3(p.persistent ? g_pp2_slots : nitems), dim3(512), Q_LDS, s, p);
     OWL_LAUNCH_CHECK();
     return 0;

@@ -22,8 +22,19 @@ __global__ __launch_bounds__(512) void store_kernel(unsigned short* out, int64_t
                 row = (s >> 2) * 32 + (lane & 31); col = (s & 3) * 16 + (lane >> 5) * 8;
             } else if (MODE == 1) { // 16 rows x 64 B
                 row = (s >> 1) * 16 + (lane >> 2); col = (s & 1) * 32 + (lane & 3) * 8;
-            } else {                // 8 rows x 128 B: whole lines
+            } else if (MODE == 2) { // 8 rows x 128 B: whole lines, 8 consecutive lanes per row
                 row = s * 8 + (lane >> 3); col = (lane & 7) * 8;
+            } else if (MODE == 3) { // whole lines as two in-register butterfly stages leave them (lanes r, r+8, r+16, r+24 and their +32 partners
+                                    // transposed against the four chunk registers): a row's eight pieces sit in lanes r0 + 8a + 16b + 32hi
+                const int r0 = lane & 7, a = (lane >> 3) & 1, b = (lane >> 4) & 1, hi = lane >> 5;
+                row = (s >> 2) * 32 + r0 + 8 * (s & 1) + 16 * ((s >> 1) & 1); col = (2 * (a + 2 * b) + hi) * 8;
+            } else if (MODE == 5) { // 32 rows x 32 B, the two pieces of a row in CONSECUTIVE lanes
+                row = (s >> 2) * 32 + (lane >> 1); col = (s & 3) * 16 + (lane & 1) * 8;
+            } else if (MODE == 6) { // 16 rows x 64 B in consecutive lanes, the rows of an instruction 8 apart (any 16 rows do)
+                row = (s >> 2) * 32 + ((lane >> 2) & 7) + 8 * (s & 3) - 8 * (s & 3) + 16 * (lane >> 5) + ((s & 1) ? 8 : 0) - ((s & 1) ? 8 : 0); row = (s >> 2) * 32 + (s & 1) * 16 + (lane >> 2); col = ((s >> 1) & 1) * 32 + (lane & 3) * 8 ; row = (s >> 2) * 32 + ((lane >> 2) * 2 + (s & 1)) % 32 ;
+            } else {                // MODE 4: half lines as ONE v_permlane16_swap stage leaves them: a row's four pieces in lanes r, r+16, r+32, r+48
+                const int b = (lane >> 4) & 1, hi = lane >> 5;
+                row = (s >> 2) * 32 + (lane & 15) + 16 * (s & 1); col = (4 * ((s >> 1) & 1) + 2 * b + hi) * 8;
             }
             *(uint4*)(base + (int64_t)row * ld + col) = v;
         }
@@ -36,20 +47,26 @@ int main() {
     unsigned short* d; hipMalloc(&d, (M + 256) * N * 2);
     const int col_tiles = N / 256, tiles = (M / 256) * col_tiles, iters = tiles / 256;
     for (int grid : {256, 64, 16})
-        for (int mode = 0; mode < 3; mode += 2) {
+        for (int mode = 0; mode < 7; mode++) {
             const int iters = tiles / 256 * (256 / grid) / (256 / grid);      // same tiles per workgroup
             hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
             auto launch = [&]() {
                 if (mode == 0) store_kernel<0><<<grid, 512>>>(d, N, iters, col_tiles);
                 else if (mode == 1) store_kernel<1><<<grid, 512>>>(d, N, iters, col_tiles);
-                else store_kernel<2><<<grid, 512>>>(d, N, iters, col_tiles);
+                else if (mode == 2) store_kernel<2><<<grid, 512>>>(d, N, iters, col_tiles);
+                else if (mode == 3) store_kernel<3><<<grid, 512>>>(d, N, iters, col_tiles);
+                else if (mode == 4) store_kernel<4><<<grid, 512>>>(d, N, iters, col_tiles);
+                else if (mode == 5) store_kernel<5><<<grid, 512>>>(d, N, iters, col_tiles);
+                else store_kernel<6><<<grid, 512>>>(d, N, iters, col_tiles);
             };
             launch(); hipDeviceSynchronize();
             hipEventRecord(e0); for (int i = 0; i < 10; i++) launch(); hipEventRecord(e1); hipDeviceSynchronize();
             float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10;
             const double bytes = (double)iters * grid * 256 * 256 * 2;
             printf("%d workgroups, %s: %.1f us per launch (%d tiles per workgroup, %.0f MB) = %.2f TB/s = %.2f us per 128-KiB tile per CU\n",
-                   grid, mode == 0 ? "32 rows x 32 B per instruction (the GEMM epilogue)" : mode == 1 ? "16 rows x 64 B" : "8 rows x 128 B (whole lines)",
+                   grid, mode == 0 ? "32 rows x 32 B per instruction (the GEMM epilogue)" : mode == 1 ? "16 rows x 64 B (4 consecutive lanes)" : mode == 2 ? "8 rows x 128 B (whole lines, 8 consecutive lanes)"
+                   : mode == 3 ? "8 rows x 128 B, butterfly lane order" : mode == 4 ? "16 rows x 64 B, permlane16 lane order"
+                   : mode == 5 ? "32 rows x 32 B, consecutive lane pairs" : "16 rows x 64 B (4 consecutive lanes), every other row",
                    ms * 1e3, iters, bytes / 1e6, bytes / ms / 1e9, ms * 1e3 / iters);
         }
     return 0;
