@@ -21,7 +21,7 @@ int owl_attention_debug(int flags);
 int owl_gemm_pp2_slots(int n);
 /* ... 1: skip every epilogue store of that kernel (tools/gemm_nostore_ab.py) */
 int owl_gemm_pp2_nostore(int on);
-int owl_gemm_pp2_lines(int on);              /* 1: forward bf16 epilogues with quad-contiguous stores (experimental; default 0) */
+int owl_gemm_pp2_lines(int on);              /* quad-contiguous epilogue stores: 0 off, 1 bias epilogue (default, = the product), 2 quick-GELU epilogue too */
 int owl_gemm_pp2_trace(void* buf);
 /* ... which of workgroup 0's tiles is stamped (0 = its first; later tiles see the sustained clock and warm queues) */
 int owl_gemm_pp2_trace_tile(int n);

@@ -168,6 +168,19 @@ __device__ __forceinline__ void epi_pass(const GemmP& p, const f32x16& t0, const
 // EPI_DQGELU / EPI_DGELU read the saved pre-activation tile (p.aux).  epi_aux_load fetches it in the STORE layout (two 16-byte loads per
 // lane and tile instead of four 8-byte ones at a row stride) so that a caller can have the loads of all its tiles in flight before the
 // first one is consumed; epi_tile_bf16 then undoes the lane pairing with the same v_permlane32_swap (it is its own inverse).
+// The wave's bias values for a whole tile in ONE LDS round trip: bq[j][qd] = floats lds_bias[32 j + 8 qd + 4 hi .. +4] (the columns of accumulator
+// quad qd of column tile j).  lds_read_f4 waits for every read on its own -- 32 serialised LDS round trips per wave and tile when the epilogue
+// re-reads the slice per 32 x 32 tile and quad (the asm statement cannot be hoisted or merged): ~3000 of the ~4650 ticks of a group's epilogue
+// interval at K = 768 (profiles/r03_gemm_anatomy.md section 5).
+__device__ __forceinline__ void epi_bias_preload(const float* lds_bias, int hi, f32x4 (&bq)[2][4]) {
+    const unsigned a = (unsigned)(uintptr_t)LPTR(lds_bias + 4 * hi);
+    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:32\n\tds_read_b128 %2, %8 offset:64\n\tds_read_b128 %3, %8 offset:96\n\t"
+                 "ds_read_b128 %4, %8 offset:128\n\tds_read_b128 %5, %8 offset:160\n\tds_read_b128 %6, %8 offset:192\n\tds_read_b128 %7, %8 offset:224\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(bq[0][0]), "=&v"(bq[0][1]), "=&v"(bq[0][2]), "=&v"(bq[0][3]), "=&v"(bq[1][0]), "=&v"(bq[1][1]), "=&v"(bq[1][2]), "=&v"(bq[1][3])
+                 : "v"(a) : "memory");
+}
+
 template <bool GUARD>
 __device__ __forceinline__ void epi_aux_load(const GemmP& p, int64_t m_tile, int64_t n_tile, int lane, uint4 (&a)[2]) {
     const int hi = lane >> 5;
@@ -182,7 +195,8 @@ __device__ __forceinline__ void epi_aux_load(const GemmP& p, int64_t m_tile, int
 
 template <int EPI, bool GUARD>
 __device__ __forceinline__ void epi_tile_bf16(const GemmP& p, const f32x16& acc, int64_t m_tile, int64_t n_tile, int lane,
-                                              uint4& chunk0, uint4& chunk1, const float* lds_bias, const uint4* aux_pre = nullptr) {
+                                              uint4& chunk0, uint4& chunk1, const float* lds_bias, const uint4* aux_pre = nullptr,
+                                              const f32x4* bias_pre = nullptr) {      // bias_pre: epi_bias_preload's bq[j] for this column tile
     constexpr bool TRANS = (EPI == EPI_TRANS_BF16);
     const int hi = lane >> 5;
     unsigned w[8];   // packed words, quad qd -> w[2*qd], w[2*qd+1]
@@ -221,7 +235,7 @@ __device__ __forceinline__ void epi_tile_bf16(const GemmP& p, const f32x16& acc,
             const f32x2_t al = {p.alpha, p.alpha};
             f32x2_t b01 = {0.f, 0.f}, b23 = {0.f, 0.f};
             if (p.bias) {                                  // wave-uniform
-                const f32x4 b4 = lds_read_f4(bias_p + 8 * qd);
+                const f32x4 b4 = bias_pre ? bias_pre[qd] : lds_read_f4(bias_p + 8 * qd);
                 b01 = (f32x2_t){b4[0], b4[1]}; b23 = (f32x2_t){b4[2], b4[3]};
             }
             const f32x2_t v01 = __builtin_elementwise_fma((f32x2_t){acc[qd * 4 + 0], acc[qd * 4 + 1]}, al, b01);
@@ -278,16 +292,23 @@ __device__ __forceinline__ void epi_tile_bf16(const GemmP& p, const f32x16& acc,
 // so epi_tile_bf16's stores are the four-step kind.  Here:
 //   * the caller stages the W tile with its rows permuted inside every 64-row group (gemm_pp2.hip, LINES): the accumulator register (j, qd, e) of
 //     half-wave hi then holds column 32 hi + 16 j + 4 qd + e of the wave's 64 -- a lane owns 64 CONTIGUOUS bytes of its row (no v_permlane32_swap);
-//   * the lane's four 16-byte pieces are transposed against the four lanes of its quad (two butterfly stages of v_cndmask + DPP quad_perm, 12
+//   * the lane's four 16-byte pieces are transposed against the four lanes of its quad (two butterfly stages of v_cndmask + DPP quad_perm, 16
 //     VALU instructions per four words): lane 4k + i then holds piece i of rows 4k .. 4k + 3, and store instruction t writes row 4k + t with the
 //     quad's 64 bytes contiguous.
 // Same values as epi_tile_bf16 (same operations per element in the same order), same number of store instructions.
-__device__ __forceinline__ unsigned dpp_lane_xor1(unsigned v) { return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); }   // quad_perm [1,0,3,2]
-__device__ __forceinline__ unsigned dpp_lane_xor2(unsigned v) { return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true); }   // quad_perm [2,3,0,1]
+
+__device__ __forceinline__ void epi_lines_bias_preload(const float* lds_bias, int hi, f32x4 (&bq)[8]) {     // floats lds_bias[32 hi + 4 t .. +4], t = 0..7
+    const unsigned a = (unsigned)(uintptr_t)LPTR(lds_bias + 32 * hi);
+    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:32\n\tds_read_b128 %3, %8 offset:48\n\t"
+                 "ds_read_b128 %4, %8 offset:64\n\tds_read_b128 %5, %8 offset:80\n\tds_read_b128 %6, %8 offset:96\n\tds_read_b128 %7, %8 offset:112\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(bq[0]), "=&v"(bq[1]), "=&v"(bq[2]), "=&v"(bq[3]), "=&v"(bq[4]), "=&v"(bq[5]), "=&v"(bq[6]), "=&v"(bq[7])
+                 : "v"(a) : "memory");
+}
 
 template <int EPI, bool GUARD>
 __device__ __forceinline__ void epi_lines_bf16(const GemmP& p, const f32x16& acc0, const f32x16& acc1, int64_t m_tile, int64_t n_wave, int lane,
-                                               const float* lds_bias) {
+                                               const float* lds_bias, const f32x4* bias_pre = nullptr) {   // bias_pre[4 j + qd]: epi_lines_bias_preload
     static_assert(EPI == EPI_BIAS_BF16 || EPI == EPI_QGELU_BF16 || EPI == EPI_GELU_BF16, "quad-contiguous epilogue: forward bf16 epilogues only");
     const int hi = lane >> 5;
     const int64_t m = m_tile + (lane & 31);
@@ -302,7 +323,7 @@ __device__ __forceinline__ void epi_lines_bf16(const GemmP& p, const f32x16& acc
             const f32x2_t al = {p.alpha, p.alpha};
             f32x2_t b01 = {0.f, 0.f}, b23 = {0.f, 0.f};
             if (p.bias) {                                  // wave-uniform
-                const f32x4 b4 = lds_read_f4(bias_p + 16 * j + 4 * qd);
+                const f32x4 b4 = bias_pre ? bias_pre[4 * j + qd] : lds_read_f4(bias_p + 16 * j + 4 * qd);
                 b01 = (f32x2_t){b4[0], b4[1]}; b23 = (f32x2_t){b4[2], b4[3]};
             }
             const f32x2_t v01 = __builtin_elementwise_fma((f32x2_t){acc[qd * 4 + 0], acc[qd * 4 + 1]}, al, b01);
@@ -337,21 +358,27 @@ __device__ __forceinline__ void epi_lines_bf16(const GemmP& p, const f32x16& acc
                     *(u32x4_t*)(aux_row + 8 * t) = (u32x4_t){a[4 * t], a[4 * t + 1], a[4 * t + 2], a[4 * t + 3]};
         }
     }
-    // 4 x 4 transposition of the 16-byte pieces d[4t .. 4t+3] against the quad's lanes
-    const bool o1 = lane & 1, o2 = lane & 2;
+    // 4 x 4 transposition of the 16-byte pieces d[4t .. 4t+3] against the quad's lanes: two butterfly stages; lanes l and l ^ X exchange so that the
+    // lane with bit X clear ends with (x, partner's x) and the other with (partner's y, y).  hipcc makes a select + v_mov_b32_dpp + two selects of each
+    // pair and stage.  (Hand-written v_cndmask_b32_dpp pairs -- x' = bit ? partner.y : x, y' = bit ? y : partner.x, half the instructions, VCC set by
+    // hand -- measured SLOWER in the model, 1209 against 1212.5 img/s on one box: the asm blocks pin the order hipcc otherwise interleaves with the
+    // conversion of the next row block and the stores.)
+    {
+        const bool o1 = lane & 1, o2 = lane & 2;
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
+        for (int c = 0; c < 4; c++) {
 #pragma unroll
-        for (int g = 0; g < 2; g++) {                      // stage 1: lanes l ^ 1, pieces (0,1) and (2,3)
-            unsigned& x = d[8 * g + c]; unsigned& y = d[8 * g + 4 + c];
-            const unsigned u = dpp_lane_xor1(o1 ? x : y);
-            if (o1) x = u; else y = u;
-        }
+            for (int g = 0; g < 2; g++) {
+                unsigned& x = d[8 * g + c]; unsigned& y = d[8 * g + 4 + c];
+                const unsigned u = (unsigned)__builtin_amdgcn_mov_dpp((int)(o1 ? x : y), 0xB1, 0xF, 0xF, true);
+                if (o1) x = u; else y = u;
+            }
 #pragma unroll
-        for (int g = 0; g < 2; g++) {                      // stage 2: lanes l ^ 2, pieces (0,2) and (1,3)
-            unsigned& x = d[4 * g + c]; unsigned& y = d[4 * g + 8 + c];
-            const unsigned u = dpp_lane_xor2(o2 ? x : y);
-            if (o2) x = u; else y = u;
+            for (int g = 0; g < 2; g++) {
+                unsigned& x = d[4 * g + c]; unsigned& y = d[4 * g + 8 + c];
+                const unsigned u = (unsigned)__builtin_amdgcn_mov_dpp((int)(o2 ? x : y), 0x4E, 0xF, 0xF, true);
+                if (o2) x = u; else y = u;
+            }
         }
     }
     const int64_t row0 = m_tile + (lane & 28), n = n_wave + 32 * hi + 8 * (lane & 3);
@@ -368,7 +395,8 @@ __device__ __forceinline__ void epi_lines_bf16(const GemmP& p, const f32x16& acc
 // n_tile + 8*qd + 4*hi.  Same operations in the same order as epi_quad (alpha, then bias, then the residual): identical bits to the
 // LDS-staged epilogue of the single-phase kernel.
 template <int EPI, bool GUARD>
-__device__ __forceinline__ void epi_tile_f32(const GemmP& p, const f32x16& acc, int64_t m_tile, int64_t n_tile, int lane, const float* lds_bias) {
+__device__ __forceinline__ void epi_tile_f32(const GemmP& p, const f32x16& acc, int64_t m_tile, int64_t n_tile, int lane, const float* lds_bias,
+                                             const f32x4* bias_pre = nullptr) {
     const int hi = lane >> 5;
     const int64_t m = m_tile + (lane & 31);
     const bool m_ok = !GUARD || m < p.M;
@@ -380,7 +408,7 @@ __device__ __forceinline__ void epi_tile_f32(const GemmP& p, const f32x16& acc, 
 #pragma unroll
         for (int e = 0; e < 4; e++) v[e] = acc[qd * 4 + e] * p.alpha;
         if (p.bias) {                                  // wave-uniform
-            const f32x4 b4 = lds_read_f4(bias_p + 8 * qd);
+            const f32x4 b4 = bias_pre ? bias_pre[qd] : lds_read_f4(bias_p + 8 * qd);
             v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
         }
         const bool ok = m_ok && (!GUARD || (n_tile + 8 * qd + 4 * hi) < p.N);

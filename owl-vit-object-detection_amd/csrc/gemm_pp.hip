@@ -301,16 +301,20 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
 #pragma unroll
                         for (int j = 0; j < 2; j++) epi_aux_load<G>(p, cm0 + grp * 128 + i * 32, cn0 + wc * 64 + j * 32, lane, auxr[i][j]);
                 }
+                // the wave's bias values, one LDS round trip (gemm_common.h, epi_bias_preload) -- not where the epilogue needs the registers itself
+                constexpr bool BIAS_PRE = (EPI == EPI_BIAS_BF16 || EPI == EPI_QGELU_BF16 || EPI == EPI_F32 || EPI == EPI_ACC_F32);
+                f32x4 bq[2][4];
+                if constexpr (BIAS_PRE) { if (p.bias) epi_bias_preload(lbias, lane >> 5, bq); }
 #pragma unroll
                 for (int i = 0; i < 4; i++)
 #pragma unroll
                     for (int j = 0; j < 2; j++) {
                         const int64_t mt = cm0 + grp * 128 + i * 32, nt = cn0 + wc * 64 + j * 32;
                         if constexpr (EPI == EPI_F32 || EPI == EPI_ACC_F32) {
-                            epi_tile_f32<EPI, G>(p, acc[i][j], mt, nt, lane, lbias + j * 32);
+                            epi_tile_f32<EPI, G>(p, acc[i][j], mt, nt, lane, lbias + j * 32, BIAS_PRE ? bq[j] : nullptr);
                         } else {
                             uint4 c0, c1;
-                            epi_tile_bf16<EPI, G>(p, acc[i][j], mt, nt, lane, c0, c1, lbias + j * 32, AUX_IN ? auxr[AUX_IN ? i : 0][j] : nullptr);
+                            epi_tile_bf16<EPI, G>(p, acc[i][j], mt, nt, lane, c0, c1, lbias + j * 32, AUX_IN ? auxr[AUX_IN ? i : 0][j] : nullptr, BIAS_PRE ? bq[j] : nullptr);
                             epi_store_chunk<EPI, G>(p, c0, mt, nt, 0, lane);
                             epi_store_chunk<EPI, G>(p, c1, mt, nt, 1, lane);
                         }

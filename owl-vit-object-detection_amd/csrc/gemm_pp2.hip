@@ -284,8 +284,14 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
         constexpr bool PLAIN_EPI = (EPI == EPI_BIAS_BF16 || EPI == EPI_QGELU_BF16 || EPI == EPI_GELU_BF16);
         if (PLAIN_EPI && inner && !p.aux && a_item < item_end) { stage_A(); a_early = true; pending_stores = 16; }
         const float* lbias = (const float*)(lds + Q_BIAS_OFF + tile_parity * 1024) + wc * 64;
+        // (trace, K-tile selector 15: the stamps record the epilogue instead -- 0 start, 1 bias values in registers, 2..5 row block i converted and its
+        //  stores issued, 6 = 5 again)
+        auto estamp = [&](int idx) {
+            if constexpr (TRACE) { if (tr_wg && tr_first && ((p.dbg >> 4) & 15) == 15) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr_ts[idx]) :: "memory"); }
+        };
         auto run = [&](auto guard_tag) {
             constexpr bool G = decltype(guard_tag)::value;
+            estamp(0);
             constexpr bool AUX_IN = (EPI == EPI_DQGELU_BF16);     // saved pre-activations of all eight 32x32 tiles requested up front (gemm_pp.hip)
             uint4 auxr[AUX_IN ? 4 : 1][2][2];
             if constexpr (AUX_IN) {
@@ -294,26 +300,41 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
 #pragma unroll
                     for (int j = 0; j < 2; j++) epi_aux_load<G>(p, cm0 + grp * 128 + i * 32, cn0 + wc * 64 + j * 32, lane, auxr[i][j]);
             }
+            // the wave's 32 bias values of this tile, read once (one LDS round trip instead of one per 32 x 32 tile and quad)
+            // (not where the epilogue needs the registers itself -- erf-GELU and the activation derivatives spill with 32 more live values)
+            constexpr bool BIAS_PRE = (EPI == EPI_BIAS_BF16 || EPI == EPI_QGELU_BF16 || EPI == EPI_F32 || EPI == EPI_ACC_F32);
+            f32x4 bq[2][4];
+            if constexpr (BIAS_PRE && !LINES) { if (has_bias) epi_bias_preload(lbias, hi, bq); }
             if constexpr (LINES) {
+                f32x4 bl[8];
+                if (has_bias) epi_lines_bias_preload(lbias, hi, bl);
+                estamp(1);
 #pragma unroll
-                for (int i = 0; i < 4; i++) epi_lines_bf16<EPI, G>(p, acc[i][0], acc[i][1], cm0 + grp * 128 + i * 32, cn0 + wc * 64, lane, lbias);
-            } else
+                for (int i = 0; i < 4; i++) {
+                    epi_lines_bf16<EPI, G>(p, acc[i][0], acc[i][1], cm0 + grp * 128 + i * 32, cn0 + wc * 64, lane, lbias, bl);
+                    estamp(2 + i);
+                }
+            } else {
+            estamp(1);
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+            for (int i = 0; i < 4; i++) {
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
                     const int64_t mt = cm0 + grp * 128 + i * 32, nt = cn0 + wc * 64 + j * 32;
                     if constexpr (EPI == EPI_F32 || EPI == EPI_ACC_F32) {
-                        epi_tile_f32<EPI, G>(p, acc[i][j], mt, nt, lane, lbias + j * 32);
+                        epi_tile_f32<EPI, G>(p, acc[i][j], mt, nt, lane, lbias + j * 32, BIAS_PRE ? bq[j] : nullptr);
                     } else if constexpr (EPI == EPI_PATCH_F32 || EPI == EPI_PATCHM_F32) {
                         epi_tile_patch<G>(p, acc[i][j], mt, nt, lane);
                     } else {
                         uint4 c0, c1;
-                        epi_tile_bf16<EPI, G>(p, acc[i][j], mt, nt, lane, c0, c1, lbias + j * 32, AUX_IN ? auxr[AUX_IN ? i : 0][j] : nullptr);
+                        epi_tile_bf16<EPI, G>(p, acc[i][j], mt, nt, lane, c0, c1, lbias + j * 32, AUX_IN ? auxr[AUX_IN ? i : 0][j] : nullptr, BIAS_PRE ? bq[j] : nullptr);
                         epi_store_chunk<EPI, G>(p, c0, mt, nt, 0, lane);
                         epi_store_chunk<EPI, G>(p, c1, mt, nt, 1, lane);
                     }
                 }
+                estamp(2 + i);
+            }
+            }
         };
         if (inner) run(std::false_type{}); else run(std::true_type{});
         tile_stamp(4);                               // (conversion done, every store of the tile issued)
@@ -321,6 +342,10 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
         tile_stamp(3);
         if constexpr (TRACE) {
             if (tr_wg && tr_first) {
+                if (lane == 0 && ((p.dbg >> 4) & 15) == 15) {
+#pragma unroll
+                    for (int i = 0; i < 11; i++) ((unsigned long long*)(lds + Q_LDS))[w * 16 + i] = tr_ts[i];
+                }
                 if (lane == 0) {
 #pragma unroll
                     for (int i = 0; i < 5; i++) ((unsigned long long*)(lds + Q_LDS))[w * 16 + 11 + i] = tile_ts[i];
@@ -351,7 +376,7 @@ static int g_pp2_nostore = 0;            // 1: every epilogue store skipped (upp
 extern "C" int owl_gemm_pp2_nostore(int on) { g_pp2_nostore = on; return 0; }
 static int g_pp2_slots = 256;            // persistent grid size (tools/: does a GEMM on half the CUs beside the other stream's kernel pay?)
 extern "C" int owl_gemm_pp2_slots(int n) { g_pp2_slots = n; return 0; }
-static int g_pp2_lines = 0;              // 1: forward bf16 epilogues with quad-contiguous stores (A/B; loses)
+static int g_pp2_lines = 1;              // quad-contiguous stores: 0 off, 1 bias epilogue (the product's choice), 2 quick-GELU epilogue too
 extern "C" int owl_gemm_pp2_lines(int on) { g_pp2_lines = on; return 0; }
 #else
 static constexpr int g_pp2_slots = 256;
@@ -379,11 +404,18 @@ static int launch_pp2(hipStream_t s, GemmP p) {
     if (g_pp2_nostore) p.M = 0;             // (after the tile counts: every store fails its row guard)
 #endif
     p.persistent = nitems > g_pp2_slots ? 1 : 0;
+    // Quad-contiguous stores (gemm_common.h, epi_lines_bf16; profiles/r03_gemm_anatomy.md section 2b): the store-bound bias epilogue, -3 ... -5 % at
+    // K = 768.  The quick-GELU epilogue is VALU-bound and loses 2-4 % with the transposition on top (tuning builds can still switch it on:
+    // owl_gemm_pp2_lines(2)); the erf-GELU one does not fit the register file with it (76 spilled registers).
 #ifdef OWL_TUNING
-    // Quad-contiguous stores (tools/gemm_lines_ab.py; measured +1 ... +2.5 % per GEMM, bit-identical: profiles/r03_gemm_anatomy.md section 2b) -- tuning
-    // builds only.  (Not the erf-GELU epilogue of the box head: its polynomial + the transposition do not fit the register file, 76 spilled registers.)
-    if constexpr (EPI == EPI_BIAS_BF16 || EPI == EPI_QGELU_BF16) {
-        if (g_pp2_lines && p.N % 8 == 0) {                // quad-contiguous stores (16-byte pieces: whole pieces inside N)
+    constexpr bool LINES_OK = (EPI == EPI_BIAS_BF16 || EPI == EPI_QGELU_BF16);
+    const bool lines_on = EPI == EPI_BIAS_BF16 ? g_pp2_lines >= 1 : g_pp2_lines >= 2;
+#else
+    constexpr bool LINES_OK = (EPI == EPI_BIAS_BF16);
+    const bool lines_on = true;
+#endif
+    if constexpr (LINES_OK) {
+        if (lines_on && p.N % 8 == 0) {                   // (16-byte pieces: whole pieces inside N)
             static unsigned long long attr_done_l = 0;
             OWL_ONCE_PER_DEVICE(attr_done_l, {
                 (void)hipFuncSetAttribute((const void*)gemm_pp2_kernel<EPI, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
@@ -393,7 +425,6 @@ static int launch_pp2(hipStream_t s, GemmP p) {
             return 0;
         }
     }
-#endif
     hipLaunchKernelGGL((gemm_pp2_kernel<EPI>), dim3(p.persistent ? g_pp2_slots : nitems), dim3(512), Q_LDS, s, p);
     OWL_LAUNCH_CHECK();
     return 0;
@@ -419,6 +450,11 @@ int owl_gemm_pp2_launch(hipStream_t s, int epi, const GemmP& p) {
         const int nitems = q.tiles_m * q.tiles_n;
         q.persistent = nitems > 256 ? 1 : 0;
         GemmP qq = q; qq.aux = g_pp2_trace;           // (the bias epilogue never reads aux; PLAIN_EPI's early A staging is off with aux set -- fine for a trace)
+        if (g_pp2_lines) {
+            (void)hipFuncSetAttribute((const void*)gemm_pp2_kernel<EPI_BIAS_BF16, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS + 2048);
+            hipLaunchKernelGGL((gemm_pp2_kernel<EPI_BIAS_BF16, true, true>), dim3(q.persistent ? 256 : nitems), dim3(512), Q_LDS + 2048, s, qq);
+            return 0;
+        }
         hipLaunchKernelGGL((gemm_pp2_kernel<EPI_BIAS_BF16, true>), dim3(q.persistent ? 256 : nitems), dim3(512), Q_LDS + 2048, s, qq);
         return 0;
     }

@@ -175,13 +175,15 @@ __global__ __launch_bounds__(512) void gemm_pph_kernel(GemmP p) {
     const float* lbias = (const float*)(lds + H_BIAS_OFF) + wc * 64;
     auto run = [&](auto guard_tag) {
         constexpr bool G = decltype(guard_tag)::value;
+        f32x4 bq[2][4];                                // the wave's bias values, one LDS round trip (gemm_common.h, epi_bias_preload)
+        if (p.bias) epi_bias_preload(lbias, lane >> 5, bq);
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 const int64_t mt = cm0 + grp * 64 + i * 32, nt = cn0 + wc * 64 + j * 32;
                 uint4 c0, c1;
-                epi_tile_bf16<EPI, G>(p, acc[i][j], mt, nt, lane, c0, c1, lbias + j * 32);
+                epi_tile_bf16<EPI, G>(p, acc[i][j], mt, nt, lane, c0, c1, lbias + j * 32, nullptr, bq[j]);
                 epi_store_chunk<EPI, G>(p, c0, mt, nt, 0, lane);
                 epi_store_chunk<EPI, G>(p, c1, mt, nt, 1, lane);
             }

@@ -48,7 +48,7 @@ def test_bench_refuses_more_gpus_than_visible():
 @pytest.mark.parametrize("schedule", ["in-line", "overlap"])
 def test_bench_single_forced_rccl_rank_reports_the_collective(schedule):
     """One forced rank over the real RCCL backend, both optimizer schedules (with more than one rank the bench defaults to the overlapped
-    one: RCCL + AdamW on a side stream while the next step's sub-batch streams already run the frozen prefix); batch 8 so that the
+    one: backward + RCCL + AdamW on the model's tail stream while the next step's sub-batch streams already run the frozen prefix); batch 8 so that the
     encoder runs its two sub-batch streams beside them."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "1", "--arch", "small",
                         "--batch", "8", "--no-cpu-baseline"] + (["--overlap"] if schedule == "overlap" else []),
@@ -57,7 +57,7 @@ def test_bench_single_forced_rccl_rank_reports_the_collective(schedule):
     out = _last_json(r.stdout)
     assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and out["backend"].startswith("nccl")
     assert out["allreduce_ms"] > 0 and out["allreduce_bytes"] > 0 and out["value"] > 0
-    assert out["config"]["optimizer_schedule"].startswith("side-stream" if schedule == "overlap" else "in-line")
+    assert out["config"]["optimizer_schedule"].startswith("backward + all-reduce + AdamW on the tail stream" if schedule == "overlap" else "in-line")
     assert out["config"]["encoder_streams"] == 2
 
 

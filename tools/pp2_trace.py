@@ -11,6 +11,8 @@ DEV = "cuda"
 M, N, K = (int(x) for x in (sys.argv[1:4] if len(sys.argv) > 3 else (73984, 2304, 768)))
 TILE = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 KT = int(sys.argv[5]) if len(sys.argv) > 5 else 4
+LINES = int(sys.argv[6]) if len(sys.argv) > 6 else 0          # 1: the quad-contiguous-store epilogue (tuning builds)
+_lib.call("owl_gemm_pp2_lines", LINES)
 A = torch.randn(ops.pad_rows(M), K, device=DEV).bfloat16()
 W = (torch.randn(N, K, device=DEV) * 0.05).bfloat16()
 bias = torch.randn(N, device=DEV)
@@ -45,6 +47,11 @@ for w in range(8):
     segs = [int(d[idx[i + 1]] - d[idx[i]]) for i in range(8)]
     print(f"w{w} {int(d[0]):6d} | " + " | ".join(f"{s:13d}" for s in segs) + f" | {int(d[10] - d[0])}")
 print(f"mean ticks per K-tile per wave {float((t[:, 10] - t[:, 0]).mean()):.0f} (64 MFMAs per SIMD = 2048 shader cycles)")
+if KT == 15:      # the stamps recorded the epilogue
+    print("epilogue of the tile, per wave (ticks): bias values read | row block 0 | 1 | 2 | 3 converted + stores issued")
+    for w in range(8):
+        e = t[w]
+        print(f"w{w}: {int(e[1] - e[0]):5d} | " + " | ".join(f"{int(e[2 + i] - e[1 + i]):5d}" for i in range(4)))
 tt = full[:, 11:16]
 print("whole tile, per wave: tile start -> K-loop start | K-loop (all K-tiles) | conversion + store issue | the epilogue barrier | tile")
 for w in range(8):
