@@ -173,7 +173,9 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
     // already reads the next tile's first fragments (+2 % on top of the two-phase K-tile at K = 768 / 3072).  VALU-bound epilogue (quick-GELU:
     // an exp and a reciprocal per element): two staggered epilogues in a row cost more than both together (-6 %), so there the groups are
     // re-synchronised at every tile as in gemm_pp.hip -- group 0 waits for group 1's last MFMA phase, both run their epilogues in one interval.
-    constexpr bool STAGGERED_EPI = (EPI == EPI_BIAS_BF16 || EPI == EPI_F32 || EPI == EPI_ACC_F32 || EPI == EPI_PATCH_F32 || EPI == EPI_PATCHM_F32);
+    // (With quad-contiguous stores -- LINES -- the bias epilogue is VALU-bound too and goes with the second kind: same box, QKV 243.6 -> 233.5 us,
+    //  out-proj 89.1 -> 87.2, step 1217 -> 1223 img/s.)
+    constexpr bool STAGGERED_EPI = ((EPI == EPI_BIAS_BF16 && !LINES) || EPI == EPI_F32 || EPI == EPI_ACC_F32 || EPI == EPI_PATCH_F32 || EPI == EPI_PATCHM_F32);
     if (STAGGERED_EPI && grp == 1) q_bar();
     unsigned long long wg_t0 = 0;
     unsigned long long wg_r0 = 0;          // s_memrealtime: 100 MHz, one counter for the chip -- comparable across workgroups
