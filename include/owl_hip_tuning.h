@@ -21,6 +21,7 @@ int owl_attention_debug(int flags);
 int owl_gemm_pp2_slots(int n);
 /* ... 1: skip every epilogue store of that kernel (tools/gemm_nostore_ab.py) */
 int owl_gemm_pp2_nostore(int on);
+int owl_gemm_pp2_block_width(int epi, int bw);   /* tile order of the two-phase GEMM: epi 0 bias / 1 quick-GELU; bw 0 = the launcher's rule, else column blocks of the largest divisor of tiles_n up to bw */
 int owl_gemm_pp2_lines(int on);              /* quad-contiguous epilogue stores: 0 off, 1 bias epilogue (default, = the product), 2 quick-GELU epilogue too */
 int owl_gemm_pp2_trace(void* buf);
 /* ... which of workgroup 0's tiles is stamped (0 = its first; later tiles see the sustained clock and warm queues) */

@@ -378,6 +378,8 @@ static int g_pp2_nostore = 0;            // 1: every epilogue store skipped (upp
 extern "C" int owl_gemm_pp2_nostore(int on) { g_pp2_nostore = on; return 0; }
 static int g_pp2_slots = 256;            // persistent grid size (tools/: does a GEMM on half the CUs beside the other stream's kernel pay?)
 extern "C" int owl_gemm_pp2_slots(int n) { g_pp2_slots = n; return 0; }
+static int g_pp2_bw[2] = {0, 0};         // column-block width of the tile order for the bias / quick-GELU epilogue: 0 = the launcher's rule, else the largest divisor of tiles_n up to this
+extern "C" int owl_gemm_pp2_block_width(int epi, int bw) { if (epi < 0 || epi > 1) return -1; g_pp2_bw[epi] = bw; return 0; }
 static int g_pp2_lines = 1;              // quad-contiguous stores: 0 off, 1 bias epilogue (the product's choice), 2 quick-GELU epilogue too
 extern "C" int owl_gemm_pp2_lines(int on) { g_pp2_lines = on; return 0; }
 #else
@@ -397,10 +399,21 @@ static int launch_pp2(hipStream_t s, GemmP p) {
     // 5 % slower blocked (its A panel is then fetched three times, beside the 455 MB of pre-activations it already streams), and so did the
     // WHOLE-batch fc1 inside the model (289 row panels: 0.387 -> 0.363 ms per launch row-major, old / new library alternated in bench.py
     // --encoder-streams 1; the stand-alone tool had it neutral) -- blocked only up to 160 row panels there (the sub-batch launches).
+    // Round 3, in the model, one process (tools/tile_order_ab.py): widths 2 ... 12 of fc1 and 3 / 9 of QKV are within 0.1 ms of each other per 26-27 ms step either
+    // schedule (only single columns lose, 0.5-1.2 ms); the whole-batch fc1 takes blocks of 6 -- the W block (2.4 MB) stays in the XCD's L2 and the launch
+    // requests ~0.3 GB instead of 0.8 GB from the fabric (row-major: 4.7 MB of W per XCD and round, answered by the infinity cache) at 26.81 vs 26.87-26.90 ms.
     p.nsplit = p.tiles_n;
-    if ((EPI == EPI_BIAS_BF16 || EPI == EPI_QGELU_BF16) && !(EPI == EPI_QGELU_BF16 && p.tiles_m > 160))
-        for (int d = 4; d >= 1; d--)
+    if (EPI == EPI_BIAS_BF16 || EPI == EPI_QGELU_BF16)
+        for (int d = (EPI == EPI_QGELU_BF16 && p.tiles_m > 160) ? 6 : 4; d >= 1; d--)
             if (p.tiles_n % d == 0) { p.nsplit = d; break; }
+#ifdef OWL_TUNING
+    if constexpr (EPI == EPI_BIAS_BF16 || EPI == EPI_QGELU_BF16) {
+        const int want = g_pp2_bw[EPI == EPI_QGELU_BF16 ? 1 : 0];
+        if (want > 0)
+            for (int d = want; d >= 1; d--)
+                if (p.tiles_n % d == 0) { p.nsplit = d; break; }
+    }
+#endif
     const int nitems = p.tiles_m * p.tiles_n;
 #ifdef OWL_TUNING
     if (g_pp2_nostore) p.M = 0;             // (after the tile counts: every store fails its row guard)
