@@ -96,15 +96,21 @@ def test_host_and_device_target_lists_pack_identically():
     assert a.sizes == b.sizes and a.Nmax == b.Nmax
 
 
-@pytest.mark.parametrize("cname,B", [("tiny", 2), ("small", 2)])
-def test_overlapped_optimizer_schedule_is_bitwise_the_inline_schedule(cname, B):
-    def train(overlap, steps=4):
+@pytest.mark.parametrize("cname,B,toggle", [("tiny", 2, False), ("small", 2, False), ("small", 2, True)])
+def test_overlapped_optimizer_schedule_is_bitwise_the_inline_schedule(cname, B, toggle):
+    """toggle: every other step runs in-line although the wrapper overlaps (what bench.py does on its kernel-timing steps: model.overlap_tail off for
+    that step) -- the all-reduce and AdamW of such a step must follow its in-line backward on the compute stream."""
+    def train(overlap, steps=5 if toggle else 4):
         cfg, model, img, lab, box, crit = _setup(cname, B)
         opt = FusedAdamW(model, lr=1e-3, weight_decay=0.1)
         dp = ddp.DataParallel(model, opt, overlap=overlap)
         assert dp.overlap == overlap
         hist = []
-        for _ in range(steps):
+        for k in range(steps):
+            if toggle and overlap:
+                model.overlap_tail = (k % 2 == 0)
+                if not model.overlap_tail:
+                    model.finish()
             opt.zero_grad()
             pb, _, ps, _ = model(img)
             loss = _loss(crit, ps, lab, pb, box)
