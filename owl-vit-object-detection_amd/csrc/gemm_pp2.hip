@@ -278,12 +278,7 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
             cur ^= 1;
         }
         tile_stamp(2);
-#ifdef OWL_PP2_EARLY_RB0
-        constexpr bool EARLY_RB0 = !STAGGERED_EPI && (EPI == EPI_BIAS_BF16 || EPI == EPI_QGELU_BF16);
-#else
-        constexpr bool EARLY_RB0 = false;
-#endif
-        if (!STAGGERED_EPI && !EARLY_RB0 && grp == 0) q_bar();     // let group 1 finish its last MFMA phase: epilogues run together
+        if (!STAGGERED_EPI && grp == 0) q_bar();     // let group 1 finish its last MFMA phase: epilogues run together
         const bool inner = (cm0 + QBM <= p.M) && (cn0 + QBN <= p.N);
         // The next tile's K-tile 1 goes into the buffer the last K-tile just left (its A rows: both groups are past LOAD B).  Its A pieces are
         // requested HERE, ahead of the epilogue's stores, so that the counted wait of the next LOAD B can leave the stores in flight.
@@ -319,7 +314,6 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     epi_lines_bf16<EPI, G>(p, acc[i][0], acc[i][1], cm0 + grp * 128 + i * 32, cn0 + wc * 64, lane, lbias, bl);
-                    if (EARLY_RB0 && i == 0 && grp == 0) q_bar();
                     estamp(2 + i);
                 }
             } else {
@@ -340,7 +334,6 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
                         epi_store_chunk<EPI, G>(p, c1, mt, nt, 1, lane);
                     }
                 }
-                if (EARLY_RB0 && i == 0 && grp == 0) q_bar();
                 estamp(2 + i);
             }
             }
