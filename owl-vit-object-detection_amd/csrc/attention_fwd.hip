@@ -90,6 +90,12 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
     const int k_tile_bytes = (int)(64 * p.ld_qk * 2);
     auto stage = [&](int buf, int kv) {                            // full tiles: every key row < T
         unsigned char* base = lds + buf * 16384;
+#ifdef OWL_TUNING      // timing-only ablation (bit 3; wrong results): from the third tile on a wave issues ONE of its four pieces -- what a workgroup of 12 or 16 waves sharing the stage buffers would issue
+        if ((p.dbg & 8) && kv >= 2) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, LPTR(base + w * 8 * 128), 16, (int)k_voff, kv * k_tile_bytes, 0, 0);
+            return;
+        }
+#endif
 #pragma unroll
         for (int qd = 0; qd < 2; qd++) {
             const int r0 = w * 8 + qd * 32;
