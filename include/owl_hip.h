@@ -87,7 +87,8 @@ int owl_attention_fwd_bf16(void* stream, const void* q, const void* k, int64_t l
  * 3 = the peeled tiling on the one-wave-per-SIMD structure (csrc/attention_fwd_w64.hip: 64 queries per wave, 256 per workgroup, softmax
  * interleaved with the MFMAs of the neighbouring tiles): needs T - 1 a multiple of 64 >= 192 and `redo_ws` -- device scratch of
  * owl_attention_fwd_workspace_bytes(B, H, T) bytes (any contents; one int per query block, written by the kernel: blocks whose scores leave the
- * range its offset-free softmax covers are redone by the classic kernel in the same call).  redo_ws may be NULL for variants 0-2. */
+ * range its offset-free softmax covers are redone by the classic kernel in the same call).  redo_ws may be NULL for variants 0-2.
+ * (4, 5: OWL_TUNING builds only -- the stamped one-wave-per-SIMD kernel; the peeled tiling as one 12-wave workgroup per CU, same bits as 2.) */
 int owl_attention_fwd_workspace_bytes(int64_t B, int64_t H, int64_t T, int64_t* bytes);   /* redo_ws; `bytes` is a HOST pointer */
 int owl_attention_fwd_vrow_bf16(void* stream, const void* q, const void* k, const void* v, int64_t ld_qkv, void* out, int64_t ld_out, float* lse, int64_t B, int64_t H, int64_t T, int64_t Tp, float scale, int variant, int* redo_ws);
 

@@ -16,8 +16,11 @@
 #include "attention_fwd_common.h"
 #include <type_traits>
 
-template <bool VROW, bool PEEL = false>
-__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
+// NW: waves per workgroup.  4 (the shipped tiling): 128 queries per workgroup, three workgroups per CU, each staging every K / V tile for itself.  12 (tuning builds,
+// peeled tiling only): ONE workgroup of 384 queries per CU shares the two stage buffers -- a third of the LDS-DMA pieces and of the K / V fetches per query, at the
+// price of twelve waves meeting at one barrier per tile: bit-identical, measured 7-10 % SLOWER at B/16 (the ablation bound for the saved pieces was -6 %).
+template <bool VROW, bool PEEL = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 1) void attn_fwd_kernel(AttnFwdP p) {
     // dynamic LDS (one object): with a static array hipcc drains the just-issued LDS-DMA (vmcnt(0)) before the
     // first ds_read of every tile
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -35,14 +38,14 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
     const int b = pair / p.H, h = pair - b * p.H;
     static_assert(VROW || !PEEL, "the peeled tiling shifts the key rows by one: row-major V only");
     if constexpr (PEEL) {
-        if (p.redo) {       // fix-up launch behind the one-wave-per-SIMD kernel: only the flagged query blocks (normally none) are redone
+        if (NW == 4 && p.redo) {       // fix-up launch behind the one-wave-per-SIMD kernel: only the flagged query blocks (normally none) are redone
             if (qb == p.nqb - 1 || !p.redo[pair * p.redo_nqb + (qb >> 1)]) return;
         }
-        if (qb == p.nqb - 1) { attn_cls_row(p, b, h, lds); return; }       // workgroup-uniform
+        if (qb == p.nqb - 1) { if (w < 4) attn_cls_row(p, b, h, lds); return; }       // workgroup-uniform (the row is written by 256 threads)
     }
     // the tiles cover tokens PEEL .. T-1: Tk keys / queries, tile-local index + PEEL = token
     const int Tk = p.T - (PEEL ? 1 : 0);
-    const int q0 = qb * 128 + w * 32;
+    const int q0 = qb * (NW * 32) + w * 32;
     const float c = p.scale_log2e;
 
     // ---- Q fragments (B operand of S^T = K Q^T): lane -> query row q0 + (lane&31), 8 d per chunk
@@ -88,8 +91,30 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnFwdP p) {
     const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, 0x7fffffff, 0x00020000);
     const int k_tile_bytes = (int)(64 * p.ld_qk * 2);
+    // NW = 12: the tile's 16 pieces (8 K, 8 V row groups of 8 rows) go round the waves: wave w takes piece w and, waves 0-3, piece w + 12
+    unsigned pc_voff[2] = {0u, 0u};
+    int pc_lds[2] = {0, 0}, pc_isv[2] = {0, 0};
+    const int pc_n = NW == 4 ? 0 : (w < 4 ? 2 : 1);
+    if constexpr (NW != 4) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int pid = w + 12 * i, isv = pid >= 8, rg = pid & 7;
+            const int r = rg * 8 + (lane >> 3);
+            pc_isv[i] = isv; pc_lds[i] = (isv ? 8192 : 0) + rg * 8 * 128;
+            pc_voff[i] = (unsigned)((r * p.ld_qk + ((lane & 7) ^ (isv ? swz_vrow(r) : ((r >> 1) & 7))) * 8) * 2);
+        }
+    }
     auto stage = [&](int buf, int kv) {                            // full tiles: every key row < T
         unsigned char* base = lds + buf * 16384;
+        if constexpr (NW != 4) {
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+                if (i < pc_n) {
+                    if (pc_isv[i]) __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, LPTR(base + pc_lds[i]), 16, (int)pc_voff[i], kv * k_tile_bytes, 0, 0);
+                    else __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, LPTR(base + pc_lds[i]), 16, (int)pc_voff[i], kv * k_tile_bytes, 0, 0);
+                }
+            return;
+        }
 #ifdef OWL_TUNING      // timing-only ablation (bit 3; wrong results): from the third tile on a wave issues ONE of its four pieces -- what a workgroup of 12 or 16 waves sharing the stage buffers would issue
         if ((p.dbg & 8) && kv >= 2) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, LPTR(base + w * 8 * 128), 16, (int)k_voff, kv * k_tile_bytes, 0, 0);
@@ -418,7 +443,7 @@ static int attn_fwd_launch(void* stream, const void* q, const void* k, int64_t l
                            int64_t Tp, float scale, int variant, int* redo = nullptr) {
     OWL_CHECK_ARG(q && k && v && out, "owl_attention_fwd_bf16: null pointer");
     OWL_CHECK_ARG(ld_qk % 8 == 0 && ld_out % 8 == 0 && Tp % 8 == 0 && T > 0 && T <= Tp, "owl_attention_fwd_bf16: bad strides (ld_qk %% 8, ld_out %% 8, Tp %% 8)");
-    OWL_CHECK_ARG(variant >= 0 && variant <= 4 && (variant <= 1 || v_row_major), "owl_attention_fwd: variant must be 0 (default), 1 (plain tiling), 2 (class token peeled; row-major V only) or 3 (one wave per SIMD)");
+    OWL_CHECK_ARG(variant >= 0 && variant <= 5 && (variant <= 1 || v_row_major), "owl_attention_fwd: variant must be 0 (default), 1 (plain tiling), 2 (class token peeled; row-major V only) or 3 (one wave per SIMD)");
     const bool can_peel = v_row_major && T >= 65 && (T - 1) % 64 == 0;
     OWL_CHECK_ARG(variant != 2 || can_peel, "owl_attention_fwd: variant 2 (peeled) needs row-major V and T - 1 a positive multiple of 64");
     const bool can_w64 = can_peel && T - 1 >= 192 && redo != nullptr;
@@ -426,7 +451,23 @@ static int attn_fwd_launch(void* stream, const void* q, const void* k, int64_t l
 #ifndef OWL_TUNING
     OWL_CHECK_ARG(variant != 4, "owl_attention_fwd: variant 4 (stamped one-wave-per-SIMD kernel) exists only in an OWL_TUNING build");
 #endif
-    const bool w64 = variant >= 3;            // (4, OWL_TUNING builds: the s_memtime-stamped kernel, no fix-up launch -- tools/attn_w64_trace.py)
+#ifndef OWL_TUNING
+    OWL_CHECK_ARG(variant != 5, "owl_attention_fwd: variant 5 (12 waves per workgroup) exists only in an OWL_TUNING build");
+#else
+    if (variant == 5) {          // experimental (tools/attn_nw12_bench.py: bit-identical, +7 ... +10 % at B/16): twelve waves per workgroup sharing the stage buffers (peeled tiling)
+        OWL_CHECK_ARG(can_peel, "owl_attention_fwd: variant 5 (12 waves per workgroup) needs row-major V and T - 1 a positive multiple of 64");
+        AttnFwdP p{};
+        p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.ld_qk = ld_qk; p.vt = (const bf16_t*)v; p.vt_img_stride = vt_img_stride;
+        p.out = (bf16_t*)out; p.ld_out = ld_out; p.lse = lse; p.T = (int)T; p.Tp = (int)Tp; p.H = (int)H;
+        p.scale_log2e = scale * 1.4426950408889634f; p.B = (int)B; p.dbg = g_attn_dbg;
+        p.nqb = (int)((T - 1 + 383) / 384) + 1;
+        dim3 grid((unsigned)(((B * H + 7) / 8) * p.nqb * 8));
+        hipLaunchKernelGGL((attn_fwd_kernel<true, true, 12>), grid, dim3(768), 2 * 16384, (hipStream_t)stream, p);
+        OWL_LAUNCH_CHECK();
+        return 0;
+    }
+#endif
+    const bool w64 = variant == 3 || variant == 4;            // (4, OWL_TUNING builds: the s_memtime-stamped kernel, no fix-up launch -- tools/attn_w64_trace.py)
     const bool peel = variant == 2 || w64 || (variant == 0 && can_peel);
     AttnFwdP p{};
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.ld_qk = ld_qk;
