@@ -399,12 +399,12 @@ static int launch_pp2(hipStream_t s, GemmP p) {
     // 5 % slower blocked (its A panel is then fetched three times, beside the 455 MB of pre-activations it already streams), and so did the
     // WHOLE-batch fc1 inside the model (289 row panels: 0.387 -> 0.363 ms per launch row-major, old / new library alternated in bench.py
     // --encoder-streams 1; the stand-alone tool had it neutral) -- blocked only up to 160 row panels there (the sub-batch launches).
-    // Round 3, in the model, one process (tools/tile_order_ab.py): widths 2 ... 12 of fc1 and 3 / 9 of QKV are within 0.1 ms of each other per 26-27 ms step either
-    // schedule (only single columns lose, 0.5-1.2 ms), so the whole-batch fc1 is blocked like the rest: the W block stays in the XCD's L2 and the launch requests
-    // less from the fabric (row-major: 4.7 MB of W per XCD and round, answered by the infinity cache -- 0.8 GB read per launch for 0.12 GB of operands).
+    // Round 3: the whole-batch fc1 (tiles_m > 160: the one-stream schedule) takes blocks of 6 -- per launch 0.353-0.358 ms like row-major (blocks of 4: 0.370, HIP events in
+    // bench.py), and the W block (2.4 MB) stays in the XCD's L2: 545 MB requested from the fabric instead of 802 (row-major: 4.7 MB of W per XCD and round, answered by the
+    // infinity cache).  At step level every width from 2 to 12 is within 0.1 ms of the others either schedule (tools/tile_order_ab.py); only single columns lose (0.5-1.2 ms).
     p.nsplit = p.tiles_n;
     if (EPI == EPI_BIAS_BF16 || EPI == EPI_QGELU_BF16)
-        for (int d = 4; d >= 1; d--)
+        for (int d = (EPI == EPI_QGELU_BF16 && p.tiles_m > 160) ? 6 : 4; d >= 1; d--)
             if (p.tiles_n % d == 0) { p.nsplit = d; break; }
 #ifdef OWL_TUNING
     if constexpr (EPI == EPI_BIAS_BF16 || EPI == EPI_QGELU_BF16) {
