@@ -74,8 +74,8 @@ from owl_vit_object_detection_amd.config import get_config
 from owl_vit_object_detection_amd.losses import PushPullLoss
 from owl_vit_object_detection_amd.models import OwlViT
 from owl_vit_object_detection_amd.optim import FusedAdamW
-rank, world, local = ddp.init_from_env("nccl")
-dev = torch.device("cuda", local)
+rank, world, local = ddp.init_from_env({backend!r})
+dev = torch.device("cuda", local if {backend!r} == "nccl" else 0)       # (gloo variant: both ranks on the one visible GPU)
 cfg = get_config("small")
 model = OwlViT(cfg, weights.make_weights(cfg), dev)
 if rank == 1:
@@ -91,20 +91,58 @@ opt.zero_grad()
 pb, _, ps, _ = model(img)
 l = crit(ps, [torch.from_numpy(x).to(dev) for x in labels], pb, [torch.from_numpy(x).to(dev) for x in boxes])
 (l["loss_ce"] + l["loss_bg"] + l["loss_bbox"] + l["loss_giou"]).backward()
+dp.finish()                                       # deferred tail: the backward runs on the tail stream -- order this stream behind it before reading .grad
 local_grad = model.flat_grad.clone()
 dp.sync_and_step(); dp.finish(); torch.cuda.synchronize()
 np.savez(os.path.join({out!r}, f"rank{{rank}}.npz"), local=local_grad.cpu().numpy(), param=model.flat_param.cpu().numpy())
+hist = []
+for k in range(3):                                # a few more steps through the steady-state schedule (step k+1's frozen prefix under step k's tail)
+    opt.zero_grad()
+    pb, _, ps, _ = model(img)
+    l = crit(ps, [torch.from_numpy(x).to(dev) for x in labels], pb, [torch.from_numpy(x).to(dev) for x in boxes])
+    tot = l["loss_ce"] + l["loss_bg"] + l["loss_bbox"] + l["loss_giou"]
+    tot.backward(); dp.sync_and_step(); hist.append(tot.detach())
+dp.finish(); torch.cuda.synchronize()
+np.savez(os.path.join({out!r}, f"steady{{rank}}.npz"), param=model.flat_param.cpu().numpy(), loss=torch.stack(hist).cpu().numpy())
 dist.barrier(); dist.destroy_process_group()
 '''
+
+
+def _run_two_ranks(tmp_path, overlap, backend):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT, out=str(tmp_path), overlap=overlap, backend=backend))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), str(script)], capture_output=True, text=True, env=_env(), timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return [np.load(tmp_path / f"{name}{k}.npz") for name in ("rank", "steady") for k in (0, 1)]
+
+
+@pytest.mark.timeout(900)
+def test_two_gloo_ranks_on_one_gpu_deferred_tail_is_bitwise_the_inline_schedule(tmp_path):
+    """Two real ranks on the ONE visible GPU (gloo all-reduce of the CUDA bucket): the schedule with more than one rank -- backward + all-reduce + AdamW on
+    the tail stream under the next forward's frozen prefix -- leaves both replicas identical and bitwise where the in-line schedule leaves them, after one
+    step and after three more."""
+    res = {}
+    for overlap in (False, True):
+        d = tmp_path / ("overlap" if overlap else "inline"); d.mkdir()
+        res[overlap] = _run_two_ranks(d, overlap, "gloo")
+    for overlap in (False, True):
+        r0, r1, s0, s1 = res[overlap]
+        np.testing.assert_array_equal(r0["param"], r1["param"]); np.testing.assert_array_equal(s0["param"], s1["param"])
+    np.testing.assert_array_equal(res[False][0]["param"], res[True][0]["param"])
+    np.testing.assert_array_equal(res[False][0]["local"], res[True][0]["local"])
+    np.testing.assert_array_equal(res[False][2]["param"], res[True][2]["param"])
+    np.testing.assert_array_equal(res[False][2]["loss"], res[True][2]["loss"])
+    np.testing.assert_array_equal(res[False][3]["loss"], res[True][3]["loss"])
 
 
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("overlap", [False, True])
 def test_two_rank_rccl_step(tmp_path, overlap):
     if torch.cuda.device_count() < 2:
-        pytest.skip("needs 2 GPUs (the driver's 8-GPU node); the same code runs on 2 gloo ranks in tests/test_ddp_cpu.py")
+        pytest.skip("needs 2 GPUs (the driver's 8-GPU node); the same code runs on 2 gloo ranks in tests/test_ddp_cpu.py and, on one GPU, in the test above")
     script = tmp_path / "worker.py"
-    script.write_text(_WORKER.format(root=ROOT, out=str(tmp_path), overlap=overlap))
+    script.write_text(_WORKER.format(root=ROOT, out=str(tmp_path), overlap=overlap, backend="nccl"))
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                         "--master-port", str(_free_port()), str(script)], capture_output=True, text=True, env=_env(), timeout=800)
     assert r.returncode == 0, r.stderr[-3000:]
