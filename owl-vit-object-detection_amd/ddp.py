@@ -108,6 +108,9 @@ class DataParallel:
         self._checked_batch = True
 
     def _step(self):
+        # A model whose backward runs on its tail stream (FusedAdamW(overlap=True) switched overlap_tail on, or a previous deferred step is still
+        # in flight) is still accumulating into / zeroing the bucket THERE: the in-line collective on this stream must be ordered behind it.
+        self._order_behind_tail()
         allreduce_flat(self.model.flat_grad, self.group)
         if not self.fused and self.world > 1:
             self.model.flat_grad.mul_(1.0 / self.world)
@@ -123,6 +126,15 @@ class DataParallel:
         with torch.cuda.stream(self.side):
             allreduce_flat(self.model.flat_grad, self.group)     # RCCL on the tail stream, behind the backward
         self.optimizer.step()                           # FusedAdamW: update + bucket zeroing on the tail stream, event for the next forward
+
+    def _order_behind_tail(self):
+        m = self.model
+        if getattr(m, "flat_grad", None) is None or not m.flat_grad.is_cuda:
+            return
+        if hasattr(m, "_wait_params"):
+            m._wait_params()                            # a deferred step's event (all-reduce / AdamW / zeroing of the previous step)
+        if getattr(m, "overlap_tail", False) or getattr(m, "_tail_stream_", None) is not None:
+            torch.cuda.current_stream().wait_stream(m._tail_stream)    # a backward that was sent to the tail stream
 
     def finish(self):
         """Make the current stream wait for a deferred step (before reading parameters outside the model's forward)."""

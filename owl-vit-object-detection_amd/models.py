@@ -133,6 +133,7 @@ class OwlViT(nn.Module):
                         self._fz[f"{i}.{k}T"] = self._fz[f"{i}.{k}"].t().contiguous()
         self.box_bias = box_bias_table(cfg.grid).to(self.device_)
         self._ws = {}
+        self._gen = 0                      # generation of the latest forward (any batch size): see _forward_impl / autograd.OwlViTFunction
         self._ws_lru = []                  # batch sizes, most recent first: workspaces of all but the newest `max_cached_batch_sizes` are dropped
         self.max_cached_batch_sizes = 2    # (a DataLoader's ragged last batch + the regular one; every further size would pin its own activations)
         self._saved = None
@@ -210,6 +211,12 @@ class OwlViT(nn.Module):
         if B in lru:
             lru.remove(B)
         lru.insert(0, B)
+        # (with a deferred tail -- overlap_tail -- the backward / optimizer of the previous step may still be reading an evicted size's buffers
+        #  on the tail stream, and the caching allocator hands freed memory to the NEXT allocation on the compute stream without waiting for
+        #  other streams: order this stream behind the tail before anything is dropped)
+        if len(lru) > max(1, int(self.max_cached_batch_sizes)) and self._tail_stream_ is not None:
+            self._wait_params()
+            torch.cuda.current_stream().wait_stream(self._tail_stream_)
         while len(lru) > max(1, int(self.max_cached_batch_sizes)):
             old = lru.pop()
             for k in [k for k in self._ws if (k if isinstance(k, int) else k[1]) == old]:
@@ -239,7 +246,7 @@ class OwlViT(nn.Module):
             qhat=torch.zeros(32, Dt, device=dev), qnorm=torch.zeros(32, device=dev),
             argmax=torch.zeros(Mh, C, dtype=torch.uint8, device=dev), inv_norm=torch.zeros(Mh, device=dev),
             img=torch.zeros(B, 3, cfg.image_size, cfg.image_size, dtype=bf, device=dev),
-            gen=0,
+            gen=0,          # set from the model-global counter by every recording forward (_forward_impl)
         )
         self._ws[key] = ws
         return ws
@@ -414,7 +421,10 @@ class OwlViT(nn.Module):
         if tuple(image.shape[1:]) != (3, cfg.image_size, cfg.image_size):
             raise ValueError(f"image must be [B,3,{cfg.image_size},{cfg.image_size}], got {tuple(image.shape)}")
         ws = self._workspace(B, train=save)
-        ws["gen"] += 1
+        # model-global, monotonically increasing: a workspace rebuilt after an LRU eviction can never carry a generation an older autograd
+        # node still holds (a per-workspace counter restarted at 0 and could collide: fwd(A) -> two other sizes evict A -> fwd(A) again)
+        self._gen += 1
+        ws["gen"] = self._gen
         M, Mh = B * Tp, B * P
         P_ = self._byname
         if self._bf16_current and self._bf16_version == self.flat_param._version:

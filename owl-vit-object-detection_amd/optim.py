@@ -27,8 +27,23 @@ class FusedAdamW:
         self.step_count = 0
         self.grad_scale = 1.0          # set to 1/world_size by the data-parallel wrapper
 
+    def _attach(self):
+        """Re-attach detached `.grad` views (nn.Module.zero_grad(set_to_none=True) drops them).  Attaching zero-fills the bucket on the CURRENT
+        stream: behind a deferred tail that may still be reading / zeroing it."""
+        m = self.model
+        if any(p.grad is None for p in m.parameters() if p.requires_grad):
+            self._sync_tail()
+        _attach_grads(m)
+
+    def _sync_tail(self):
+        """Order the current stream behind everything the tail stream holds (deferred backward / all-reduce / AdamW / zeroing)."""
+        m = self.model
+        m._wait_params()
+        if m.flat_param.is_cuda and getattr(m, "_tail_stream_", None) is not None and torch.cuda.current_stream() != m._tail_stream_:
+            torch.cuda.current_stream().wait_stream(m._tail_stream_)
+
     def zero_grad(self, set_to_none: bool = False):
-        _attach_grads(self.model)
+        self._attach()
         if getattr(self.model, "_grad_clean", False):
             return                       # a deferred step (ddp.DataParallel(overlap=True)) already zeroed the bucket on its stream
         self.model._wait_params()
@@ -37,7 +52,7 @@ class FusedAdamW:
     @torch.no_grad()
     def step(self):
         m = self.model
-        _attach_grads(m)
+        self._attach()
         m._grad_clean = False
         self.step_count += 1
         deferred = getattr(m, "overlap_tail", False) and m.flat_param.is_cuda and torch.cuda.current_stream() != m._tail_stream
@@ -63,9 +78,11 @@ class FusedAdamW:
                   float(self.grad_scale))
 
     def state_dict(self):
+        self._sync_tail()               # a deferred step may still be writing the moments on the tail stream
         return dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, lr=self.lr, betas=self.betas,
                     eps=self.eps, weight_decay=self.weight_decay)
 
     def load_state_dict(self, sd):
+        self._sync_tail()
         self.step_count = int(sd["step"])
         self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])

@@ -232,3 +232,18 @@ def test_workspace_cache_keeps_the_two_latest_batch_sizes():
         model(img[:2]); model(img[:3])
     with pytest.raises(RuntimeError, match="evicted"):
         _loss(crit, ps, lab[:1], pb, box[:1]).backward()
+
+
+def test_evicted_then_rebuilt_workspace_cannot_collide_with_an_old_graph():
+    """fwd(A) -> forwards at two other sizes evict A -> a NEW fwd(A) rebuilds the workspace.  With a per-workspace counter restarted at zero the
+    rebuilt workspace carried the old graph's generation and the old backward silently differentiated against the new forward's activations; the
+    generation is model-global now."""
+    cfg, model, img, lab, box, crit = _setup(B=3)
+    pb_old, _, ps_old, _ = model(img[:1])
+    with torch.no_grad():
+        model(img[:2]); model(img[:3])                     # evicts size 1
+    pb_new, _, ps_new, _ = model(img[:1] * 0.5)            # rebuilds size 1: other activations
+    with pytest.raises(RuntimeError, match="overwritten"):
+        _loss(crit, ps_old, lab[:1], pb_old, box[:1]).backward()
+    _loss(crit, ps_new, lab[:1], pb_new, box[:1]).backward()     # the live graph still works
+    assert torch.isfinite(model.flat_grad).all()

@@ -80,7 +80,7 @@ cfg = get_config("small")
 model = OwlViT(cfg, weights.make_weights(cfg), dev)
 if rank == 1:
     model.flat_param.add_(0.5)                    # the broadcast from rank 0 must undo this
-opt = FusedAdamW(model, lr=1e-3, weight_decay=0.1)
+opt = FusedAdamW(model, lr=1e-3, weight_decay=0.1, overlap={opt_overlap})
 dp = ddp.DataParallel(model, opt, overlap={overlap})
 per = 2
 dp.check_equal_batches(per)
@@ -108,9 +108,9 @@ dist.barrier(); dist.destroy_process_group()
 '''
 
 
-def _run_two_ranks(tmp_path, overlap, backend):
+def _run_two_ranks(tmp_path, overlap, backend, opt_overlap=False):
     script = tmp_path / "worker.py"
-    script.write_text(_WORKER.format(root=ROOT, out=str(tmp_path), overlap=overlap, backend=backend))
+    script.write_text(_WORKER.format(root=ROOT, out=str(tmp_path), overlap=overlap, backend=backend, opt_overlap=opt_overlap))
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                         "--master-port", str(_free_port()), str(script)], capture_output=True, text=True, env=_env(), timeout=800)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -137,12 +137,28 @@ def test_two_gloo_ranks_on_one_gpu_deferred_tail_is_bitwise_the_inline_schedule(
 
 
 @pytest.mark.timeout(900)
+def test_two_gloo_ranks_tail_stream_backward_with_the_inline_collective(tmp_path):
+    """FusedAdamW(overlap=True) sends the backward to the tail stream while DataParallel(overlap=False) all-reduces in-line on the compute
+    stream -- the collective must order itself behind the tail (ddp.DataParallel._order_behind_tail), or it reads a bucket the backward is still writing.
+    Replicas identical, bitwise the plain in-line schedule."""
+    d0 = tmp_path / "inline"; d0.mkdir()
+    d1 = tmp_path / "mixed"; d1.mkdir()
+    ref = _run_two_ranks(d0, False, "gloo")
+    mix = _run_two_ranks(d1, False, "gloo", opt_overlap=True)
+    np.testing.assert_array_equal(mix[0]["param"], mix[1]["param"]); np.testing.assert_array_equal(mix[2]["param"], mix[3]["param"])
+    np.testing.assert_array_equal(ref[0]["local"], mix[0]["local"])
+    np.testing.assert_array_equal(ref[0]["param"], mix[0]["param"])
+    np.testing.assert_array_equal(ref[2]["param"], mix[2]["param"])
+    np.testing.assert_array_equal(ref[2]["loss"], mix[2]["loss"])
+
+
+@pytest.mark.timeout(900)
 @pytest.mark.parametrize("overlap", [False, True])
 def test_two_rank_rccl_step(tmp_path, overlap):
     if torch.cuda.device_count() < 2:
         pytest.skip("needs 2 GPUs (the driver's 8-GPU node); the same code runs on 2 gloo ranks in tests/test_ddp_cpu.py and, on one GPU, in the test above")
     script = tmp_path / "worker.py"
-    script.write_text(_WORKER.format(root=ROOT, out=str(tmp_path), overlap=overlap, backend="nccl"))
+    script.write_text(_WORKER.format(root=ROOT, out=str(tmp_path), overlap=overlap, backend="nccl", opt_overlap=False))
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                         "--master-port", str(_free_port()), str(script)], capture_output=True, text=True, env=_env(), timeout=800)
     assert r.returncode == 0, r.stderr[-3000:]
