@@ -32,9 +32,9 @@ extern "C" {
 
 /* ---- runtime ---------------------------------------------------------------------------------- */
 /* Bumped whenever a prototype, an argument's meaning or a caller-provided scratch layout changes (1 = round 1; 2 = round 2: per-call `tile` /
- * `variant` arguments, partial-sum scratch of the row reductions, 5D+4 box_final_bwd partials; 3 = round 3).  owl_abi_version() returns the value
+ * `variant` arguments, partial-sum scratch of the row reductions, 5D+4 box_final_bwd partials; 3 = round 3; 4 = round 4: `slow_tiles` statistic of the attention forward).  owl_abi_version() returns the value
  * the library was BUILT with: a binding compares it with the header it was generated from and refuses a mismatch (_lib.load() does). */
-#define OWL_ABI_VERSION 3
+#define OWL_ABI_VERSION 4
 const char* owl_last_error(void);
 int owl_abi_version(void);
 
@@ -88,9 +88,12 @@ int owl_attention_fwd_bf16(void* stream, const void* q, const void* k, int64_t l
  * interleaved with the MFMAs of the neighbouring tiles): needs T - 1 a multiple of 64 >= 192 and `redo_ws` -- device scratch of
  * owl_attention_fwd_workspace_bytes(B, H, T) bytes (any contents; one int per query block, written by the kernel: blocks whose scores leave the
  * range its offset-free softmax covers are redone by the classic kernel in the same call).  redo_ws may be NULL for variants 0-2.
+ * slow_tiles (optional, may be NULL): device int, += 1 for every (wave = 32 queries, 64-key tile) pair that leaves the fast path -- the tile's row sums
+ * against the offset the wave already holds exceed 2^40 (or are inf / NaN) and the tile is recomputed with an explicit maximum.  A wave's first tile
+ * is not counted.  Zero on scores of ordinary size (HF-init weights); trained weights with attention sinks trip it about once per wave and layer.
  * (4, 5: OWL_TUNING builds only -- the stamped one-wave-per-SIMD kernel; the peeled tiling as one 12-wave workgroup per CU, same bits as 2.) */
 int owl_attention_fwd_workspace_bytes(int64_t B, int64_t H, int64_t T, int64_t* bytes);   /* redo_ws; `bytes` is a HOST pointer */
-int owl_attention_fwd_vrow_bf16(void* stream, const void* q, const void* k, const void* v, int64_t ld_qkv, void* out, int64_t ld_out, float* lse, int64_t B, int64_t H, int64_t T, int64_t Tp, float scale, int variant, int* redo_ws);
+int owl_attention_fwd_vrow_bf16(void* stream, const void* q, const void* k, const void* v, int64_t ld_qkv, void* out, int64_t ld_out, float* lse, int64_t B, int64_t H, int64_t T, int64_t Tp, float scale, int variant, int* redo_ws, int* slow_tiles);
 
 /* backward of the fused attention (layers whose attention runs backward): qkv row-major [B*Tp,3D] (q|k|v), dO / O row-major
  * [B*Tp,D], lse from the forward; writes dqkv [B*Tp,3D] (dq|dk|dv, bf16).  Every transposed operand of the dK/dV/dQ MFMAs is read

@@ -305,6 +305,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 1) void attn_fwd_kernel(Attn
                     s[t][r] = __builtin_amdgcn_exp2f(s[t][r] - M);
                     ts += s[t][r];
                 }
+            // statistics for the caller (bench.py --weights trained_like, tests): how often the stale-offset verdict fails.  The first tile of a
+            // wave always comes here when its scores are large; it is not counted.
+            if (!first && p.slow_tiles && lane == 0) atomicAdd(p.slow_tiles, 1);
         }
         l_part += ts;
         // ---- O^T += V^T P^T (4 chunks of 16 keys, 2 d-blocks) ----
@@ -440,7 +443,7 @@ int attn_fwd_w64_launch(hipStream_t stream, const AttnFwdP& base, int* redo, int
 
 static int attn_fwd_launch(void* stream, const void* q, const void* k, int64_t ld_qk, const void* v, int v_row_major,
                            int64_t vt_img_stride, void* out, int64_t ld_out, float* lse, int64_t B, int64_t H, int64_t T,
-                           int64_t Tp, float scale, int variant, int* redo = nullptr) {
+                           int64_t Tp, float scale, int variant, int* redo = nullptr, int* slow_tiles = nullptr) {
     OWL_CHECK_ARG(q && k && v && out, "owl_attention_fwd_bf16: null pointer");
     OWL_CHECK_ARG(ld_qk % 8 == 0 && ld_out % 8 == 0 && Tp % 8 == 0 && T > 0 && T <= Tp, "owl_attention_fwd_bf16: bad strides (ld_qk %% 8, ld_out %% 8, Tp %% 8)");
     OWL_CHECK_ARG(variant >= 0 && variant <= 5 && (variant <= 1 || v_row_major), "owl_attention_fwd: variant must be 0 (default), 1 (plain tiling), 2 (class token peeled; row-major V only) or 3 (one wave per SIMD)");
@@ -475,7 +478,7 @@ static int attn_fwd_launch(void* stream, const void* q, const void* k, int64_t l
     p.out = (bf16_t*)out; p.ld_out = ld_out; p.lse = lse;
     p.T = (int)T; p.Tp = (int)Tp; p.H = (int)H;
     p.scale_log2e = scale * 1.4426950408889634f;
-    p.B = (int)B; p.dbg = g_attn_dbg;
+    p.B = (int)B; p.dbg = g_attn_dbg; p.slow_tiles = slow_tiles;
     p.nqb = peel ? (int)((T - 1 + 127) / 128) + 1 : (int)((T + 127) / 128);      // peeled: the last "block" is the class-token row
     const int64_t npairs8 = (B * H + 7) / 8;                  // pairs per XCD (rounded up)
     dim3 grid((unsigned)(npairs8 * p.nqb * 8));
@@ -502,8 +505,8 @@ extern "C" int owl_attention_fwd_bf16(void* stream, const void* q, const void* k
 
 // same, with V read where the QKV GEMM leaves it: row-major [B*Tp, ld_qkv], head h at column h*64 of `v` (no V^T copy at all)
 extern "C" int owl_attention_fwd_vrow_bf16(void* stream, const void* q, const void* k, const void* v, int64_t ld_qkv, void* out,
-                                           int64_t ld_out, float* lse, int64_t B, int64_t H, int64_t T, int64_t Tp, float scale, int variant, int* redo_ws) {
-    return attn_fwd_launch(stream, q, k, ld_qkv, v, 1, 0, out, ld_out, lse, B, H, T, Tp, scale, variant, redo_ws);
+                                           int64_t ld_out, float* lse, int64_t B, int64_t H, int64_t T, int64_t Tp, float scale, int variant, int* redo_ws, int* slow_tiles) {
+    return attn_fwd_launch(stream, q, k, ld_qkv, v, 1, 0, out, ld_out, lse, B, H, T, Tp, scale, variant, redo_ws, slow_tiles);
 }
 
 extern "C" int owl_attention_fwd_workspace_bytes(int64_t B, int64_t H, int64_t T, int64_t* bytes) {

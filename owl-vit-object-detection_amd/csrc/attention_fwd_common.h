@@ -12,6 +12,7 @@ struct AttnFwdP {
     float scale_log2e;
     const int* redo;                                    // fix-up mode (behind attention_fwd_w64.hip): run only the 128-query blocks whose
     int redo_nqb;                                       // 256-query block is flagged in redo[pair * redo_nqb + (qb >> 1)]
+    int* slow_tiles;                                    // optional device counter: += 1 per (wave, key tile) that leaves the fast path after a wave's first tile
 };
 
 __device__ __forceinline__ int swap23(int m) { return (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1); }

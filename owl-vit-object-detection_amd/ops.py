@@ -104,11 +104,16 @@ def attention_redo_ws(B, H, T, device):
     return buf
 
 
-def attention_fwd_vrow(q, k, v, ld_qkv, out, ld_out, lse, B, H, T, Tp, scale, variant=None):
+ATTN_SLOW_TILES = None   # optional int32[1] device tensor: every attention forward adds its count of slow-path tiles (bench.py --weights trained_like, tests)
+
+
+def attention_fwd_vrow(q, k, v, ld_qkv, out, ld_out, lse, B, H, T, Tp, scale, variant=None, slow_tiles=None):
     """attention_fwd with V row-major (a column slice of the qkv rows): no V^T copy."""
     variant = int(ATTN_VARIANT if variant is None else variant)
     redo = attention_redo_ws(B, H, T, out.device) if variant >= 3 else None
-    _lib.call("owl_attention_fwd_vrow_bf16", stream(), q, k, v, ld_qkv, out, ld_out, lse, B, H, T, Tp, float(scale), variant, redo)
+    if slow_tiles is None:
+        slow_tiles = ATTN_SLOW_TILES
+    _lib.call("owl_attention_fwd_vrow_bf16", stream(), q, k, v, ld_qkv, out, ld_out, lse, B, H, T, Tp, float(scale), variant, redo, slow_tiles)
     return out
 
 

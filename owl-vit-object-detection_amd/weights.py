@@ -80,8 +80,15 @@ def _std(name: str, cfg: OwlConfig) -> float:
     return 0.02
 
 
-def make_weights(cfg: OwlConfig, seed: int = 1234) -> "OrderedDict[str, np.ndarray]":
-    """name -> float32 ndarray; identical on every box for a given (cfg, seed)."""
+def make_weights(cfg: OwlConfig, seed: int = 1234, profile: str = "init") -> "OrderedDict[str, np.ndarray]":
+    """name -> float32 ndarray; identical on every box for a given (cfg, seed, profile).
+
+    profile "init": the HF initialisation scales (near-uniform softmax, no outlier channels, |sims| <~ 0.2).
+    profile "trained_like": the same draw reshaped to the statistics a TRAINED checkpoint shows (`trained_like` below)."""
+    if profile == "trained_like":
+        return trained_like(cfg, make_weights(cfg, seed, "init"), seed)
+    if profile != "init":
+        raise ValueError(f"unknown weight profile `{profile}` (init | trained_like)")
     out = OrderedDict()
     for name, shape in param_shapes(cfg).items():
         n = int(np.prod(shape))
@@ -100,6 +107,106 @@ def make_weights(cfg: OwlConfig, seed: int = 1234) -> "OrderedDict[str, np.ndarr
             out[name] = (0.02 * z).reshape(shape).astype(np.float32)
         else:
             out[name] = (_std(name, cfg) * z).reshape(shape).astype(np.float32)
+    return out
+
+
+# ---- "trained-like" statistics -------------------------------------------------------------------------
+# The reference trains from a TRAINED checkpoint (src/models.py:152 `from_pretrained`); neither box can download one.  What a trained CLIP / OWL-ViT
+# vision tower has and the HF init lacks, and which kernel path each item leans on:
+#   * a few "massive" residual channels, tens of times the typical scale, in every token (bias-fed) and much larger still in a handful of
+#     "sink" tokens            -> bf16 branch outputs / LayerNorm inputs with a coarse ulp; f32 residual stream
+#   * LayerNorm gains spread over two orders of magnitude       -> bf16 rounding of h = LN(x) channel by channel
+#   * attention logits with std ~ 8 (peaked softmax) and sink keys that a query can prefer by > 2^40 over everything it has seen
+#                                                              -> the attention forward's stale-offset / row-sum verdict / redo path
+#   * class embeddings aligned with the query bank so that |sims| reaches 0.9+   -> the focal BCE near its log clamp
+# Everything is a deterministic function of the "init" draw: the GPU box regenerates the tensors fixture F10 was made from.
+TRAINED_LIKE = dict(
+    massive_channels=(1 / 7, 1 / 3, 5 / 8),          # channel index as a fraction of D
+    massive_bias=(40.0, -25.0, 60.0),                # pre_layernorm.bias there (typical entries ~ 1)
+    fc2_bias_layers={3: (20.0, 10.0, -30.0), 7: (-12.0, 25.0, 15.0)},   # branch outputs that carry large values
+    ln_gain_log_range=(0.1, 10.0),                   # gamma log-uniform in this range ...
+    ln_gain_massive=0.3,                             # ... except on the massive channels (trained models damp them)
+    qk_gain=5.0,                                     # q_proj / k_proj weights x this: logit std ~ 6-10 at B/16 (tools/weight_stats.py)
+    sink_tokens=(0.55, 0.9, 0.995),                  # patch index as a fraction of P (late keys: the running offset is set before them)
+    sink_embed=60.0,                                 # position_embedding[sink, c0]: the sink tokens' massive activation
+    sink_k_col=3.0,                                  # k_proj.weight[:, c0] x this (all layers): sink keys stand out
+    class_align=((3, 5.5), (10, -2.0), (17, 1.0)),   # class_predictor.dense0.bias += a * |e|_typ * queries[j]
+)
+
+
+def trained_like(cfg: OwlConfig, base: "OrderedDict[str, np.ndarray]", seed: int = 1234) -> "OrderedDict[str, np.ndarray]":
+    t = TRAINED_LIKE
+    D, P = cfg.hidden, cfg.patches
+    out = OrderedDict((k, v.copy()) for k, v in base.items())
+    ch = [int(f * D) for f in t["massive_channels"]]
+    lo, hi = np.log(t["ln_gain_log_range"][0]), np.log(t["ln_gain_log_range"][1])
+    for name in out:
+        if ("layernorm" in name or "layer_norm" in name) and name.endswith("weight"):
+            u = rng.uniform(seed, cfg.name + "/tl/" + name, D)
+            g = np.exp(lo + (hi - lo) * u)
+            g[ch] = t["ln_gain_massive"]
+            sign = np.where(rng.uniform(seed, cfg.name + "/tl/sign/" + name, D) < 0.1, -1.0, 1.0)     # a few negative gains, as trained models have
+            out[name] = (g * sign).astype(np.float32)
+    b = out["backbone.pre_layernorm.bias"]
+    b[ch] = np.asarray(t["massive_bias"], np.float32)
+    out["backbone.pre_layernorm.weight"][ch] = 2.0                      # the sink tokens' activation passes pre_layernorm at full size
+    for li, vals in t["fc2_bias_layers"].items():
+        if li < cfg.layers:
+            out[f"backbone.encoder.layers.{li}.mlp.fc2.bias"][ch] = np.asarray(vals, np.float32)
+    pos = out["backbone.embeddings.position_embedding.weight"]
+    for f in t["sink_tokens"]:
+        pos[1 + min(P - 1, int(f * P)), ch[0]] = t["sink_embed"]
+    for i in range(cfg.layers):
+        pre = f"backbone.encoder.layers.{i}.self_attn."
+        out[pre + "q_proj.weight"] *= np.float32(t["qk_gain"])
+        out[pre + "k_proj.weight"] *= np.float32(t["qk_gain"])
+        out[pre + "q_proj.bias"] *= np.float32(t["qk_gain"])
+        out[pre + "k_proj.bias"] *= np.float32(t["qk_gain"])
+        out[pre + "k_proj.weight"][:, ch[0]] *= np.float32(t["sink_k_col"])
+    # class head: e = W f + b with |W f| ~ |f| (rows of std D^-0.5); feats are LayerNorm outputs, |f|^2 ~ sum gamma^2
+    g_pp = out["post_post_layernorm.weight"].astype(np.float64)
+    e_typ = float(np.sqrt((g_pp ** 2).sum() / D * cfg.text_dim))        # typical |W f|
+    q = out["queries"][0].astype(np.float64)
+    cb = out["class_predictor.dense0.bias"].astype(np.float64)
+    for j, a in t["class_align"]:
+        if j < q.shape[0]:
+            cb = cb + a * e_typ * q[j]
+    out["class_predictor.dense0.bias"] = cb.astype(np.float32)
+    return out
+
+
+# ---- checkpoint-name adapter (VERDICT r03 missing #3) -------------------------------------------------------------------
+def from_hf_state_dict(sd, queries=None) -> "OrderedDict[str, np.ndarray]":
+    """HF `OwlViTForObjectDetection.state_dict()` names -> the reference wrapper's parameter names (ref src/models.py:41-62: `backbone` = HF
+    `owlvit.vision_model`, `post_post_layernorm` = HF `layer_norm`, `class_predictor` = HF `class_head`, `box_head` unchanged).  Only the tensors
+    the vision path owns are taken (the text tower stays with `text.TextTower`; `class_head.logit_shift / logit_scale` are dropped by the reference,
+    src/models.py:24-38).  `queries` ([1, 3C, Dt] or [3C, Dt]) is the reference's `query_bank` (src/models.py:161-169); pass it here or add it to
+    the result before `load_model(..., state=)`.  Values may be torch tensors or arrays; the result holds float32 ndarrays."""
+    out = OrderedDict()
+
+    def arr(v):
+        if hasattr(v, "detach"):
+            v = v.detach().to("cpu").float().numpy()
+        return np.ascontiguousarray(np.asarray(v, dtype=np.float32))
+    for k, v in sd.items():
+        if k.startswith("owlvit.vision_model."):
+            name = "backbone." + k[len("owlvit.vision_model."):]
+        elif k.startswith("vision_model."):                      # a bare OwlViTModel / vision tower state dict
+            name = "backbone." + k[len("vision_model."):]
+        elif k.startswith("layer_norm."):
+            name = "post_post_layernorm." + k[len("layer_norm."):]
+        elif k.startswith("class_head.dense0."):
+            name = "class_predictor.dense0." + k[len("class_head.dense0."):]
+        elif k.startswith("box_head."):
+            name = k
+        else:
+            continue                                             # text tower, projections, logit shift / scale, buffers
+        if name.endswith("position_ids"):
+            continue
+        out[name] = arr(v)
+    if queries is not None:
+        q = arr(queries)
+        out["queries"] = q[None] if q.ndim == 2 else q
     return out
 
 

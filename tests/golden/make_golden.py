@@ -90,7 +90,7 @@ torch.manual_seed(0)
 torch.set_num_threads(8)
 
 
-def build_reference_model(cfg, seed=1234):
+def build_reference_model(cfg, seed=1234, profile="init"):
     hf_cfg = OwlViTConfig(
         vision_config=dict(hidden_size=cfg.hidden, intermediate_size=cfg.mlp, num_hidden_layers=cfg.layers,
                            num_attention_heads=cfg.heads, image_size=cfg.image_size, patch_size=cfg.patch_size,
@@ -102,7 +102,7 @@ def build_reference_model(cfg, seed=1234):
     hf_cfg._attn_implementation = "eager"
     hf_cfg.vision_config._attn_implementation = "eager"
     hf = OwlViTForObjectDetection(hf_cfg)
-    W = weights.make_weights(cfg, seed)
+    W = weights.make_weights(cfg, seed, profile)
     sd = hf.state_dict()
     for name, arr in W.items():
         if name == "queries":
@@ -195,6 +195,10 @@ def grad_summary(grads, full):
         else:
             d["gradnorm/" + n] = np.float64(np.linalg.norm(g.astype(np.float64)))
             d["gradhead/" + n] = g.reshape(-1)[:64].copy()
+            # a strided 4096-element sample over the WHOLE tensor (a 64-element head is bf16 noise for the small tensors)
+            flat = g.reshape(-1)
+            stride = max(1, flat.size // 4096)
+            d["gradsample/" + n] = flat[::stride][:4096].copy()
     return d
 
 
@@ -233,6 +237,78 @@ def _full(cname, tag, seed=1234):
 
 def f2():
     _full("owlvit-base-patch16", "f2_b16")
+
+
+def attention_stats(model, cfg, image):
+    """Statistics of the reference's own attention logits on `image` (hooks on every layer's layer_norm1): per layer the std / max of the logits
+    and a simulation of the HIP forward's softmax-offset logic on them -- the kernel (csrc/attention_fwd.hip) exponentiates a 64-key tile against
+    the offset it already holds and only recomputes (`slow path`) when a row sum of the tile exceeds 2^40; one wave = 32 consecutive queries, the class
+    token is peeled (key 0 is the initial state, |s0| > 40 sets the offset), tiles cover keys 1..T-1 in order.  `slow_tiles` = (wave, tile) pairs
+    that would take the slow path at this layer, all heads (the first tile of a wave does not count: it cannot overflow an empty state)."""
+    hs = {}
+    hooks = []
+    for li, layer in enumerate(model.backbone.encoder.layers):
+        hooks.append(layer.layer_norm1.register_forward_hook(lambda m, i, o, li=li: hs.__setitem__(li, o.detach())))
+    with torch.no_grad():
+        model(torch.from_numpy(image))
+    for h in hooks:
+        h.remove()
+    H, dh, T = cfg.heads, cfg.head_dim, cfg.tokens
+    LOG2E = 1.4426950408889634
+    std, mx, slow, peak = [], [], [], []
+    for li, layer in enumerate(model.backbone.encoder.layers):
+        h = hs[li][0]
+        sa = layer.self_attn
+        q = (h @ sa.q_proj.weight.T + sa.q_proj.bias).view(T, H, dh).transpose(0, 1)
+        k = (h @ sa.k_proj.weight.T + sa.k_proj.bias).view(T, H, dh).transpose(0, 1)
+        att = torch.matmul(q, k.transpose(1, 2)) * (dh ** -0.5)            # [H, T, T] natural-log units
+        std.append(float(att.std())); mx.append(float(att.abs().max()))
+        peak.append(float(torch.softmax(att, -1).max(-1).values.mean()))
+        s2 = att[:, 1:, :] * LOG2E                                          # queries 1..T-1 (query 0 is the VALU-only workgroup)
+        nq = (T - 1) // 32 * 32
+        n_slow = 0
+        s0 = s2[:, :nq, 0]
+        M = torch.where(s0.abs() > 40, s0, torch.zeros_like(s0))           # [H, nq] per-query offset
+        keys = s2[:, :nq, 1:]
+        for t0 in range(0, keys.shape[-1] - 63, 64):
+            tile = keys[:, :, t0:t0 + 64]
+            rs = torch.exp2((tile - M[..., None]).double()).sum(-1)        # row sums against the held offset
+            trip = (rs > 2.0 ** 40).view(H, nq // 32, 32).any(-1)          # wave-uniform verdict
+            n_slow += int(trip.sum())
+            tm = tile.max(-1).values
+            upd = trip[..., None].expand(H, nq // 32, 32).reshape(H, nq)
+            M = torch.where(upd, torch.maximum(M, tm), M)
+        slow.append(n_slow)
+    return dict(logit_std=np.array(std), logit_absmax=np.array(mx), softmax_peak_mean=np.array(peak), slow_tiles=np.array(slow, np.int64))
+
+
+def f10():
+    """F10 -- trained-like statistics end to end: weights.make_weights(cfg, profile="trained_like") through the reference at batch 1,
+    tiny (all intermediates + all gradients) and full B/16 768^2 (outputs, losses, decisions, gradient norms + samples), plus the attention statistics
+    of the reference's own logits (what the HIP attention forward's offset / verdict logic will meet)."""
+    for cname, tag, full in (("tiny", "f10_tiny_trained", True), ("owlvit-base-patch16", "f10_b16_trained", False)):
+        cfg = get_config(cname)
+        model, _ = build_reference_model(cfg, profile="trained_like")
+        img = synth.make_images(cfg, 1)
+        labels, boxes = synth.make_targets(cfg, 1, max_boxes=6 if full else 16)
+        scales = synth.class_scales(cfg, labels)
+        taps = {} if full else None
+        out, grads = run_reference_step(model, cfg, img, labels[0], boxes[0], scales, taps)
+        out["target_classes"] = recover_spread_labels(cfg, out)
+        out["scales"] = scales
+        if full:
+            for k, v in taps.items():
+                out["tap/" + k] = v.numpy()
+        out.update(grad_summary(grads, full=full))
+        st = attention_stats(model, cfg, img)
+        for k, v in st.items():
+            out["attn/" + k] = v
+        np.savez_compressed(os.path.join(HERE, f"{tag}.npz"), **out)
+        print(tag, {k: float(out[k]) for k in ("loss_ce", "loss_bg", "loss_bbox", "loss_giou")})
+        print("   |sims| max", float(np.abs(out["pred_sims"]).max()), "quantiles", np.quantile(np.abs(out["pred_sims"]), [0.5, 0.9, 0.99]).round(3),
+              "boxes range", float(out["pred_boxes"].min()), float(out["pred_boxes"].max()))
+        print("   logit std per layer", st["logit_std"].round(2), "\n   |logit| max", st["logit_absmax"].round(1),
+              "\n   mean softmax peak", st["softmax_peak_mean"].round(3), "\n   slow tiles per layer", st["slow_tiles"])
 
 
 def f3():

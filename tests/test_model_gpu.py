@@ -346,3 +346,103 @@ def test_l14_train_step_matches_reference_fixture_f4(golden_dir):
         assert float(gr.double().norm()) == pytest.approx(ref_norm, rel=REL_NORM_L14), n
     print(f"L/14 end-to-end gradients vs F4: worst |norm ratio - 1| = {worst_norm:.3e}")
     print("near-tie between a matched prediction and its target:", near_tie)
+
+
+# ---------------------------------------------------------------------------------------------------
+# F10: trained-like statistics end to end against the reference.  Every other fixture is taken at HF-init random weights
+# (near-uniform softmax, no outlier channels, |sims| <~ 0.2); weights.make_weights(profile="trained_like") has massive residual channels, LayerNorm
+# gains over two decades, attention logits of std ~ 8 with sink keys that trip the forward kernel's stale-offset verdict, and |sims| > 0.9.
+# The north star's bf16 bar (outputs within 1e-2) is the assertion; measured values are printed and quoted in DESIGN.md.
+# ---------------------------------------------------------------------------------------------------
+TOL_TRAINED = 1e-2
+
+
+def _sample(gr, n=4096):
+    flat = gr.reshape(-1)
+    stride = max(1, flat.numel() // n)
+    return flat[::stride][:n]
+
+
+@pytest.mark.parametrize("cname,tag,max_boxes", [("tiny", "f10_tiny_trained", 6), ("owlvit-base-patch16", "f10_b16_trained", 16)])
+def test_trained_like_train_step_matches_reference_fixture_f10(golden_dir, cname, tag, max_boxes):
+    from owl_vit_object_detection_amd import ops
+    cfg = get_config(cname)
+    g = np.load(os.path.join(golden_dir, f"{tag}.npz"))
+    img = synth.make_images(cfg, 1)
+    labels, boxes = synth.make_targets(cfg, 1, max_boxes=max_boxes)
+    counter = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.ATTN_SLOW_TILES = counter
+    try:
+        model, crit, lg, grads, pb, ps = _step_hip(cfg, weights.make_weights(cfg, profile="trained_like"), img, labels, boxes, g["scales"])
+        torch.cuda.synchronize()
+    finally:
+        ops.ATTN_SLOW_TILES = None
+    slow = int(counter.item())
+    eb, es = _maxerr(pb, torch.from_numpy(g["pred_boxes"])), _maxerr(ps, torch.from_numpy(g["pred_sims"]))
+    rb = float((pb.cpu() - torch.from_numpy(g["pred_boxes"])).pow(2).mean().sqrt()); rs = float((ps.cpu() - torch.from_numpy(g["pred_sims"])).pow(2).mean().sqrt())
+    same = float((crit.last["target_classes"][0].cpu() == torch.from_numpy(g["target_classes"])).float().mean())
+    print(f"F10 {cname}: max|d boxes|={eb:.3e} (rms {rb:.2e}) max|d sims|={es:.3e} (rms {rs:.2e}); max|sims| ref {float(np.abs(g['pred_sims']).max()):.3f}; "
+          f"slow-path tiles: kernel {slow}, predicted from the reference's logits {int(g['attn/slow_tiles'].sum())}; target agreement {same}")
+    print("   losses", lg, "ref", {k: float(g[k]) for k in LOSS_KEYS})
+    assert eb < TOL_TRAINED and es < TOL_TRAINED, (eb, es)
+    # the attention forward's stale-offset verdict: exercised where the reference's own logits say it must be (and only there)
+    pred = int(g["attn/slow_tiles"].sum())
+    if pred == 0:
+        assert slow == 0
+    else:
+        assert 0.5 * pred <= slow <= 2.0 * pred, (slow, pred)
+    bound = _class_loss_bound(cfg, g, es)
+    ref_l, n_swaps, n_rows = _reference_losses_for_decisions(cfg, g, labels, boxes, crit, eb, es)
+    print("   decisions differing from the fixture: assignment swaps", n_swaps, "label rows", n_rows)
+    for k in LOSS_KEYS:
+        ref = ref_l[k] if (n_swaps or n_rows) else float(g[k])
+        assert abs(lg[k] - ref) <= max(2e-2 * abs(ref), 1e-2, bound.get(k, 0.0)), (k, lg[k], ref, bound)
+    # gradients: norm ratio + cosine on a 4096-element strided sample of every tensor that carries signal
+    key = "grad/" if ("grad/queries" in g.files) else None
+    big = max(float(np.linalg.norm(g["grad/" + n])) if key else float(g["gradnorm/" + n]) for n in grads)
+    worst_norm, worst_cos, lines = 0.0, 1.0, []
+    for n, gr in grads.items():
+        ref_full = torch.from_numpy(g["grad/" + n]) if key else None
+        ref_norm = float(ref_full.double().norm()) if key else float(g["gradnorm/" + n])
+        ref_s = _sample(ref_full) if key else torch.from_numpy(g["gradsample/" + n])
+        ours_s = _sample(gr)
+        ratio = float(gr.double().norm()) / max(ref_norm, 1e-30)
+        cos = float((ours_s.double() * ref_s.double()).sum() / (ours_s.double().norm() * ref_s.double().norm() + 1e-30))
+        lines.append(f"     {n:58s} |ref|={ref_norm:.3e} norm ratio {ratio:.4f} cos(sample) {cos:.5f}")
+        if ref_norm < 1e-2 * big or n_swaps or n_rows:
+            continue
+        worst_norm = max(worst_norm, abs(ratio - 1.0)); worst_cos = min(worst_cos, cos)
+    print("\n".join(lines))
+    print(f"   F10 {cname} end-to-end gradients: worst |norm ratio - 1| = {worst_norm:.3e}, worst sample cosine = {worst_cos:.5f}")
+    assert worst_norm < 0.25 and worst_cos > 0.9, (worst_norm, worst_cos)
+
+
+@pytest.mark.parametrize("cname,B", [("tiny", 2), ("owlvit-base-patch16", 1)])
+def test_backward_chain_trained_like_matches_oracle_given_same_upstream(cname, B):
+    """The backward-chain test on trained-like weights: peaked softmax through the attention backward, large LayerNorm gains through ln_bwd."""
+    cfg = get_config(cname)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    Wnp = weights.make_weights(cfg, profile="trained_like")
+    img = synth.make_images(cfg, B)
+    gen = torch.Generator().manual_seed(5)
+    d_boxes = torch.randn(B, cfg.patches, 4, generator=gen) * 0.1
+    d_sims = torch.randn(B, cfg.patches, cfg.n_classes, generator=gen) * 0.1
+    w = {k: torch.from_numpy(v) for k, v in Wnp.items()}
+    names = O.trainable_names(w)
+    ww = {n: (t.clone().requires_grad_(True) if n in names else t) for n, t in w.items()}
+    taps = {}
+    rb, rs = O.model_forward(cfg, ww, torch.from_numpy(img), taps)
+    with torch.no_grad():
+        e = torch.nn.functional.linear(taps["feats"], w["class_predictor.dense0.weight"], w["class_predictor.dense0.bias"])
+        e = e / (torch.linalg.norm(e, dim=-1, keepdim=True) + 1e-6)
+        q = w["queries"] / torch.linalg.norm(w["queries"], dim=-1, keepdim=True) + 1e-6
+        top2 = (e @ q.transpose(1, 2)).view(B, cfg.patches, cfg.n_classes, 3).topk(2, dim=-1).values
+        d_sims = d_sims * ((top2[..., 0] - top2[..., 1]) > 0.02).float()
+    model = OwlViT(cfg, Wnp, DEV)
+    pb, _, ps, _ = model(torch.from_numpy(img).to(DEV))
+    torch.autograd.backward([pb, ps], [d_boxes.to(DEV), d_sims.to(DEV)])
+    grads = {n: p.grad.detach().float().cpu() for n, p in model.named_parameters() if p.requires_grad}
+    torch.autograd.backward([rb, rs], [d_boxes, d_sims])
+    gref = {n: ww[n].grad for n in names}
+    worst, worst_cos = _grad_report(grads, gref, f"backward-only trained-like {cname} B={B}")
+    assert worst < 5e-2 and worst_cos > 0.998, (worst, worst_cos)

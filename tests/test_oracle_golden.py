@@ -13,8 +13,8 @@ from owl_vit_object_detection_amd.config import get_config
 LOSS_KEYS = ("loss_ce", "loss_bg", "loss_bbox", "loss_giou")
 
 
-def _w(cfg, seed=1234):
-    return {k: torch.from_numpy(v) for k, v in weights.make_weights(cfg, seed).items()}
+def _w(cfg, seed=1234, profile="init"):
+    return {k: torch.from_numpy(v) for k, v in weights.make_weights(cfg, seed, profile).items()}
 
 
 @pytest.mark.parametrize("cname", ["tiny", "tiny-l14"])
@@ -52,13 +52,13 @@ def test_f1_tiny_full_intermediates_losses_grads(golden_dir, cname):
         np.testing.assert_allclose(grads[n].numpy(), ref, rtol=1e-3, atol=tol, err_msg=n)
 
 
-def _check_full(golden_dir, cname, tag):
+def _check_full(golden_dir, cname, tag, profile="init"):
     path = os.path.join(golden_dir, f"{tag}.npz")
     if not os.path.exists(path):
         pytest.skip(f"{tag}.npz not generated")
     cfg = get_config(cname)
     g = np.load(path)
-    w = _w(cfg)
+    w = _w(cfg, profile=profile)
     img = torch.from_numpy(synth.make_images(cfg, 1))
     labels, boxes = synth.make_targets(cfg, 1, max_boxes=16)
     scales = torch.from_numpy(synth.class_scales(cfg, labels))
@@ -81,6 +81,42 @@ def _check_full(golden_dir, cname, tag):
 def test_f2_b16_full_size(golden_dir):
     """BASELINE configs[0]: owlvit-base-patch16, batch 1, 768x768, 10 classes, CPU path."""
     _check_full(golden_dir, "owlvit-base-patch16", "f2_b16")
+
+
+@pytest.mark.timeout(600)
+def test_f10_b16_trained_like_full_size(golden_dir):
+    """F10: the reference run on trained-like weights (massive channels, wide LayerNorm gains, peaked attention with sink keys, |sims| > 0.9) --
+    the oracle reproduces it at fp32 tightness, decisions included."""
+    _check_full(golden_dir, "owlvit-base-patch16", "f10_b16_trained", profile="trained_like")
+    g = np.load(os.path.join(golden_dir, "f10_b16_trained.npz"))
+    assert float(np.abs(g["pred_sims"]).max()) > 0.9 and 5.0 < float(g["attn/logit_std"].mean()) < 10.0 and int(g["attn/slow_tiles"].min()) > 0
+
+
+def test_f10_tiny_trained_like_all_intermediates(golden_dir):
+    cfg = get_config("tiny")
+    g = np.load(os.path.join(golden_dir, "f10_tiny_trained.npz"))
+    w = _w(cfg, profile="trained_like")
+    img = torch.from_numpy(synth.make_images(cfg, 1))
+    labels, boxes = synth.make_targets(cfg, 1, max_boxes=6)
+    scales = torch.from_numpy(synth.class_scales(cfg, labels))
+    taps = {}
+    pb, ps = O.model_forward(cfg, w, img, taps)
+    for k in ["embed", "pre_ln", "feats"] + [f"backbone.encoder.layers.{i}.out" for i in range(cfg.layers)]:
+        ref = g["tap/" + k]
+        np.testing.assert_allclose(taps[k].numpy(), ref, rtol=2e-4, atol=2e-5 * max(1.0, float(np.abs(ref).max())), err_msg=k)
+    np.testing.assert_allclose(pb.numpy(), g["pred_boxes"], atol=2e-5)
+    np.testing.assert_allclose(ps.numpy(), g["pred_sims"], atol=2e-5)
+    lab = [torch.from_numpy(l) for l in labels]
+    tb = [torch.from_numpy(b) for b in boxes]
+    (pb2, ps2), losses, grads = O.train_step(cfg, w, img, lab, tb, scales)
+    details = []
+    O.push_pull_loss(ps2, lab, pb2, tb, cfg.n_classes, scales, details)
+    assert np.array_equal(details[0]["pred_idx"].numpy(), g["pred_idx"]) and np.array_equal(details[0]["target_classes"].numpy(), g["target_classes"])
+    for k in LOSS_KEYS:
+        assert float(losses[k]) == pytest.approx(float(g[k]), rel=2e-4, abs=1e-6), k
+    for n, gr in grads.items():
+        ref = g["grad/" + n]
+        np.testing.assert_allclose(gr.numpy(), ref, rtol=2e-3, atol=2e-4 * max(1e-6, float(np.abs(ref).max())), err_msg=n)
 
 
 @pytest.mark.timeout(1200)
