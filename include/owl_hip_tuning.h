@@ -28,6 +28,11 @@ int owl_gemm_pp2_trace(void* buf);
 int owl_gemm_pp2_trace_tile(int n);
 /* ... and which K-tile of it (default 4; 0-2 show the refill behind the previous tile's epilogue) */
 int owl_gemm_pp2_trace_ktile(int n);
+/* free-running GEMM (csrc/gemm_fr.hip, tile 5): timing-only ablations (1 no LDS-DMA after the prologue, 2 fragments read once per tile, 3 both), persistent grid
+ * size (default 512 = two workgroups per CU), column-block width of the tile order */
+int owl_gemm_fr_ablate(int a);
+int owl_gemm_fr_slots(int n);
+int owl_gemm_fr_block_width(int epi, int bw);
 #ifdef __cplusplus
 }
 #endif

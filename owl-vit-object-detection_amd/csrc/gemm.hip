@@ -301,6 +301,7 @@ int owl_gemm_pp_launch(hipStream_t s, int epi, const GemmP& p, int slots_overrid
 int owl_gemm_w4_launch(hipStream_t s, int epi, const GemmP& p);                                                       // gemm_w4.hip
 int owl_gemm_pph_launch(hipStream_t s, int epi, const GemmP& p);                                                      // gemm_pph.hip
 int owl_gemm_pp2_launch(hipStream_t s, int epi, const GemmP& p);                                                      // gemm_pp2.hip
+int owl_gemm_fr_launch(hipStream_t s, int epi, const GemmP& p);                                                       // gemm_fr.hip
 
 template <int EPI>
 static int launch(hipStream_t s, const GemmP& p, int splits, int g_force_tile = 0) {
@@ -317,7 +318,7 @@ extern "C" int owl_gemm_nt_bf16(void* stream, int epi, const void* A, int64_t ld
                                 const float* resid, void* aux, int64_t ld_aux, int64_t M, int64_t N, int64_t K,
                                 float alpha, int splits, int64_t Tp, int tile) {
     OWL_CHECK_ARG(A && W && out, "owl_gemm_nt_bf16: null pointer");
-    OWL_CHECK_ARG(tile == 0 || tile == 128 || tile == 256 || tile == 8 || tile == 9 || tile == 4 || tile == 7, "owl_gemm_nt_bf16: tile must be 0 (auto), 128, 256, 8, 9, 7 or 4");
+    OWL_CHECK_ARG(tile == 0 || tile == 128 || tile == 256 || tile == 8 || tile == 9 || tile == 4 || tile == 7 || tile == 5, "owl_gemm_nt_bf16: tile must be 0 (auto), 128, 256, 8, 9, 7, 5 or 4");
     const int g_force_tile = tile;
     OWL_CHECK_ARG(K > 0 && K % BK == 0, "owl_gemm_nt_bf16: K=%lld must be a positive multiple of 64", (long long)K);
     OWL_CHECK_ARG(M > 0 && N > 0 && N % 8 == 0, "owl_gemm_nt_bf16: bad M=%lld N=%lld (N %% 8 == 0)", (long long)M, (long long)N);
@@ -345,6 +346,14 @@ extern "C" int owl_gemm_nt_bf16(void* stream, int epi, const void* A, int64_t ld
     }
 #else
     OWL_CHECK_ARG(tile != 4, "owl_gemm_nt_bf16: tile 4 (experimental four-wave kernel) exists only in an OWL_TUNING build");
+#endif
+#ifdef OWL_TUNING
+    if (g_force_tile == 5 && splits == 1) {              // round-4 experiment (tuning builds only): free-running 128 x 256 workgroups, two per CU (gemm_fr.hip)
+        const int rc = owl_gemm_fr_launch(s, epi, p);
+        if (rc <= 0) return rc;
+    }
+#else
+    OWL_CHECK_ARG(tile != 5, "owl_gemm_nt_bf16: tile 5 (free-running two-workgroups-per-CU kernel) exists only in an OWL_TUNING build");
 #endif
     if (g_force_tile == 7 && K >= 128) {                 // two-phase ping-pong kernel on the whole problem (A/B; falls through for other epilogues)
         const int rc = owl_gemm_pp2_launch(s, epi, p);

@@ -84,11 +84,11 @@ def make_weights(cfg: OwlConfig, seed: int = 1234, profile: str = "init") -> "Or
     """name -> float32 ndarray; identical on every box for a given (cfg, seed, profile).
 
     profile "init": the HF initialisation scales (near-uniform softmax, no outlier channels, |sims| <~ 0.2).
-    profile "trained_like": the same draw reshaped to the statistics a TRAINED checkpoint shows (`trained_like` below)."""
-    if profile == "trained_like":
-        return trained_like(cfg, make_weights(cfg, seed, "init"), seed)
+    profile "trained_like" / "trained_like_hard": the same draw reshaped to the statistics a TRAINED checkpoint shows (`trained_like` below)."""
+    if profile in TRAINED_LIKE_PROFILES:
+        return trained_like(cfg, make_weights(cfg, seed, "init"), seed, profile)
     if profile != "init":
-        raise ValueError(f"unknown weight profile `{profile}` (init | trained_like)")
+        raise ValueError(f"unknown weight profile `{profile}` (init | {' | '.join(TRAINED_LIKE_PROFILES)})")
     out = OrderedDict()
     for name, shape in param_shapes(cfg).items():
         n = int(np.prod(shape))
@@ -124,9 +124,9 @@ TRAINED_LIKE = dict(
     massive_channels=(1 / 7, 1 / 3, 5 / 8),          # channel index as a fraction of D
     massive_bias=(40.0, -25.0, 60.0),                # pre_layernorm.bias there (typical entries ~ 1)
     fc2_bias_layers={3: (20.0, 10.0, -30.0), 7: (-12.0, 25.0, 15.0)},   # branch outputs that carry large values
-    ln_gain_log_range=(0.1, 10.0),                   # gamma log-uniform in this range ...
+    ln_gain_log_range=(0.3, 3.0),                    # gamma log-uniform in this range (one decade) ...
     ln_gain_massive=0.3,                             # ... except on the massive channels (trained models damp them)
-    qk_gain=5.0,                                     # q_proj / k_proj weights x this: logit std ~ 6-10 at B/16 (tools/weight_stats.py)
+    qk_gain=16.0,                                    # q_proj / k_proj weights x this: logit std ~ 8 at B/16 (tests/golden/make_golden.py f10 prints it)
     sink_tokens=(0.55, 0.9, 0.995),                  # patch index as a fraction of P (late keys: the running offset is set before them)
     sink_embed=60.0,                                 # position_embedding[sink, c0]: the sink tokens' massive activation
     sink_k_col=3.0,                                  # k_proj.weight[:, c0] x this (all layers): sink keys stand out
@@ -134,8 +134,18 @@ TRAINED_LIKE = dict(
 )
 
 
-def trained_like(cfg: OwlConfig, base: "OrderedDict[str, np.ndarray]", seed: int = 1234) -> "OrderedDict[str, np.ndarray]":
-    t = TRAINED_LIKE
+# "trained_like_hard": LayerNorm gains over TWO decades (VERDICT r03's literal [0.1, 10]).  That alone makes the network ill-conditioned -- fp32 arithmetic
+# on bf16-ROUNDED WEIGHTS, nothing else rounded, already moves pred_boxes by 2e-2 (tests/bf16_emulation.py) -- so no bf16 implementation can hold the
+# 1e-2 bar on it; it pins that the HIP path's deviation there is the data type's (tests/test_model_gpu.py).  The peaked attention is NOT what costs
+# accuracy: one decade of gains with logit std 10 stays at 4e-3.
+TRAINED_LIKE_PROFILES = {
+    "trained_like": TRAINED_LIKE,
+    "trained_like_hard": dict(TRAINED_LIKE, ln_gain_log_range=(0.1, 10.0), qk_gain=5.0),
+}
+
+
+def trained_like(cfg: OwlConfig, base: "OrderedDict[str, np.ndarray]", seed: int = 1234, profile: str = "trained_like") -> "OrderedDict[str, np.ndarray]":
+    t = TRAINED_LIKE_PROFILES[profile]
     D, P = cfg.hidden, cfg.patches
     out = OrderedDict((k, v.copy()) for k, v in base.items())
     ch = [int(f * D) for f in t["massive_channels"]]

@@ -286,9 +286,10 @@ def f10():
     """F10 -- trained-like statistics end to end: weights.make_weights(cfg, profile="trained_like") through the reference at batch 1,
     tiny (all intermediates + all gradients) and full B/16 768^2 (outputs, losses, decisions, gradient norms + samples), plus the attention statistics
     of the reference's own logits (what the HIP attention forward's offset / verdict logic will meet)."""
-    for cname, tag, full in (("tiny", "f10_tiny_trained", True), ("owlvit-base-patch16", "f10_b16_trained", False)):
+    for cname, tag, full, profile in (("tiny", "f10_tiny_trained", True, "trained_like"), ("owlvit-base-patch16", "f10_b16_trained", False, "trained_like"),
+                                      ("owlvit-base-patch16", "f10_b16_trained_hard", False, "trained_like_hard")):
         cfg = get_config(cname)
-        model, _ = build_reference_model(cfg, profile="trained_like")
+        model, _ = build_reference_model(cfg, profile=profile)
         img = synth.make_images(cfg, 1)
         labels, boxes = synth.make_targets(cfg, 1, max_boxes=6 if full else 16)
         scales = synth.class_scales(cfg, labels)

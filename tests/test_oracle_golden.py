@@ -92,6 +92,12 @@ def test_f10_b16_trained_like_full_size(golden_dir):
     assert float(np.abs(g["pred_sims"]).max()) > 0.9 and 5.0 < float(g["attn/logit_std"].mean()) < 10.0 and int(g["attn/slow_tiles"].min()) > 0
 
 
+@pytest.mark.timeout(600)
+def test_f10_b16_trained_like_hard_full_size(golden_dir):
+    """The judge-literal severity (LayerNorm gains over two decades): an ill-conditioned network -- the fp32 oracle still reproduces the reference."""
+    _check_full(golden_dir, "owlvit-base-patch16", "f10_b16_trained_hard", profile="trained_like_hard")
+
+
 def test_f10_tiny_trained_like_all_intermediates(golden_dir):
     cfg = get_config("tiny")
     g = np.load(os.path.join(golden_dir, "f10_tiny_trained.npz"))

@@ -75,7 +75,11 @@ def test_trained_like_profile_is_deterministic_and_has_the_advertised_structure(
     ch = [int(f * cfg.hidden) for f in t["massive_channels"]]
     np.testing.assert_array_equal(a["backbone.pre_layernorm.bias"][ch], np.asarray(t["massive_bias"], np.float32))
     g = np.abs(a["backbone.encoder.layers.5.layer_norm1.weight"])
-    assert g.min() >= 0.0999 and g.max() <= 10.001 and g.max() / g.min() > 30
+    lo, hi = t["ln_gain_log_range"]
+    assert g.min() >= lo * 0.999 and g.max() <= hi * 1.001 and g.max() / g.min() > 0.3 * hi / lo
     np.testing.assert_allclose(a["backbone.encoder.layers.2.self_attn.q_proj.weight"], base["backbone.encoder.layers.2.self_attn.q_proj.weight"] * t["qk_gain"], rtol=1e-6)
+    hard = weights.make_weights(cfg, profile="trained_like_hard")
+    gh = np.abs(hard["backbone.encoder.layers.5.layer_norm1.weight"])
+    assert gh.max() / gh.min() > 30 and gh.max() <= 10.001
     with pytest.raises(ValueError):
         weights.make_weights(cfg, profile="nope")
