@@ -13,12 +13,16 @@ HBM, random-init weights (no network on the box).
 (torch.distributed.run, one process per GPU, RCCL); it exits non-zero if fewer than N GPUs are visible.
 
 Prints ONE JSON line (rank 0) with the driver's contract plus:
-  roofline       -- the dominant kernel by time (`gemm_pp2_kernel<bias>`: QKV / out-proj / fc2 / dX GEMMs, ~30 % of the
-                    step): algorithmic FLOPs per launch / mean launch duration, HIP events on the launch stream inside
-                    the timed region; peak = 2.5 PFLOP/s dense bf16 MFMA (MI355X_MICROARCH.md)
+  roofline       -- the dominant op by time (the bias-epilogue GEMM: QKV / out-proj / fc2 / dX, ~30 % of the step; one op =
+                    `gemm_pp2_kernel<bias>` + its half-height remainder launch `gemm_pph_kernel<bias>` where the dispatcher
+                    splits): algorithmic FLOPs per op / mean op duration, HIP events on the launch stream inside the timed
+                    region; peak = 2.5 PFLOP/s dense bf16 MFMA (MI355X_MICROARCH.md)
   roofline_other -- the same measurement for the fc1 GEMM (`gemm_pp2_kernel<qgelu>`) and the fused attention forward
   cpu_baseline   -- the CPU oracle (parity-checked restatement of the reference path) timed on this box's host cores
-                    (batch 1 and batch 8, median of >= 5 steps after 2 warm-ups), rank 0 at N = 1 only
+                    (batch 1 -- the reference's own batch size --, median of >= 5 steps after 2 warm-ups), rank 0 at N = 1 only
+With more than one rank the line also carries `replicas_equal` (MIN / MAX all-reduce of an exact checksum of the trainable bucket) and the
+result of the schedule pre-flight (`config.schedule_check`): the deferred-tail schedule is only reported after it reproduced the in-line
+schedule's losses and parameters bitwise on this very node; an in-line measurement is taken FIRST and is what the line falls back to.
 """
 import argparse
 import json
@@ -46,9 +50,12 @@ PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md "Peak BF16/FP
 # (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE in separate passes, FETCH x2 per MI355X_MICROARCH.md "HBM"); None elsewhere
 # The JSON carries the digest of the kernel sources it was measured on (tools/pmc_traffic.py); a figure taken on other sources is
 # refused (traffic = null) rather than quoted: a kernel edit must not silently keep an old number.
-TRAFFIC_FILE = "profiles/r03_traffic.json"
-TRAFFIC_SOURCE = "profiles/r03_hbm_traffic.md"
-TRAFFIC = {"gemm_pp2_kernel<bias>": None, "gemm_pp2_kernel<qgelu>": None, "attn_fwd_kernel<VROW>": None}
+TRAFFIC_FILE = "profiles/r04_traffic.json"
+TRAFFIC_SOURCE = "profiles/r04_hbm_traffic.md"
+LABEL_BIAS = "gemm op <bias> (gemm_pp2_kernel + gemm_pph_kernel remainder)"
+LABEL_QGELU = "gemm_pp2_kernel<qgelu>"
+LABEL_ATTN = "attn_fwd_kernel<VROW>"
+TRAFFIC_ALL = {}            # workload key ("<arch>/<batch per GPU>") -> {label: bytes per op}
 TRAFFIC_NOTE = None
 
 
@@ -67,7 +74,7 @@ try:
     with open(os.path.join(ROOT, TRAFFIC_FILE)) as _f:
         _t = json.load(_f)
     if _t.get("kernel_source_digest") == kernel_source_digest():
-        TRAFFIC.update({k: v for k, v in _t.items() if k in TRAFFIC})
+        TRAFFIC_ALL = _t.get("workloads", {})
     else:
         TRAFFIC_NOTE = f"{TRAFFIC_FILE} was measured on other kernel sources (digest {_t.get('kernel_source_digest')}): not quoted"
 except (OSError, ValueError):
@@ -83,6 +90,10 @@ def parse():
     ap.add_argument("--arch", default="owlvit-base-patch16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--cpu-batch8", action="store_true", help="also time the CPU oracle at batch 8 (~20 s per step: 2 warm-ups + --cpu-steps timed steps)")
+    ap.add_argument("--weights", choices=("init", "trained_like", "trained_like_hard"), default="init",
+                    help="weights.make_weights profile: init = HF initialisation scales (headline); trained_like = massive residual channels, wide LayerNorm "
+                         "gains, attention logits of std ~ 8 with sink keys, |sims| > 0.9 (fixture F10): the attention forward then takes its slow path")
     ap.add_argument("--forward-only", action="store_true", help="BASELINE configs[1]-style forward throughput (diagnostic)")
     ap.add_argument("--targets", choices=("lists", "packed"), default="lists",
                     help="lists = per-image label/box lists through PushPullLoss.__call__ as ref main.py:77-83 (headline); "
@@ -91,6 +102,9 @@ def parse():
     ap.add_argument("--overlap", action="store_true", help="backward + all-reduce + AdamW on the model's tail stream under the next step's frozen prefix "
                                                            "(models.OwlViT.overlap_tail; bitwise the in-line result)")
     ap.add_argument("--no-overlap", action="store_true", help="in-line all-reduce + AdamW even with more than one rank")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="nccl = RCCL (the product path).  gloo: test-only -- lets several ranks share one visible GPU (tests/test_ddp_rccl_gpu.py runs the "
+                         "multi-rank flow of this file on a 1-GPU box); never a benchmark result")
     ap.add_argument("--no-kernel-events", action="store_true", help="no HIP events around the GEMM / attention launches (overhead A/B)")
     ap.add_argument("--encoder-streams", type=int, default=2,
                     help="sub-batches of the encoder forward / dX-only backward, one HIP stream each (OwlViT(encoder_streams=...)); 1 = one stream "
@@ -140,9 +154,11 @@ def _cpu_model_string():
     return "unknown CPU"
 
 
-def cpu_baseline(cfg, steps):
+def cpu_baseline(cfg, steps, batch8=False):
     """Time the CPU oracle (restated reference path, fp32) on this box's host cores: full train steps (fwd + matcher + loss +
-    bwd; the 11 ms AdamW is left out as in BASELINE.md's breakdown) at batch 1 and batch 8, median after 2 warm-ups."""
+    bwd; the 11 ms AdamW is left out as in BASELINE.md's breakdown) at batch 1 (the reference's own batch size; SURVEY.md 8(d)(ii) protocol:
+    median of >= 5 steps after 2 warm-ups).  Batch 8 costs ~20 s per step and the oracle gains nothing from batching (0.41 against 0.48 img/s,
+    profiles/r03_cpu_threads.md): that leg runs only with --cpu-batch8, at the same protocol."""
     from oracle import owl_oracle as O
     from owl_vit_object_detection_amd import synth, weights
     # SURVEY.md section 8(d)(ii) names os.cpu_count() threads; measured on the GPU box's 256 logical cores (profiles/r03_cpu_threads.md) the
@@ -153,10 +169,8 @@ def cpu_baseline(cfg, steps):
     torch.set_num_threads(cores)
     w = {k: torch.from_numpy(v) for k, v in weights.make_weights(cfg).items()}
     res = {}
-    # batch 8 costs ~20 s per step: by default it gets 1 warm-up + 2 timed steps (the batch-1 leg keeps the full 2 + `steps`) so that the
-    # default run stays inside the bench contract's "10-30 s of CPU work, a few minutes in all"; --cpu-steps >= 8 runs the full protocol on
-    # both legs.  The oracle gains nothing from batching, so `value` is the batch-1 figure either way (profiles/r03_cpu_threads.md)
-    for B, n_warm, n_steps in ((1, 2, steps), (8, 2 if steps >= 8 else 1, steps if steps >= 8 else 2)):
+    steps = max(5, steps)
+    for B, n_warm, n_steps in ((1, 2, steps),) + (((8, 2, steps),) if batch8 else ()):
         img = torch.from_numpy(synth.make_images(cfg, B))
         labels, boxes = synth.make_targets(cfg, B, max_boxes=16)
         lab = [torch.from_numpy(l) for l in labels]; tb = [torch.from_numpy(b) for b in boxes]
@@ -169,14 +183,18 @@ def cpu_baseline(cfg, steps):
             O.train_step(cfg, w, img, lab, tb, scales)
             ts.append(time.perf_counter() - t0)
         res[B] = (float(np.median(ts)), len(ts), n_warm)
-    (m1, n1, w1), (m8, n8, w8) = res[1], res[8]
-    best = max(1.0 / m1, 8.0 / m8)
-    return {"value": round(best, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-            "batch1_images_per_sec": round(1.0 / m1, 4), "batch8_images_per_sec": round(8.0 / m8, 4),
-            "cpu": f"{_cpu_model_string()} ({total} logical cores, {cores} torch threads used)",
-            "sample": f"fp32 train steps (fwd+matcher+loss+bwd) of {cfg.name} on the CPU oracle: batch 1 median {m1:.2f} s/step over "
-                      f"{n1} steps after {w1} warm-ups, batch 8 median {m8:.2f} s/step over {n8} steps after {w8} warm-up(s); value = the "
-                      "better of the two; the reference itself: 0.32 img/s on 8 vCPUs (BASELINE.md section 2)"}
+    m1, n1, w1 = res[1]
+    out = {"value": round(1.0 / m1, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+           "batch1_images_per_sec": round(1.0 / m1, 4),
+           "cpu": f"{_cpu_model_string()} ({total} logical cores, {cores} torch threads used)",
+           "sample": f"fp32 train steps (fwd+matcher+loss+bwd) of {cfg.name} on the CPU oracle at the reference's batch size of 1: median {m1:.2f} s/step "
+                     f"over {n1} steps after {w1} warm-ups; the reference itself: 0.32 img/s on 8 vCPUs (BASELINE.md section 2)"}
+    if 8 in res:
+        m8, n8, w8 = res[8]
+        out["batch8_images_per_sec"] = round(8.0 / m8, 4)
+        out["value"] = round(max(1.0 / m1, 8.0 / m8), 4)
+        out["sample"] += f"; batch 8: median {m8:.2f} s/step over {n8} steps after {w8} warm-ups (value = the better of the two)"
+    return out
 
 
 EVENT_EVERY = 10
@@ -188,7 +206,7 @@ class KernelTimer:
     def __init__(self):
         self.on = False
         self.rec = {}           # kernel label -> list of (event0, event1, flops)
-        self.traffic_applies = True     # the counter file was taken on the headline workload (B/16, batch 32 per GPU)
+        self.traffic = {}               # label -> counter bytes per op for THIS workload (profiles/r04_traffic.json), if measured on these kernel sources
 
     def wrap(self, orig, classify):
         def f(*a, **k):
@@ -215,9 +233,8 @@ class KernelTimer:
         mean_ms = float(np.mean(ms))
         achieved = flops / (mean_ms * 1e-3) / 1e12
         return {"bound": "mfma", "kernel": label, "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": TRAFFIC.get(label) if self.traffic_applies else None,
-                "traffic_source": (TRAFFIC_SOURCE if TRAFFIC.get(label) else TRAFFIC_NOTE) if self.traffic_applies
-                                  else f"{TRAFFIC_FILE} is the headline workload's (B/16, batch 32): not quoted for this one",
+                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": self.traffic.get(label),
+                "traffic_source": TRAFFIC_SOURCE if self.traffic.get(label) else (TRAFFIC_NOTE or f"{TRAFFIC_FILE} holds no counter pass for this workload"),
                 "launches_timed": len(ev), "ms_per_launch": round(mean_ms, 4), "gflop_per_launch": round(flops / 1e9, 2),
                 "ms_total_per_step": None}
 
@@ -232,7 +249,9 @@ def main():
     from owl_vit_object_detection_amd.optim import FusedAdamW
     from owl_vit_object_detection_amd import synth
 
-    rank, world, local = ddp.init_from_env("nccl")
+    rank, world, local = ddp.init_from_env(args.backend)
+    if args.backend == "gloo":
+        local = local % max(1, torch.cuda.device_count())
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run --nproc-per-node {args.gpus}, "
                          f"or plain `python bench.py --gpus {args.gpus}`)")
@@ -243,17 +262,21 @@ def main():
     cfg = get_config(args.arch)
     B = args.batch
 
-    model = OwlViT(cfg, weights.make_weights(cfg), dev, encoder_streams=args.encoder_streams)    # identical weights on every rank (seeded)
+    model = OwlViT(cfg, weights.make_weights(cfg, profile=args.weights), dev, encoder_streams=args.encoder_streams)    # identical weights on every rank (seeded)
+    slow_tiles = torch.zeros(1, dtype=torch.int32, device=dev)      # attention forward: (wave, key tile) pairs that left the fast path (csrc/attention_fwd.hip)
+    ops.ATTN_SLOW_TILES = slow_tiles
     batches = synth_batches(cfg, B, dev, rank)
     scales = synth.class_scales(cfg, [l for l in batches[0]["labels_np"]])
     crit = PushPullLoss(cfg.n_classes, scales)
     opt = FusedAdamW(model, lr=3e-6, weight_decay=0.1)            # ref config.yaml:10,12
-    dp = ddp.DataParallel(model, opt, overlap=(args.overlap or world > 1) and not args.no_overlap)
+    dist_active = world > 1 or os.environ.get("OWL_FORCE_DIST", "0") == "1"
+    want_overlap = (args.overlap or world > 1) and not args.no_overlap
+    dp = ddp.DataParallel(model, opt, overlap=want_overlap)
     dp.check_equal_batches(B)
 
     # ---- kernel timing: HIP events around the GEMM (bf16-output epilogues) and fused-attention-forward launches -------
     kt = KernelTimer()
-    kt.traffic_applies = (cfg.name == "owlvit-base-patch16" and B == 32 and not args.forward_only)
+    kt.traffic = {} if (args.forward_only or args.weights != "init") else TRAFFIC_ALL.get(f"{cfg.name}/{B}", {})
 
     def classify_gemm(epi, A, W, out, bias=None, resid=None, aux=None, M=None, N=None, K=None, **kw):
         if epi not in (ops.EPI_BIAS_BF16, ops.EPI_QGELU_BF16):
@@ -261,10 +284,10 @@ def main():
         K = K if K is not None else A.shape[-1]; N = N if N is not None else W.shape[0]; M = M if M is not None else A.shape[0]
         if not (K % 128 == 0 and M >= 512 and N >= 256):
             return None                                            # not the ping-pong kernel (csrc/gemm.hip dispatch)
-        return ("gemm_pp2_kernel<bias>" if epi == ops.EPI_BIAS_BF16 else "gemm_pp2_kernel<qgelu>", 2.0 * M * N * K)
+        return (LABEL_BIAS if epi == ops.EPI_BIAS_BF16 else LABEL_QGELU, 2.0 * M * N * K)
 
     def classify_attn(q, k, v, ld, out, ld_out, lse, B_, H, T, Tp, scale):
-        return ("attn_fwd_kernel<VROW>", 4.0 * B_ * H * T * T * 64)   # QK^T + PV per launch
+        return (LABEL_ATTN, 4.0 * B_ * H * T * T * 64)   # QK^T + PV per launch
 
     if not args.no_kernel_events:
         ops.gemm = kt.wrap(ops.gemm, classify_gemm)
@@ -288,7 +311,7 @@ def main():
         if args.forward_only:
             with torch.no_grad():
                 model(bt["img"])
-            return
+            return None
         opt.zero_grad()
         pred_boxes, _, pred_sims, _ = model(bt["img"])
         if mode == "lists":
@@ -298,6 +321,12 @@ def main():
         loss = losses["loss_ce"] + losses["loss_bg"] + losses["loss_bbox"] + losses["loss_giou"]
         loss.backward()
         dp.sync_and_step()
+        return loss.detach()
+
+    def set_schedule(overlap):
+        dp.finish(); torch.cuda.synchronize()
+        dp.overlap = bool(overlap)
+        model.overlap_tail = bool(overlap)
 
     def timed_run(mode, steps, warmup, record):
         for i in range(warmup):
@@ -306,6 +335,7 @@ def main():
             dist.barrier()
         dp.finish()
         torch.cuda.synchronize()
+        slow_tiles.zero_()
         t0 = time.perf_counter()
         for i in range(steps):
             # Kernel events on every EVENT_EVERY-th timed step only: an event pair around each of a step's ~70 GEMM / attention launches
@@ -331,15 +361,50 @@ def main():
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        return dt
+        return dt, int(slow_tiles.item())
 
-    dt = timed_run(args.targets, args.steps, args.warmup, True)
-    other = None
-    if not args.forward_only and not args.no_compare:
-        other_mode = "packed" if args.targets == "lists" else "lists"
-        other = (other_mode, timed_run(other_mode, args.steps, 1, False))
+    # ---- more than one rank (or one forced rank): make the run unloseable ---------------------------------------------
+    # The deferred-tail schedule (backward + RCCL + AdamW on the model's tail stream under the next forward's frozen prefix) is the faster one with
+    # peers, but an 8-GPU node is the first place it meets RCCL with more than one rank.  So: (1) measure the IN-LINE schedule first -- RCCL on the
+    # compute stream, the plain usage -- and keep its line; (2) pre-flight: the same two steps from the same state in-line and deferred must give the
+    # same losses and parameters BITWISE (tests/test_ddp_rccl_gpu.py does this over gloo); (3) only then measure the deferred schedule, under a
+    # watchdog that prints the in-line line and exits if the deferred phase does not come back.  `replicas_equal` is checked after each phase.
+    def replicas_equal():
+        if not dist_active:
+            return None
+        c = model.flat_param.view(torch.int32).to(torch.int64).sum()          # exact: any differing bit moves it
+        t = torch.stack([c, -c])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t[0]) == -int(t[1]))
 
-    if rank == 0:
+    def snapshot():
+        dp.finish(); torch.cuda.synchronize()
+        return (model.flat_param.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.step_count)
+
+    def restore(st):
+        dp.finish(); torch.cuda.synchronize()
+        model.flat_param.copy_(st[0]); opt.exp_avg.copy_(st[1]); opt.exp_avg_sq.copy_(st[2]); opt.step_count = st[3]
+        model.flat_grad.zero_(); model._grad_clean = False
+        model.refresh_compute_weights(force=True)
+        torch.cuda.synchronize()
+
+    def preflight(mode):
+        st = snapshot()
+        res = {}
+        for overlap in (False, True):
+            set_schedule(overlap)
+            losses = [step(k, mode) for k in range(2)]
+            dp.finish(); torch.cuda.synchronize()
+            res[overlap] = (torch.stack(losses).cpu(), model.flat_param.clone())
+            restore(st)
+        same = torch.equal(res[False][0], res[True][0]) and torch.equal(res[False][1], res[True][1])
+        if dist_active:                                       # every rank must reach the same verdict
+            t = torch.tensor([1 if same else 0], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            same = bool(int(t[0]))
+        return same
+
+    def report(dt, slow, schedule, extra_cfg):
         ms = dt / args.steps * 1e3
         value = B * world * args.steps / dt
         flops_img = cfg.flops_forward() if args.forward_only else cfg.flops_train_step()
@@ -348,26 +413,28 @@ def main():
                       + ("OWL-ViT-B/16 768x768" if cfg.name == "owlvit-base-patch16" else f"{cfg.name} {cfg.image_size}x{cfg.image_size}"),
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic (CLIP-normalised uniform-u8 pixels, 1-16 boxes/image, 10 classes; random-init weights)",
+            "dtype": "bf16", "data": "synthetic (CLIP-normalised uniform-u8 pixels, 1-16 boxes/image, 10 classes; "
+                                     + ("random-init weights)" if args.weights == "init" else f"random weights reshaped to trained-like statistics, weights.make_weights(profile='{args.weights}'))"),
             "config": {"workload": f"{cfg.name} bf16, batch={B}/GPU, {cfg.image_size}x{cfg.image_size}, "
                                    + ("forward only" if args.forward_only else "full train step (matcher+loss+backward+AdamW)")
                                    + (f", DDP over {world} GPUs, one RCCL all-reduce of the flat grad bucket/step" if world > 1 else ""),
                        "global_batch": B * world, "tokens": cfg.tokens, "parallelism": f"dp{world}",
                        "targets": args.targets + (" (per-image label/box lists through PushPullLoss.__call__, ref main.py:77-83)" if args.targets == "lists" else " (pre-padded)"),
                        "encoder_streams": args.encoder_streams,
-                       "optimizer_schedule": "backward + all-reduce + AdamW on the tail stream under the next step's frozen prefix (bitwise the in-line schedule)" if dp.overlap else "in-line",
+                       "weights": args.weights,
+                       "attention_slow_tiles_per_step": round(slow / max(1, args.steps), 1),
+                       "optimizer_schedule": schedule,
                        "gflop_per_image": round(flops_img / 1e9, 1),
                        "step_mfma_frac": round(flops_img * value / world / 1e12 / PEAK_BF16_TFLOPS, 4)},
             "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
-            "backend": (dist.get_backend() + " (RCCL over xGMI)") if dist.is_initialized() else "none (single process)",
+            "backend": (dist.get_backend() + (" (RCCL over xGMI)" if dist.get_backend() == "nccl" else " (TEST ONLY: not a benchmark)")) if dist.is_initialized() else "none (single process)",
         }
-        if other is not None:
-            out["config"]["images_per_sec_" + other[0] + "_targets"] = round(B * world * args.steps / other[1], 2)
+        out["config"].update(extra_cfg)
         if ar_events:
             out["allreduce_ms"] = round(float(np.mean([a.elapsed_time(b) for a, b in ar_events])), 4)
             out["allreduce_bytes"] = int(model.flat_numel * 4)
         main_r, others = None, []
-        for label in ("gemm_pp2_kernel<bias>", "gemm_pp2_kernel<qgelu>", "attn_fwd_kernel<VROW>"):
+        for label in (LABEL_BIAS, LABEL_QGELU, LABEL_ATTN):
             r = kt.summary(label)
             if r is None:
                 continue
@@ -381,9 +448,61 @@ def main():
         if main_r is not None:
             out["roofline"] = main_r
             out["roofline_other"] = others
+        return out
+
+    SCHED_TAIL = "backward + all-reduce + AdamW on the tail stream under the next step's frozen prefix (bitwise the in-line schedule)"
+    extra = {}
+    line = None
+    if dist_active and want_overlap and not args.forward_only:
+        import threading
+        set_schedule(False)
+        dt_in, slow_in = timed_run(args.targets, args.steps, args.warmup, True)
+        eq_in = replicas_equal()
+        extra["images_per_sec_inline_schedule"] = round(B * world * args.steps / dt_in, 2)
+        line_inline = report(dt_in, slow_in, "in-line", dict(extra))
+        line_inline["replicas_equal"] = eq_in
+
+        def bail():            # the deferred phase did not come back: the in-line measurement is the result
+            if rank == 0:
+                line_inline["config"]["schedule_check"] = f"deferred-tail phase did not finish within {int(limit)} s: in-line schedule reported"
+                print(json.dumps(line_inline), flush=True)
+            os._exit(0 if rank == 0 else 3)
+        limit = max(120.0, 40.0 * dt_in)
+        dog = threading.Timer(limit, bail); dog.daemon = True; dog.start()
+        ok = preflight(args.targets)
+        if ok:
+            set_schedule(True)
+            dt, slow = timed_run(args.targets, args.steps, args.warmup, False)
+            eq = replicas_equal()
+            dog.cancel()
+            if eq is False or eq_in is False:
+                ok = False
+        else:
+            dog.cancel()
+        if ok:
+            extra["schedule_check"] = "pre-flight: 2 steps from one state, deferred tail == in-line bitwise (losses and parameters); in-line measured first"
+            extra["images_per_sec_deferred_tail_schedule"] = round(B * world * args.steps / dt, 2)
+            line = report(dt, slow, SCHED_TAIL, extra)
+            line["replicas_equal"] = bool(eq and eq_in)
+        else:
+            set_schedule(False)
+            line_inline["config"]["schedule_check"] = "pre-flight MISMATCH between the deferred-tail and the in-line schedule (or replicas diverged): in-line schedule reported"
+            line = line_inline
+    else:
+        set_schedule(want_overlap and not args.forward_only and model.flat_grad.is_cuda)
+        dt, slow = timed_run(args.targets, args.steps, args.warmup, True)
+        line = report(dt, slow, SCHED_TAIL if dp.overlap else "in-line", extra)
+        if dist_active:
+            line["replicas_equal"] = replicas_equal()
+    if not args.forward_only and not args.no_compare:
+        other_mode = "packed" if args.targets == "lists" else "lists"
+        dt_o, _ = timed_run(other_mode, args.steps, 1, False)
+        line["config"]["images_per_sec_" + other_mode + "_targets"] = round(B * world * args.steps / dt_o, 2)
+
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_steps)
-        print(json.dumps(out), flush=True)
+            line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_steps, args.cpu_batch8)
+        print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

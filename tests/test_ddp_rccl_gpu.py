@@ -29,6 +29,10 @@ def _env(**kw):
     return env
 
 
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
 def _last_json(stdout):
     lines = [l for l in stdout.splitlines() if l.startswith("{")]
     assert lines, stdout[-2000:]
@@ -59,10 +63,27 @@ def test_bench_single_forced_rccl_rank_reports_the_collective(schedule):
     assert out["allreduce_ms"] > 0 and out["allreduce_bytes"] > 0 and out["value"] > 0
     assert out["config"]["optimizer_schedule"].startswith("backward + all-reduce + AdamW on the tail stream" if schedule == "overlap" else "in-line")
     assert out["config"]["encoder_streams"] == 2
+    assert out["replicas_equal"] is True
+    if schedule == "overlap":      # the unloseable flow: in-line measured first, pre-flight bitwise check, then the deferred tail
+        assert out["config"]["schedule_check"].startswith("pre-flight: 2 steps from one state, deferred tail == in-line bitwise")
+        assert out["config"]["images_per_sec_inline_schedule"] > 0 and out["config"]["images_per_sec_deferred_tail_schedule"] > 0
 
 
-def _free_port():
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+@pytest.mark.timeout(900)
+def test_bench_two_gloo_ranks_on_one_gpu_run_the_multi_rank_flow():
+    """bench.py's flow for more than one rank with two REAL ranks on the one visible GPU (gloo moves the bucket; `--backend gloo` is
+    test-only): in-line measurement first, pre-flight deferred == in-line bitwise, deferred measurement, replicas equal after both."""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "4", "--warmup", "1",
+                        "--arch", "small", "--batch", "4", "--no-cpu-baseline", "--no-compare"], capture_output=True, text=True, env=_env(), timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _last_json(r.stdout)
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["backend"].startswith("gloo")
+    assert out["replicas_equal"] is True
+    assert out["config"]["schedule_check"].startswith("pre-flight: 2 steps from one state, deferred tail == in-line bitwise"), out["config"]
+    assert out["config"]["optimizer_schedule"].startswith("backward + all-reduce + AdamW on the tail stream")
+    assert out["config"]["global_batch"] == 8 and out["value"] > 0
+
 
 
 _WORKER = r'''

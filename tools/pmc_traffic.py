@@ -29,13 +29,25 @@ print("| kernel | launches | read MB / launch (FETCH_SIZE x2) | written MB / lau
 for k, n, rd, wr in rows[:40]:
     print(f"| {k[:80]} | {n} | {rd/1e6:.1f} | {wr/1e6:.1f} | {(rd+wr)/1e6:.1f} |")
 if "--json" in sys.argv:
-    out = {}
-    for k, n, rd, wr in rows:
-        if re.match(r"void gemm_pp2_kernel<0[,>]", k) and "gemm_pp2_kernel<bias>" not in out: out["gemm_pp2_kernel<bias>"] = round(rd + wr)   # (rows are sorted by total traffic: the shipped instantiation first)
-        elif re.match(r"void gemm_pp2_kernel<1[,>]", k) and "gemm_pp2_kernel<qgelu>" not in out: out["gemm_pp2_kernel<qgelu>"] = round(rd + wr)
-        elif re.match(r"void attn_fwd_kernel<true, true[,>]", k) and "12>" not in k: out["attn_fwd_kernel<VROW>"] = round(rd + wr)        # (class token peeled: what T = 1 + 64 n runs)
-        elif re.match(r"void attn_fwd_kernel<true, false[,>]", k) and "attn_fwd_kernel<VROW>" not in out: out["attn_fwd_kernel<VROW>"] = round(rd + wr)
+    # bench.py's `roofline.traffic`: bytes per OP of the three timed ops for one workload ("<arch>/<batch per GPU>", --workload), merged into the JSON if it
+    # was written on the same kernel sources (else the file starts afresh: a figure measured on other sources is never kept)
+    def per_op(pat, extra_pat=None):
+        n = sum(n_ for k, n_, rd, wr in rows if re.match(pat, k))
+        tot = sum((rd + wr) * n_ for k, n_, rd, wr in rows if re.match(pat, k) or (extra_pat and re.match(extra_pat, k)))
+        return round(tot / n) if n else None
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from bench import kernel_source_digest            # bench.py quotes these figures only for the sources they were measured on
-    out["kernel_source_digest"] = kernel_source_digest()
-    json.dump(out, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
+    from bench import kernel_source_digest, LABEL_BIAS, LABEL_QGELU, LABEL_ATTN
+    w = {LABEL_BIAS: per_op(r"void gemm_pp2_kernel<0[,>]", r"void gemm_pph_kernel<0[,>]"),        # the remainder launch belongs to the op
+         LABEL_QGELU: per_op(r"void gemm_pp2_kernel<1[,>]", r"void gemm_pph_kernel<1[,>]"),
+         LABEL_ATTN: per_op(r"void attn_fwd_kernel<true, (true|false), 4>")}
+    path = sys.argv[sys.argv.index("--json") + 1]
+    key = sys.argv[sys.argv.index("--workload") + 1] if "--workload" in sys.argv else "owlvit-base-patch16/32"
+    out = {"kernel_source_digest": kernel_source_digest(), "workloads": {}}
+    try:
+        old = json.load(open(path))
+        if old.get("kernel_source_digest") == out["kernel_source_digest"]:
+            out["workloads"] = old.get("workloads", {})
+    except (OSError, ValueError):
+        pass
+    out["workloads"][key] = {k: v for k, v in w.items() if v}
+    json.dump(out, open(path, "w"), indent=1)
