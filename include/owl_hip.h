@@ -32,7 +32,7 @@ extern "C" {
 
 /* ---- runtime ---------------------------------------------------------------------------------- */
 /* Bumped whenever a prototype, an argument's meaning or a caller-provided scratch layout changes (1 = round 1; 2 = round 2: per-call `tile` /
- * `variant` arguments, partial-sum scratch of the row reductions, 5D+4 box_final_bwd partials; 3 = round 3; 4 = round 4: `slow_tiles` statistic of the attention forward).  owl_abi_version() returns the value
+ * `variant` arguments, partial-sum scratch of the row reductions, 5D+4 box_final_bwd partials; 3 = round 3; 4 = round 4: `slow_tiles` statistic of the attention forward; the V^T attention form, attention variants 3-5, GEMM epilogues 5 / 6 and tiles 8 / 9 / 5 / 4 moved to OWL_TUNING builds).  owl_abi_version() returns the value
  * the library was BUILT with: a binding compares it with the header it was generated from and refuses a mismatch (_lib.load() does). */
 #define OWL_ABI_VERSION 4
 const char* owl_last_error(void);
@@ -42,14 +42,15 @@ int owl_abi_version(void);
  * replaces aten::addmm/mm under HF5:437-439,457 (q/k/v/out proj), HF5:472,474 (fc1/fc2),
  * HF5:994-997 (box head dense0/1), ref src/models.py:25 (class dense0) and their autograd forms.
  * epi: 0 bias->bf16 | 1 bias+quick_gelu->bf16 (aux = pre-activation) | 2 bias+erf-gelu->bf16 |
- *      3 resid+acc+bias->f32 | 4 alpha*acc(+bias)->f32 | 5 atomicAdd f32 (split-K) |
- *      6 per-head transposed bf16 out_t[b][n][t] (m = b*Tp + t) | 8 acc*quick_gelu'(aux)->bf16 |
- *      9 acc*gelu'(aux)->bf16 | 10 out f32 += acc | 11 split-K slab.
+ *      3 resid+acc+bias->f32 | 4 alpha*acc(+bias)->f32 | 8 acc*quick_gelu'(aux)->bf16 |
+ *      9 acc*gelu'(aux)->bf16 | 10 out f32 += acc | 11 split-K slab
+ *      (5 atomicAdd f32 and 6 per-head transposed bf16: OWL_TUNING builds only -- the train path uses neither).
  * a_rows / w_rows clamp the tile loads; M, N guard the stores; K % 64 == 0.
  * tile: kernel choice, per call (no global state): 0 = automatic (large shapes: 256x256x64 tiles on the two-phase ping-pong schedule, 8 waves,
- *       gemm_pp2.hip -- for narrow outputs with the remainder round on half-height 128x256 tiles --; 128x128x64 otherwise); tests and tools pin one
- *       kernel with 128 | 256 (single-phase) | 8 (four-phase ping-pong, never split) | 9 (four-phase ping-pong + half-height remainder wherever it
- *       fits) | 7 (two-phase ping-pong on the whole problem) | 4 (experimental four-wave; OWL_TUNING builds only).  All give identical bits.                           */
+ *       gemm_pp2.hip -- for narrow outputs with the remainder round on half-height 128x256 tiles, gemm_pph.hip --; 128x128x64 otherwise); tests pin one
+ *       kernel with 128 | 256 (the single-phase REFERENCE kernel every other one is held to, bit for bit) | 7 (two-phase ping-pong on the whole
+ *       problem).  All give identical bits.  (8, 9, 5, 4: the round-1 four-phase ping-pong, the round-4 free-running and the four-wave experiments,
+ *       OWL_TUNING builds only.)                                                                                                                   */
 int owl_gemm_nt_bf16(void* stream, int epi, const void* A, int64_t lda, int64_t a_rows, const void* W, int64_t ldw, int64_t w_rows, const float* bias, void* out, int64_t ldo, const float* resid, void* aux, int64_t ld_aux, int64_t M, int64_t N, int64_t K, float alpha, int splits, int64_t Tp, int tile);
 /* epi 11 = split-K partial slabs out[split][M][ldo] (f32, no atomics); reduce them with owl_slab_reduce */
 int owl_gemm_effective_splits(int64_t K, int splits);
@@ -74,26 +75,18 @@ int owl_layernorm_fwd(void* stream, const float* x, const float* gamma, const fl
 int owl_add_layernorm_fwd(void* stream, const float* x, const void* delta_bf16, float* x_out, const float* gamma, const float* beta, void* out, int out_bf16, float* stats, int64_t rows, int64_t D, float eps, const void* delta2_bf16);
 
 /* ---- fused self-attention forward (HF5:377-402): softmax(Q K^T * scale) V, dh = 64 -----------------
- * q, k row-major [B*Tp, ld_qk] (head h at column h*64); vt = V^T per head [B][..][64][Tp] as written
- * by epilogue 6; out row-major [B*Tp, ld_out]; lse optional [B,H,Tp] (log2 domain).               */
-int owl_attention_fwd_bf16(void* stream, const void* q, const void* k, int64_t ld_qk, const void* vt, int64_t vt_img_stride, void* out, int64_t ld_out, float* lse, int64_t B, int64_t H, int64_t T, int64_t Tp, float scale);
-/* Same fused attention forward with V read where the QKV GEMM leaves it: `v` = row-major [B*Tp, ld_qkv] (same row stride as q and k),
- * head h at column h*64 of `v`; the [64 key][64 d] tile is transposed by the LDS hardware (ds_read_b64_tr_b16), so the frozen layers
- * need no V^T copy and run ONE N = 3D QKV GEMM (HF5:437-439).  Bit-identical to owl_attention_fwd_bf16 on the same data.
- * variant (per call, no global state): 0 = the library's choice; 1 = plain tiling (tokens 0..T-1 in 64-key tiles / 128-query blocks: the bits
- * of owl_attention_fwd_bf16); 2 = class token peeled: token 0 enters every other query's online softmax as its initial state and is itself
- * one VALU-only workgroup per (image, head), the tiles cover tokens 1..T-1 -- needs T - 1 a positive multiple of 64 (else rc != 0);
- * same values as 1 to bf16 round-off (other summation order), 5.8 % faster at T = 2305.  0 picks 2 wherever it is allowed;
- * 3 = the peeled tiling on the one-wave-per-SIMD structure (csrc/attention_fwd_w64.hip: 64 queries per wave, 256 per workgroup, softmax
- * interleaved with the MFMAs of the neighbouring tiles): needs T - 1 a multiple of 64 >= 192 and `redo_ws` -- device scratch of
- * owl_attention_fwd_workspace_bytes(B, H, T) bytes (any contents; one int per query block, written by the kernel: blocks whose scores leave the
- * range its offset-free softmax covers are redone by the classic kernel in the same call).  redo_ws may be NULL for variants 0-2.
+ * q, k, v row-major [B*Tp, ld_qkv] (head h at column h*64 of each; normally three column slices of the one [B*Tp, 3D] QKV GEMM output,
+ * HF5:437-439); out row-major [B*Tp, ld_out]; lse optional [B,H,Tp] (log2 domain).  V is read where the QKV GEMM leaves it: the
+ * [64 key][64 d] tile is transposed by the LDS hardware (ds_read_b64_tr_b16) -- no V^T copy of anything exists.
+ * variant (per call, no global state): 0 = the library's choice; 1 = plain tiling (tokens 0..T-1 in 64-key tiles / 128-query blocks);
+ * 2 = class token peeled: token 0 enters every other query's online softmax as its initial state and is itself one VALU-only workgroup
+ * per (image, head), the tiles cover tokens 1..T-1 -- needs T - 1 a positive multiple of 64 (else rc != 0); same values as 1 to bf16
+ * round-off (other summation order), 5.8 % faster at T = 2305.  0 picks 2 wherever it is allowed.
  * slow_tiles (optional, may be NULL): device int, += 1 for every (wave = 32 queries, 64-key tile) pair that leaves the fast path -- the tile's row sums
  * against the offset the wave already holds exceed 2^40 (or are inf / NaN) and the tile is recomputed with an explicit maximum.  A wave's first tile
- * is not counted.  Zero on scores of ordinary size (HF-init weights); trained weights with attention sinks trip it about once per wave and layer.
- * (4, 5: OWL_TUNING builds only -- the stamped one-wave-per-SIMD kernel; the peeled tiling as one 12-wave workgroup per CU, same bits as 2.) */
-int owl_attention_fwd_workspace_bytes(int64_t B, int64_t H, int64_t T, int64_t* bytes);   /* redo_ws; `bytes` is a HOST pointer */
-int owl_attention_fwd_vrow_bf16(void* stream, const void* q, const void* k, const void* v, int64_t ld_qkv, void* out, int64_t ld_out, float* lse, int64_t B, int64_t H, int64_t T, int64_t Tp, float scale, int variant, int* redo_ws, int* slow_tiles);
+ * is not counted.  Zero on scores of ordinary size (HF-init weights); trained-like weights with attention sinks trip it about once per wave and layer.
+ * (The round-1 V^T form, the one-wave-per-SIMD and the 12-wave experiments: OWL_TUNING builds, include/owl_hip_tuning.h.) */
+int owl_attention_fwd_vrow_bf16(void* stream, const void* q, const void* k, const void* v, int64_t ld_qkv, void* out, int64_t ld_out, float* lse, int64_t B, int64_t H, int64_t T, int64_t Tp, float scale, int variant, int* slow_tiles);
 
 /* backward of the fused attention (layers whose attention runs backward): qkv row-major [B*Tp,3D] (q|k|v), dO / O row-major
  * [B*Tp,D], lse from the forward; writes dqkv [B*Tp,3D] (dq|dk|dv, bf16).  Every transposed operand of the dK/dV/dQ MFMAs is read

@@ -28,6 +28,13 @@ int owl_gemm_pp2_trace(void* buf);
 int owl_gemm_pp2_trace_tile(int n);
 /* ... and which K-tile of it (default 4; 0-2 show the refill behind the previous tile's epilogue) */
 int owl_gemm_pp2_trace_ktile(int n);
+/* round-1 attention forward with V^T per head [B][heads*64][Tp] as written by GEMM epilogue 6 (bit-identical to variant 1 of owl_attention_fwd_vrow_bf16) */
+int owl_attention_fwd_bf16(void* stream, const void* q, const void* k, int64_t ld_qk, const void* vt, int64_t vt_img_stride, void* out, int64_t ld_out, float* lse, int64_t B, int64_t H, int64_t T, int64_t Tp, float scale);
+/* attention forward experiments: variant 3 = one wave per SIMD, 64 queries per wave (csrc/attention_fwd_w64.hip; blocks whose scores leave the range of its
+ * offset-free softmax are flagged in redo_ws and redone by the classic kernel in the same call), 4 = its s_memtime-stamped form, 5 = one 12-wave workgroup
+ * per CU sharing the stage buffers; 0-2 as owl_attention_fwd_vrow_bf16.  redo_ws: owl_attention_fwd_workspace_bytes(B, H, T) bytes (`bytes`: HOST pointer) */
+int owl_attention_fwd_workspace_bytes(int64_t B, int64_t H, int64_t T, int64_t* bytes);
+int owl_attention_fwd_w64_bf16(void* stream, const void* q, const void* k, const void* v, int64_t ld_qkv, void* out, int64_t ld_out, float* lse, int64_t B, int64_t H, int64_t T, int64_t Tp, float scale, int variant, int* redo_ws);
 /* free-running GEMM (csrc/gemm_fr.hip, tile 5): timing-only ablations (1 no LDS-DMA after the prologue, 2 fragments read once per tile, 3 both), persistent grid
  * size (default 512 = two workgroups per CU), column-block width of the tile order */
 int owl_gemm_fr_ablate(int a);

@@ -439,24 +439,26 @@ static constexpr int g_attn_dbg = 0;
 #endif
 
 // variant: 0 = the library's choice (peeled wherever it can be), 1 = plain tiling, 2 = peeled (row-major V, T - 1 a positive multiple of 64)
+#ifdef OWL_TUNING
 int attn_fwd_w64_launch(hipStream_t stream, const AttnFwdP& base, int* redo, int dbg);      // attention_fwd_w64.hip
+#endif
 
 static int attn_fwd_launch(void* stream, const void* q, const void* k, int64_t ld_qk, const void* v, int v_row_major,
                            int64_t vt_img_stride, void* out, int64_t ld_out, float* lse, int64_t B, int64_t H, int64_t T,
                            int64_t Tp, float scale, int variant, int* redo = nullptr, int* slow_tiles = nullptr) {
-    OWL_CHECK_ARG(q && k && v && out, "owl_attention_fwd_bf16: null pointer");
-    OWL_CHECK_ARG(ld_qk % 8 == 0 && ld_out % 8 == 0 && Tp % 8 == 0 && T > 0 && T <= Tp, "owl_attention_fwd_bf16: bad strides (ld_qk %% 8, ld_out %% 8, Tp %% 8)");
-    OWL_CHECK_ARG(variant >= 0 && variant <= 5 && (variant <= 1 || v_row_major), "owl_attention_fwd: variant must be 0 (default), 1 (plain tiling), 2 (class token peeled; row-major V only) or 3 (one wave per SIMD)");
+    OWL_CHECK_ARG(q && k && v && out, "owl_attention_fwd: null pointer");
+    OWL_CHECK_ARG(ld_qk % 8 == 0 && ld_out % 8 == 0 && Tp % 8 == 0 && T > 0 && T <= Tp, "owl_attention_fwd: bad strides (ld_qk %% 8, ld_out %% 8, Tp %% 8)");
+#ifdef OWL_TUNING
+    OWL_CHECK_ARG(variant >= 0 && variant <= 5 && (variant <= 1 || v_row_major), "owl_attention_fwd: variant must be 0 (default), 1 (plain tiling), 2 (class token peeled; row-major V only), 3-5 (tuning)");
+#else
+    OWL_CHECK_ARG(variant >= 0 && variant <= 2, "owl_attention_fwd_vrow_bf16: variant must be 0 (the library's choice), 1 (plain tiling) or 2 (class token peeled); the one-wave-per-SIMD and "
+                                                "12-wave experiments (3-5) exist only in an OWL_TUNING build");
+#endif
     const bool can_peel = v_row_major && T >= 65 && (T - 1) % 64 == 0;
     OWL_CHECK_ARG(variant != 2 || can_peel, "owl_attention_fwd: variant 2 (peeled) needs row-major V and T - 1 a positive multiple of 64");
+#ifdef OWL_TUNING
     const bool can_w64 = can_peel && T - 1 >= 192 && redo != nullptr;
-    OWL_CHECK_ARG(variant < 3 || can_w64, "owl_attention_fwd: variant 3 (one wave per SIMD) needs row-major V, T - 1 a multiple of 64 >= 192 and the redo scratch");
-#ifndef OWL_TUNING
-    OWL_CHECK_ARG(variant != 4, "owl_attention_fwd: variant 4 (stamped one-wave-per-SIMD kernel) exists only in an OWL_TUNING build");
-#endif
-#ifndef OWL_TUNING
-    OWL_CHECK_ARG(variant != 5, "owl_attention_fwd: variant 5 (12 waves per workgroup) exists only in an OWL_TUNING build");
-#else
+    OWL_CHECK_ARG(variant < 3 || variant == 5 || can_w64, "owl_attention_fwd: variant 3 (one wave per SIMD) needs row-major V, T - 1 a multiple of 64 >= 192 and the redo scratch");
     if (variant == 5) {          // experimental (tools/attn_nw12_bench.py: bit-identical, +7 ... +10 % at B/16): twelve waves per workgroup sharing the stage buffers (peeled tiling)
         OWL_CHECK_ARG(can_peel, "owl_attention_fwd: variant 5 (12 waves per workgroup) needs row-major V and T - 1 a positive multiple of 64");
         AttnFwdP p{};
@@ -469,8 +471,11 @@ static int attn_fwd_launch(void* stream, const void* q, const void* k, int64_t l
         OWL_LAUNCH_CHECK();
         return 0;
     }
+    const bool w64 = variant == 3 || variant == 4;            // (4: the s_memtime-stamped kernel, no fix-up launch -- tools/attn_w64_trace.py)
+#else
+    constexpr bool w64 = false;
+    (void)redo;
 #endif
-    const bool w64 = variant == 3 || variant == 4;            // (4, OWL_TUNING builds: the s_memtime-stamped kernel, no fix-up launch -- tools/attn_w64_trace.py)
     const bool peel = variant == 2 || w64 || (variant == 0 && can_peel);
     AttnFwdP p{};
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.ld_qk = ld_qk;
@@ -482,6 +487,7 @@ static int attn_fwd_launch(void* stream, const void* q, const void* k, int64_t l
     p.nqb = peel ? (int)((T - 1 + 127) / 128) + 1 : (int)((T + 127) / 128);      // peeled: the last "block" is the class-token row
     const int64_t npairs8 = (B * H + 7) / 8;                  // pairs per XCD (rounded up)
     dim3 grid((unsigned)(npairs8 * p.nqb * 8));
+#ifdef OWL_TUNING
     if (w64) {
         // 64 queries per wave, one wave per SIMD; then the classic kernel over the query blocks it flagged (normally none: a launch of
         // workgroups that read one flag and exit)
@@ -490,27 +496,35 @@ static int attn_fwd_launch(void* stream, const void* q, const void* k, int64_t l
         p.redo = redo;
         p.redo_nqb = (int)((T - 1 + 255) / 256);
     }
-    if (!v_row_major) hipLaunchKernelGGL((attn_fwd_kernel<false>), grid, dim3(256), 2 * 16384, (hipStream_t)stream, p);
-    else if (peel) hipLaunchKernelGGL((attn_fwd_kernel<true, true>), grid, dim3(256), 2 * 16384, (hipStream_t)stream, p);
+    if (!v_row_major) { hipLaunchKernelGGL((attn_fwd_kernel<false>), grid, dim3(256), 2 * 16384, (hipStream_t)stream, p); OWL_LAUNCH_CHECK(); return 0; }
+#endif
+    if (peel) hipLaunchKernelGGL((attn_fwd_kernel<true, true>), grid, dim3(256), 2 * 16384, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((attn_fwd_kernel<true>), grid, dim3(256), 2 * 16384, (hipStream_t)stream, p);
     OWL_LAUNCH_CHECK();
     return 0;
 }
 
+// fused attention forward, V read where the QKV GEMM leaves it: row-major [B*Tp, ld_qkv], head h at column h*64 of `v` (no V^T copy exists)
+extern "C" int owl_attention_fwd_vrow_bf16(void* stream, const void* q, const void* k, const void* v, int64_t ld_qkv, void* out,
+                                           int64_t ld_out, float* lse, int64_t B, int64_t H, int64_t T, int64_t Tp, float scale, int variant, int* slow_tiles) {
+    return attn_fwd_launch(stream, q, k, ld_qkv, v, 1, 0, out, ld_out, lse, B, H, T, Tp, scale, variant, nullptr, slow_tiles);
+}
+
+#ifdef OWL_TUNING
+// tuning builds (include/owl_hip_tuning.h): the round-1 form with V^T per head as written by the transposing GEMM epilogue; the one-wave-per-SIMD / 12-wave
+// experiments (variant 3, 4, 5) with their redo scratch
 extern "C" int owl_attention_fwd_bf16(void* stream, const void* q, const void* k, int64_t ld_qk, const void* vt,
                                       int64_t vt_img_stride, void* out, int64_t ld_out, float* lse, int64_t B,
                                       int64_t H, int64_t T, int64_t Tp, float scale) {
     return attn_fwd_launch(stream, q, k, ld_qk, vt, 0, vt_img_stride, out, ld_out, lse, B, H, T, Tp, scale, 0);
 }
-
-// same, with V read where the QKV GEMM leaves it: row-major [B*Tp, ld_qkv], head h at column h*64 of `v` (no V^T copy at all)
-extern "C" int owl_attention_fwd_vrow_bf16(void* stream, const void* q, const void* k, const void* v, int64_t ld_qkv, void* out,
-                                           int64_t ld_out, float* lse, int64_t B, int64_t H, int64_t T, int64_t Tp, float scale, int variant, int* redo_ws, int* slow_tiles) {
-    return attn_fwd_launch(stream, q, k, ld_qkv, v, 1, 0, out, ld_out, lse, B, H, T, Tp, scale, variant, redo_ws, slow_tiles);
+extern "C" int owl_attention_fwd_w64_bf16(void* stream, const void* q, const void* k, const void* v, int64_t ld_qkv, void* out,
+                                          int64_t ld_out, float* lse, int64_t B, int64_t H, int64_t T, int64_t Tp, float scale, int variant, int* redo_ws) {
+    return attn_fwd_launch(stream, q, k, ld_qkv, v, 1, 0, out, ld_out, lse, B, H, T, Tp, scale, variant, redo_ws, nullptr);
 }
-
 extern "C" int owl_attention_fwd_workspace_bytes(int64_t B, int64_t H, int64_t T, int64_t* bytes) {
     OWL_CHECK_ARG(bytes && B > 0 && H > 0 && T > 0, "owl_attention_fwd_workspace_bytes: bad arguments");
     *bytes = B * H * ((T - 1 + 255) / 256 + 1) * (int64_t)sizeof(int);
     return 0;
 }
+#endif

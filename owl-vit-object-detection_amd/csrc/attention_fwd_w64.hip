@@ -18,6 +18,7 @@
 //
 // Tiling: class token peeled exactly like attn_fwd_kernel<true, true> (token 0 = initial state of every other query's softmax and one VALU-only
 // workgroup per (image, head)); tiles cover tokens 1..T-1, which must be a multiple of 64 keys (B/16: 2304 = 36 tiles = 9 query blocks).
+#ifdef OWL_TUNING   // whole file: a tuning-build experiment, not part of the shipped library
 #include "attention_fwd_common.h"
 #include <type_traits>
 
@@ -363,3 +364,4 @@ int attn_fwd_w64_launch(hipStream_t stream, const AttnFwdP& base, int* redo, int
     OWL_LAUNCH_CHECK();
     return 0;
 }
+#endif  // OWL_TUNING (whole file)

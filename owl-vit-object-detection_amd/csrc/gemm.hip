@@ -318,7 +318,14 @@ extern "C" int owl_gemm_nt_bf16(void* stream, int epi, const void* A, int64_t ld
                                 const float* resid, void* aux, int64_t ld_aux, int64_t M, int64_t N, int64_t K,
                                 float alpha, int splits, int64_t Tp, int tile) {
     OWL_CHECK_ARG(A && W && out, "owl_gemm_nt_bf16: null pointer");
-    OWL_CHECK_ARG(tile == 0 || tile == 128 || tile == 256 || tile == 8 || tile == 9 || tile == 4 || tile == 7 || tile == 5, "owl_gemm_nt_bf16: tile must be 0 (auto), 128, 256, 8, 9, 7, 5 or 4");
+#ifdef OWL_TUNING
+    OWL_CHECK_ARG(tile == 0 || tile == 128 || tile == 256 || tile == 8 || tile == 9 || tile == 4 || tile == 7 || tile == 5, "owl_gemm_nt_bf16: tile must be 0 (auto), 128, 256, 7 (or, tuning builds, 8, 9, 5, 4)");
+#else
+    OWL_CHECK_ARG(tile == 0 || tile == 128 || tile == 256 || tile == 7, "owl_gemm_nt_bf16: tile must be 0 (auto), 128, 256 or 7 (8, 9, 5, 4: the four-phase ping-pong, free-running and four-wave "
+                                                                      "experiments exist only in an OWL_TUNING build)");
+    OWL_CHECK_ARG(epi != EPI_TRANS_BF16 && epi != EPI_ATOMIC_F32, "owl_gemm_nt_bf16: epilogues 5 (f32 atomics) and 6 (per-head transposed) exist only in an OWL_TUNING build "
+                                                                    "(the train path uses split-K slabs and reads V row-major)");
+#endif
     const int g_force_tile = tile;
     OWL_CHECK_ARG(K > 0 && K % BK == 0, "owl_gemm_nt_bf16: K=%lld must be a positive multiple of 64", (long long)K);
     OWL_CHECK_ARG(M > 0 && N > 0 && N % 8 == 0, "owl_gemm_nt_bf16: bad M=%lld N=%lld (N %% 8 == 0)", (long long)M, (long long)N);
@@ -337,23 +344,19 @@ extern "C" int owl_gemm_nt_bf16(void* stream, int epi, const void* A, int64_t ld
     splits = (nk + p.kt_per_split - 1) / p.kt_per_split;
     hipStream_t s = (hipStream_t)stream;
     const bool split_ok = (epi == EPI_ATOMIC_F32 || epi == EPI_SLAB_F32);
-    OWL_CHECK_ARG(splits == 1 || split_ok, "owl_gemm_nt_bf16: split-K needs the atomic or slab epilogue");
+    OWL_CHECK_ARG(splits == 1 || split_ok, "owl_gemm_nt_bf16: split-K needs the slab epilogue");
     // bf16-output epilogues on big problems run the ping-pong schedule (gemm_pp.hip): 13-26 % faster, bit-identical
 #ifdef OWL_TUNING
     if (g_force_tile == 4 && K >= 128) {                 // experimental four-wave kernel (tuning builds only)
         const int rc = owl_gemm_w4_launch(s, epi, p);
         if (rc <= 0) return rc;
     }
-#else
-    OWL_CHECK_ARG(tile != 4, "owl_gemm_nt_bf16: tile 4 (experimental four-wave kernel) exists only in an OWL_TUNING build");
 #endif
 #ifdef OWL_TUNING
     if (g_force_tile == 5 && splits == 1) {              // round-4 experiment (tuning builds only): free-running 128 x 256 workgroups, two per CU (gemm_fr.hip)
         const int rc = owl_gemm_fr_launch(s, epi, p);
         if (rc <= 0) return rc;
     }
-#else
-    OWL_CHECK_ARG(tile != 5, "owl_gemm_nt_bf16: tile 5 (free-running two-workgroups-per-CU kernel) exists only in an OWL_TUNING build");
 #endif
     if (g_force_tile == 7 && K >= 128) {                 // two-phase ping-pong kernel on the whole problem (A/B; falls through for other epilogues)
         const int rc = owl_gemm_pp2_launch(s, epi, p);
@@ -366,7 +369,11 @@ extern "C" int owl_gemm_nt_bf16(void* stream, int epi, const void* A, int64_t ld
             const int rc = owl_gemm_pp2_launch(s, epi, q);
             if (rc <= 0) return rc;
         }
-        return owl_gemm_pp_launch(s, epi, q, g_debug_slots, g_persistent, g_debug_nostore);
+#ifdef OWL_TUNING
+        return owl_gemm_pp_launch(s, epi, q, g_debug_slots, g_persistent, g_debug_nostore);      // the four-phase kernel (tile 8 / 9, the transposing epilogue)
+#else
+        return 1;                    // not a two-phase epilogue: the single-phase kernel below
+#endif
     };
     const bool pp_auto = (g_force_tile == 0 && M >= 512 && N >= 256 && ((M + 255) / 256) * ((N + 255) / 256) >= 48);
     if ((g_force_tile == 8 || g_force_tile == 9 || pp_auto) && K >= 128 && (epi != EPI_TRANS_BF16 || (Tp > 0 && Tp % 4 == 0 && N % 64 == 0)) &&
@@ -412,11 +419,15 @@ extern "C" int owl_gemm_nt_bf16(void* stream, int epi, const void* A, int64_t ld
         case EPI_RESID_F32: OWL_CHECK_ARG(resid, "EPI_RESID_F32 needs resid"); return launch<EPI_RESID_F32>(s, p, 1, g_force_tile);
         case EPI_ACC_F32: p.resid = (const float*)out; return launch<EPI_ACC_F32>(s, p, 1, g_force_tile);
         case EPI_F32: return launch<EPI_F32>(s, p, 1, g_force_tile);
+#ifdef OWL_TUNING
         case EPI_ATOMIC_F32: OWL_CHECK_ARG(!bias, "atomic epilogue takes no bias"); return launch<EPI_ATOMIC_F32>(s, p, splits, g_force_tile);
+#endif
         case EPI_SLAB_F32: OWL_CHECK_ARG(!bias, "slab epilogue takes no bias"); return launch<EPI_SLAB_F32>(s, p, splits, g_force_tile);
+#ifdef OWL_TUNING
         case EPI_TRANS_BF16:
             OWL_CHECK_ARG(Tp > 0 && Tp % 4 == 0 && N % 64 == 0, "EPI_TRANS_BF16: Tp %% 4, N %% 64");
             return launch<EPI_TRANS_BF16>(s, p, 1, g_force_tile);
+#endif
         case EPI_DQGELU_BF16: OWL_CHECK_ARG(aux, "EPI_DQGELU needs aux"); return launch<EPI_DQGELU_BF16>(s, p, 1, g_force_tile);
         case EPI_DGELU_BF16: OWL_CHECK_ARG(aux, "EPI_DGELU needs aux"); return launch<EPI_DGELU_BF16>(s, p, 1, g_force_tile);
         default: owl_set_error("owl_gemm_nt_bf16: unknown epilogue %d", epi); return -1;

@@ -24,6 +24,7 @@
 //
 // At a tile boundary group 0 waits one extra barrier (group 1's last MFMA half) so that both groups run their epilogues
 // together; group 1's extra barrier at the next tile start re-creates the offset.  Barrier counts per tile: 8 nk + 1 each.
+#ifdef OWL_TUNING   // whole file: a tuning-build experiment, not part of the shipped library
 #include "gemm_common.h"
 #include <type_traits>
 
@@ -381,3 +382,4 @@ int owl_gemm_pp_launch(hipStream_t s, int epi, const GemmP& p, int slots_overrid
         default: return 1;
     }
 }
+#endif  // OWL_TUNING (whole file)

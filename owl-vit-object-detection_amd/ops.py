@@ -12,7 +12,7 @@ EPI_TRANS_BF16, EPI_PATCH_F32, EPI_DQGELU_BF16, EPI_DGELU_BF16, EPI_ACC_F32, EPI
 
 ROW_PAD = 128
 ATTN_VARIANT = 0   # default `variant` of attention_fwd_vrow(): 0 = the library's choice; 1 plain tiling, 2 class token peeled (tests / tools)
-GEMM_TILE = 0      # default `tile` argument of gemm(): 0 = automatic kernel choice; tests / tools pin one kernel (128 | 256 | 8 | 4)
+GEMM_TILE = 0      # default `tile` argument of gemm(): 0 = automatic kernel choice; tests / tools pin one kernel (128 | 256 | 7; tuning builds: 8 | 9 | 5 | 4)
 
 
 def stream() -> int:
@@ -82,7 +82,15 @@ def layernorm(x, gamma, beta, out, rows, D, stats=None, eps=1e-5, delta=None, x_
     return out
 
 
+def _tuning_only(what):
+    import os
+    if os.environ.get("OWL_TUNING", "0") != "1":
+        raise RuntimeError(f"{what} exists only in an OWL_TUNING build of libowlhip.so (OWL_TUNING=1 bash csrc/build.sh, run with OWL_TUNING=1)")
+
+
 def attention_fwd(q, k, ld_qk, vt, vt_img_stride, out, ld_out, lse, B, H, T, Tp, scale):
+    """Tuning builds only: the round-1 form with V^T per head (include/owl_hip_tuning.h)."""
+    _tuning_only("the V^T attention forward")
     _lib.call("owl_attention_fwd_bf16", stream(), q, k, ld_qk, vt, vt_img_stride, out, ld_out, lse, B, H, T, Tp,
               float(scale))
     return out
@@ -92,7 +100,7 @@ _attn_redo = {}
 
 
 def attention_redo_ws(B, H, T, device):
-    """Scratch of the one-wave-per-SIMD attention forward (one int per query block; contents irrelevant): one buffer per (device, stream)."""
+    """Tuning builds only: scratch of the one-wave-per-SIMD attention forward (one int per query block; contents irrelevant): one buffer per (device, stream)."""
     device = torch.device(device)
     if device.index is None:
         device = torch.device("cuda", torch.cuda.current_device())
@@ -108,12 +116,15 @@ ATTN_SLOW_TILES = None   # optional int32[1] device tensor: every attention forw
 
 
 def attention_fwd_vrow(q, k, v, ld_qkv, out, ld_out, lse, B, H, T, Tp, scale, variant=None, slow_tiles=None):
-    """attention_fwd with V row-major (a column slice of the qkv rows): no V^T copy."""
+    """Fused attention forward; q / k / v are column slices of the row-major qkv rows (no V^T copy).  variant 0-2: include/owl_hip.h; 3-5: tuning builds."""
     variant = int(ATTN_VARIANT if variant is None else variant)
-    redo = attention_redo_ws(B, H, T, out.device) if variant >= 3 else None
+    if variant >= 3:
+        _tuning_only(f"attention forward variant {variant}")
+        _lib.call("owl_attention_fwd_w64_bf16", stream(), q, k, v, ld_qkv, out, ld_out, lse, B, H, T, Tp, float(scale), variant, attention_redo_ws(B, H, T, out.device))
+        return out
     if slow_tiles is None:
         slow_tiles = ATTN_SLOW_TILES
-    _lib.call("owl_attention_fwd_vrow_bf16", stream(), q, k, v, ld_qkv, out, ld_out, lse, B, H, T, Tp, float(scale), variant, redo, slow_tiles)
+    _lib.call("owl_attention_fwd_vrow_bf16", stream(), q, k, v, ld_qkv, out, ld_out, lse, B, H, T, Tp, float(scale), variant, slow_tiles)
     return out
 
 

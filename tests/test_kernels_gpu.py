@@ -1,6 +1,7 @@
 """Per-kernel numerics on a real MI355X: each HIP kernel (called through the C ABI) against a plain
 PyTorch fp32 reference of the same op on the same (bf16-rounded) inputs."""
 import math
+import os
 
 import pytest
 import torch
@@ -34,12 +35,15 @@ def qgelu(x):
     return x * torch.sigmoid(1.702 * x)
 
 
-@pytest.fixture(params=[128, 256, 8, 7, 0], ids=["tile128", "tile256", "pingpong", "pingpong2", "auto"])
+_TUNING = os.environ.get("OWL_TUNING", "0") == "1"
+
+
+@pytest.fixture(params=[128, 256, 7, 0] + ([8, 5] if _TUNING else []), ids=["tile128", "tile256", "pingpong2", "auto"] + (["pingpong", "free-running"] if _TUNING else []))
 def gemm_tile(request):
-    """Run the GEMM tests on every kernel: 128x128 4-wave, 256x256 8-wave, the 256x256 four-phase ping-pong schedule (gemm_pp.hip; it
-    takes the bf16-output epilogues with K >= 128 and falls through to tile256 otherwise), the two-phase ping-pong kernel on the whole
-    problem (gemm_pp2.hip: what the model runs) and the library's automatic choice (two-phase + half-height remainder tiles, gemm_pph.hip)
-    -- each against `A @ W.T` in fp32, including the odd shapes (M = 777, N = 264 / 328) where clamped loads and store guards live."""
+    """Run the GEMM tests on every kernel: 128x128 4-wave, 256x256 8-wave (the single-phase reference kernels), the two-phase ping-pong kernel on
+    the whole problem (gemm_pp2.hip: what the model runs) and the library's automatic choice (two-phase + half-height remainder tiles,
+    gemm_pph.hip) -- each against `A @ W.T` in fp32, including the odd shapes (M = 777, N = 264 / 328) where clamped loads and store guards
+    live.  Tuning builds add the round-1 four-phase ping-pong kernel (gemm_pp.hip) and the round-4 free-running one (gemm_fr.hip)."""
     from owl_vit_object_detection_amd import _lib
     ops.GEMM_TILE = request.param
     yield request.param
@@ -86,10 +90,11 @@ def test_gemm_epilogues(gemm_tile):
     # accumulate
     ops.gemm(ops.EPI_ACC_F32, A, W, o32, M=M)
     report("acc", o32[:M], 1.5 * acc, 1e-3, 1e-4)
-    # split-K atomic
-    o32.zero_()
-    ops.gemm(ops.EPI_ATOMIC_F32, A, W, o32, M=M, splits=3)
-    report("atomic", o32[:M], acc, 1e-3, 1e-4)
+    # split-K atomic (tuning builds only: the train path uses the deterministic slabs below)
+    if os.environ.get("OWL_TUNING", "0") == "1":
+        o32.zero_()
+        ops.gemm(ops.EPI_ATOMIC_F32, A, W, o32, M=M, splits=3)
+        report("atomic", o32[:M], acc, 1e-3, 1e-4)
     # split-K slabs + deterministic reduce
     from owl_vit_object_detection_amd import _lib
     ns = _lib.load().owl_gemm_effective_splits(K, 2)
@@ -111,6 +116,7 @@ def test_gemm_epilogues(gemm_tile):
     report("dgelu", out[:M], acc * g2, 2e-2, 1e-2)
 
 
+@pytest.mark.skipif(os.environ.get("OWL_TUNING", "0") != "1", reason="tuning-build experiment (OWL_TUNING=1 build of libowlhip.so): not in the shipped ABI")
 def test_gemm_transposed_epilogue(gemm_tile):
     B, Tp, T, K, N = 2, 152, 150, 128, 192          # 3 heads of 64
     M = B * Tp
@@ -228,16 +234,12 @@ def _attn_case(B, H, T, seed):
     q = v[:, :T, :D].float().view(B, T, H, 64).transpose(1, 2)
     k = v[:, :T, D:2 * D].float().view(B, T, H, 64).transpose(1, 2)
     vv = v[:, :T, 2 * D:].float().view(B, T, H, 64).transpose(1, 2)
-    # V^T buffer [B][H][64][Tp] (+ slack for the last tile's over-read)
-    vt_flat = torch.zeros(B * H * 64 * Tp + 128, dtype=torch.bfloat16, device=DEV)
-    vt = vt_flat[: B * H * 64 * Tp].view(B, H, 64, Tp)
-    vt[:, :, :, :T] = vv.transpose(2, 3).bfloat16()
     att = torch.softmax(q @ k.transpose(2, 3) * 0.125, -1)
     ref = (att @ vv).transpose(1, 2).reshape(B, T, D)
     lse_ref = torch.logsumexp(q @ k.transpose(2, 3) * 0.125, -1) / math.log(2.0)
     out = ops.zeros_rows(M, D, torch.bfloat16, DEV)
     lse = torch.zeros(B, H, Tp, device=DEV)
-    ops.attention_fwd(qkv, qkv[:, D:], 3 * D, vt_flat, H * 64 * Tp, out, D, lse, B, H, T, Tp, 0.125)
+    ops.attention_fwd_vrow(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, out, D, lse, B, H, T, Tp, 0.125, variant=1)      # plain tiling: tokens 0..T-1 in 64-key tiles
     report(f"attn T={T}", out[:M].view(B, Tp, D)[:, :T], ref, 2e-2, 2e-2)
     report(f"lse T={T}", lse[:, :, :T], lse_ref, 2e-3, 1e-3)
 
@@ -258,11 +260,9 @@ def test_attention_fwd_spiked_scores():
     x[0, 10, :D] *= 6.0
     v[:, :T] = x.bfloat16()
     q = v[:, :T, :D].float(); k = v[:, :T, D:2 * D].float(); vv = v[:, :T, 2 * D:].float()
-    vt_flat = torch.zeros(64 * Tp + 128, dtype=torch.bfloat16, device=DEV)
-    vt_flat[: 64 * Tp].view(64, Tp)[:, :T] = vv[0].t().bfloat16()
     ref = torch.softmax(q @ k.transpose(1, 2) * 0.125, -1) @ vv
     out = ops.zeros_rows(M, D, torch.bfloat16, DEV)
-    ops.attention_fwd(qkv, qkv[:, D:], 3 * D, vt_flat, 64 * Tp, out, D, None, B, H, T, Tp, 0.125)
+    ops.attention_fwd_vrow(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, out, D, None, B, H, T, Tp, 0.125, variant=1)
     report("attn spiked", out[:T], ref[0], 3e-2, 2e-2)
 
 
@@ -428,8 +428,9 @@ def test_add2_layernorm_matches_two_separate_adds():
 
 @pytest.mark.parametrize("B,H,T", [(2, 3, 333), (1, 2, 37), (2, 12, 2305), (1, 16, 3601), (3, 12, 577)])
 def test_attention_fwd_vrow_matches_vt_variant_bitwise(B, H, T):
-    """V read row-major through the LDS transpose-reads (plain tiling, variant 1) gives the very bits of the V^T form (same MFMAs,
-    same order); the library default (variant 0) is either that or the peeled tiling, selected by T alone."""
+    """The library default (variant 0) is the plain tiling (variant 1) or the peeled one, selected by T alone.  Tuning builds also carry the round-1
+    form that takes V^T per head: V read row-major through the LDS transpose-reads gives its very bits (same MFMAs, same order)."""
+    tuning = os.environ.get("OWL_TUNING", "0") == "1"
     torch.manual_seed(B * 100 + T)
     Tp = (T + 7) // 8 * 8; D = H * 64; M = B * Tp
     qkv = torch.zeros(ops.pad_rows(M), 3 * D, device=DEV, dtype=torch.bfloat16)
@@ -438,9 +439,10 @@ def test_attention_fwd_vrow_matches_vt_variant_bitwise(B, H, T):
     vt[: B * D * Tp].view(B, D, Tp)[:] = qkv[:M, 2 * D:].reshape(B, Tp, D).transpose(1, 2)
     o1 = torch.zeros(ops.pad_rows(M), D, device=DEV, dtype=torch.bfloat16); l1 = torch.zeros(B, H, Tp, device=DEV)
     o2 = torch.zeros_like(o1); l2 = torch.zeros_like(l1)
-    ops.attention_fwd(qkv, qkv[:, D:], 3 * D, vt, D * Tp, o1, D, l1, B, H, T, Tp, 0.125)
     ops.attention_fwd_vrow(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, o2, D, l2, B, H, T, Tp, 0.125, variant=1)
-    assert torch.equal(o1, o2) and torch.equal(l1, l2)
+    if tuning:
+        ops.attention_fwd(qkv, qkv[:, D:], 3 * D, vt, D * Tp, o1, D, l1, B, H, T, Tp, 0.125)
+        assert torch.equal(o1, o2) and torch.equal(l1, l2)
     assert bool(torch.isfinite(o2.float()).all())
     o3 = torch.zeros_like(o1); l3 = torch.zeros_like(l1)
     ops.attention_fwd_vrow(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, o3, D, l3, B, H, T, Tp, 0.125, variant=0)
@@ -583,6 +585,7 @@ def test_layernorm_bwd_matches_torch_autograd(rows, D, bf16_dy):
 
 
 # ---- attention forward, one wave per SIMD (variant 3; csrc/attention_fwd_w64.hip) -----------------------------------------------------------------
+@pytest.mark.skipif(os.environ.get("OWL_TUNING", "0") != "1", reason="tuning-build experiment (OWL_TUNING=1 build of libowlhip.so): not in the shipped ABI")
 @pytest.mark.parametrize("B,H,T", [(1, 1, 193), (1, 1, 257), (2, 3, 577), (3, 2, 1025), (2, 12, 2305), (1, 2, 449), (1, 1, 3585)])
 def test_attention_fwd_one_wave_per_simd(B, H, T):
     """64 queries per wave, softmax interleaved with the neighbouring tiles' MFMAs (peeled tiling, T - 1 = 3 .. 56 key tiles, odd and even, full and
@@ -612,6 +615,7 @@ def test_attention_fwd_one_wave_per_simd(B, H, T):
     assert torch.equal(v(o3), v(out))
 
 
+@pytest.mark.skipif(os.environ.get("OWL_TUNING", "0") != "1", reason="tuning-build experiment (OWL_TUNING=1 build of libowlhip.so): not in the shipped ABI")
 @pytest.mark.parametrize("spike_key,spike_q,gain", [(250, 10, 12.0), (0, 5, 12.0), (2304, 2000, 12.0), (70, 0, 12.0), (0, 700, -12.0), (1, 1, 12.0)])
 def test_attention_fwd_one_wave_per_simd_redo_path(spike_key, spike_q, gain):
     """Scores outside the range of the offset-free softmax: the block raises its flag and the classic kernel redoes exactly that block in the same
@@ -644,9 +648,32 @@ def test_attention_fwd_one_wave_per_simd_redo_path(spike_key, spike_q, gain):
                 assert torch.equal(lse[0, h, rows], l2[0, h, rows])
 
 
+@pytest.mark.skipif(os.environ.get("OWL_TUNING", "0") != "1", reason="tuning-build experiment (OWL_TUNING=1 build of libowlhip.so): not in the shipped ABI")
 def test_attention_fwd_one_wave_per_simd_rejects_other_lengths():
     B, H, T = 1, 1, 129
     Tp = 136; D = 64
     qkv = ops.zeros_rows(Tp, 3 * D, torch.bfloat16, DEV); out = ops.zeros_rows(Tp, D, torch.bfloat16, DEV)
     with pytest.raises(RuntimeError, match="one wave per SIMD"):
         ops.attention_fwd_vrow(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, out, D, None, B, H, T, Tp, 0.125, variant=3)
+
+
+@pytest.mark.skipif(_TUNING, reason="the shipped library's refusals; a tuning build carries the experiments")
+def test_shipped_library_refuses_the_tuning_only_kernels():
+    """VERDICT r03 #5: the default libowlhip.so exports one entry per fused op; experiments are refused loudly, not silently re-routed."""
+    from owl_vit_object_detection_amd import _lib
+    B, H, T, Tp, D = 1, 1, 193, 200, 64
+    qkv = ops.zeros_rows(Tp, 3 * D, torch.bfloat16, DEV); out = ops.zeros_rows(Tp, D, torch.bfloat16, DEV)
+    with pytest.raises(RuntimeError, match="OWL_TUNING"):
+        ops.attention_fwd_vrow(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, out, D, None, B, H, T, Tp, 0.125, variant=3)
+    with pytest.raises(_lib.OwlLibError, match="variant must be 0"):
+        _lib.call("owl_attention_fwd_vrow_bf16", ops.stream(), qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, out, D, None, B, H, T, Tp, 0.125, 3, None)
+    A = ops.zeros_rows(512, 128, torch.bfloat16, DEV); W = torch.zeros(256, 128, dtype=torch.bfloat16, device=DEV); o = ops.zeros_rows(512, 256, torch.bfloat16, DEV)
+    for tile in (8, 9, 5, 4):
+        with pytest.raises(_lib.OwlLibError, match="tile must be 0"):
+            ops.gemm(ops.EPI_BIAS_BF16, A, W, o, M=512, tile=tile)
+    for epi in (ops.EPI_ATOMIC_F32, ops.EPI_TRANS_BF16):
+        with pytest.raises(_lib.OwlLibError, match="OWL_TUNING build"):
+            ops.gemm(epi, A, W, torch.zeros(512, 256, device=DEV), M=512, Tp=8)
+    lib = _lib.load()
+    for sym in ("owl_attention_fwd_bf16", "owl_attention_fwd_w64_bf16", "owl_attention_fwd_workspace_bytes", "owl_gemm_fr_ablate", "owl_gemm_set_persistent"):
+        assert not hasattr(lib, sym), sym

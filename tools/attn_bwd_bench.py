@@ -10,7 +10,7 @@ def run(B, H, T, iters=10):
     qkvT = torch.zeros(B * 3 * D * Tp + 256, device=DEV, dtype=torch.bfloat16)
     qkvT[: B * 3 * D * Tp].view(B, 3 * D, Tp)[:] = qkv[:M].view(B, Tp, 3 * D).transpose(1, 2)
     o = torch.zeros(ops.pad_rows(M), D, device=DEV, dtype=torch.bfloat16); lse = torch.zeros(B, H, Tp, device=DEV)
-    ops.attention_fwd(qkv, qkv[:, D:], 3 * D, qkvT[2 * D * Tp:], 3 * D * Tp, o, D, lse, B, H, T, Tp, 0.125)
+    ops.attention_fwd_vrow(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, o, D, lse, B, H, T, Tp, 0.125)
     do = torch.zeros_like(o); do[:M] = (torch.randn(M, D, device=DEV) * 0.1).bfloat16()
     doT = torch.zeros(B * D * Tp + 256, device=DEV, dtype=torch.bfloat16); doT[: B * D * Tp].view(B, D, Tp)[:] = do[:M].view(B, Tp, D).transpose(1, 2)
     dvec = torch.zeros(B, H, Tp, device=DEV); dqkv = torch.zeros_like(qkv)
