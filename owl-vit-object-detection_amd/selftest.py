@@ -34,10 +34,16 @@ def smoke() -> None:
     (rb, rs), lo, gref = O.train_step(cfg, w, torch.from_numpy(img), [torch.from_numpy(l) for l in labels],
                                       [torch.from_numpy(b) for b in boxes], torch.from_numpy(scales))
     eb = float((pb.detach().cpu() - rb).abs().max()); es = float((ps.detach().cpu() - rs).abs().max())
-    assert eb < 1e-2 and es < 1e-2, (eb, es)
+    # bands at ~2x what this step measures (round 4: boxes 1.46e-3, sims 1.65e-3; losses <= 1e-2 relative on this 36-patch config;
+    # whole-tensor gradient cosines >= 0.9989): the north star's bar is 1e-2 on the outputs
+    assert eb < 3e-3 and es < 3.5e-3, (eb, es)
     for k, v in lo.items():
-        assert abs(float(losses[k]) - float(v)) <= 1e-2 + 2e-2 * abs(float(v)), (k, float(losses[k]), float(v))
-    g = model.p("box_head.dense1.weight").grad.cpu(); r = gref["box_head.dense1.weight"]
-    assert float((g * r).sum() / (g.norm() * r.norm())) > 0.99
+        assert abs(float(losses[k]) - float(v)) <= 2e-2 * abs(float(v)), (k, float(losses[k]), float(v))
+    for name in ("queries", "class_predictor.dense0.weight", "box_head.dense1.weight", "backbone.encoder.layers.11.mlp.fc2.weight",
+                 "backbone.encoder.layers.11.self_attn.v_proj.weight"):
+        g = model.p(name).grad.detach().float().cpu().reshape(-1); r = gref[name].float().reshape(-1)
+        assert g.numel() >= 4096 or name == "queries", name
+        cos = float((g * r).sum() / (g.norm() * r.norm()))
+        assert cos > 0.995, (name, cos)
     assert float((model.flat_param - before).abs().max()) > 0, "optimizer did not move the parameters"
     print(f"smoke ok: max|d boxes|={eb:.2e} max|d sims|={es:.2e} losses=" + str({k: round(float(v), 4) for k, v in losses.items()}))

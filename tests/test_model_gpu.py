@@ -21,9 +21,53 @@ DEV = "cuda"
 # 1.9e-3 / 6.7e-4 (L/14), 1.7e-3 / 7.2e-4 (B/32); parity-test configs (tiny / small: 2 heads, D = 128 / 256, where one bf16 ulp of a
 # feature is a larger share of a cosine) boxes <= 1.7e-3 / sims <= 1.8e-3.
 TOL_BOXES, TOL_SIMS, TOL_SIMS_SMALLCFG = 4e-3, 2e-3, 3.5e-3
-# end-to-end gradient sanity bands of the full-size fixtures, ~2x the measured deviation (B/16 F2: worst norm ratio 8.1e-2, worst
-# 64-element cosine 0.944; L/14 F4: 5.1e-3).  The strict all-element check is the backward-chain test (measured <= 9.7e-3).
-REL_NORM, REL_NORM_L14, MIN_COS = 0.16, 0.02, 0.9
+# End-to-end gradient bands of the full-size fixtures: per tensor |norm ratio - 1| and the cosine on a 4096-element strided
+# sample of the WHOLE tensor (fixture key gradsample/), asserted at ~2x what the round-4 build measures (profiles/r04_parity_bands.md; the numbers
+# are printed by every run).  Default band for every tensor; the named ones need more and say why.  The strict all-element check is the
+# backward-chain test (measured <= 9.7e-3 rel-L2 at HF-init weights).
+# Measured (round 4):
+#   F4 (L/14): every tensor within 7.4e-3 / cosine >= 0.99606.
+#   F2 (B/16): tensors fed by the CLASS loss only (queries, class_predictor.*) within 1.4e-3 / 0.99998.  Matched row 450 of this fixture sits 2e-4 from
+#   its target in x0 (reference) -- the bf16 forward puts it at -4e-4, sign(p - t) of the L1 term flips, and that row carries the largest box
+#   gradient of the image (|d_box| 2.0 against 0.1-0.5 for the other twelve: tests/diag_box_grad.py).  Every tensor downstream of the BOX loss inherits
+#   it: backbone / LayerNorm tensors 2.6e-2 ... 7.7e-2 / 0.942 ... 0.967, box_head.* unrelated to the reference (skipped, as before).  The box path is
+#   pinned instead by test_loss_backward_at_the_operating_point (HIP d_boxes / d_sims == the oracle's autograd AT THE HIP OUTPUTS, 1e-7) and by the
+#   backward-chain test (same upstream into both backwards, <= 9.5e-3 on every tensor, batch 8 of B/16 included).
+GRAD_BANDS_DEFAULT = (1.5e-2, 0.992)                # (|norm ratio - 1|, min cosine on the 4096-element sample)
+_CLASS_ONLY = ("queries", "class_predictor.dense0.weight", "class_predictor.dense0.bias")
+GRAD_BANDS_F2 = {n: (3e-3, 0.9999) for n in _CLASS_ONLY}
+GRAD_BANDS_F2_BOX_FED = (0.155, 0.88)               # 2x (7.7e-2, 1 - 0.942): see above
+GRAD_BANDS_F4 = {}
+# losses: F2 <= 8.0e-4 (loss_ce 3.1e-4), F4 <= 5.0e-4 relative; parity-test configs (36-144 patches: one bf16 ulp of a sim is a larger share of a
+# loss): tiny B=1 loss_ce 9.75e-3, tiny B=3 4.4e-3, tiny-l14 3.2e-3, small 7e-4
+LOSS_REL_SMALLCFG = 2e-2
+LOSS_REL = 2e-3
+
+
+def _check_grads_vs_fixture(g, grads, tag, bands, skip=lambda n: False):
+    """Per-tensor comparison of the end-to-end gradients with a reference fixture: norm ratio (gradnorm/) + cosine on the 4096-element strided
+    sample (gradsample/).  Tensors whose reference norm is below 1e-5 (k_proj.bias: the true gradient is zero) must be ~zero."""
+    worst_norm, worst_cos, lines, bad = 0.0, 1.0, [], []
+    for n, gr in grads.items():
+        ref_norm = float(g["gradnorm/" + n])
+        if ref_norm < 1e-5:
+            assert float(gr.double().norm()) < 1e-3, n
+            continue
+        ratio = float(gr.double().norm()) / ref_norm
+        ref_s = torch.from_numpy(g["gradsample/" + n]).double()
+        ours_s = _sample(gr).double()
+        cos = float((ours_s * ref_s).sum() / (ours_s.norm() * ref_s.norm() + 1e-30))
+        skipped = skip(n)
+        lines.append(f"     {n:58s} |ref|={ref_norm:.3e} |norm ratio - 1| {abs(ratio - 1):.3e} cos(4096 sample) {cos:.5f}" + ("  (skipped: near-tie)" if skipped else ""))
+        if skipped:
+            continue
+        bn, bc = bands.get(n, bands.get("*", GRAD_BANDS_DEFAULT))
+        worst_norm = max(worst_norm, abs(ratio - 1.0)); worst_cos = min(worst_cos, cos)
+        if abs(ratio - 1.0) > bn or cos < bc:
+            bad.append((n, abs(ratio - 1.0), cos, bn, bc))
+    print("\n".join(lines))
+    print(f"{tag} end-to-end gradients: worst |norm ratio - 1| = {worst_norm:.3e}, worst 4096-sample cosine = {worst_cos:.5f}")
+    assert not bad, bad
 
 
 def _tol_sims(cname):
@@ -137,7 +181,8 @@ def _grad_report(grads, ref, tag):
     return worst, worst_cos
 
 
-@pytest.mark.parametrize("cname,B", [("tiny", 1), ("tiny", 3), ("small", 2), ("tiny-l14", 2), ("owlvit-base-patch32", 2), ("owlvit-base-patch16", 1), ("owlvit-large-patch14", 1)])
+@pytest.mark.parametrize("cname,B", [("tiny", 1), ("tiny", 3), ("small", 2), ("tiny-l14", 2), ("owlvit-base-patch32", 2), ("owlvit-base-patch16", 1), ("owlvit-large-patch14", 1),
+                                     ("owlvit-base-patch16", 8)])       # batch 8 of B/16: the batched backward tied to the oracle directly, not via batch-1 self-consistency
 def test_backward_chain_matches_oracle_given_same_upstream(cname, B):
     """Backward kernels in isolation: identical upstream (d_boxes, d_sims) into the HIP backward and into
     the oracle's autograd -- removes the loss's 1/|sim| amplification of bf16 forward noise."""
@@ -187,7 +232,8 @@ def test_train_step_matches_oracle(cname, B):
     assert eb < TOL_BOXES and es < _tol_sims(cname), (eb, es)
     # matched loss within the bf16 bar (relative for the large class terms)
     for k in LOSS_KEYS:
-        assert lg[k] == pytest.approx(float(lo[k]), rel=2e-2, abs=1e-2), (k, lg[k], float(lo[k]))
+        print(f"   {k}: {lg[k]:.6f} oracle {float(lo[k]):.6f} rel {abs(lg[k] - float(lo[k])) / abs(float(lo[k])):.2e}")
+        assert abs(lg[k] - float(lo[k])) <= LOSS_REL_SMALLCFG * abs(float(lo[k])), (k, lg[k], float(lo[k]))
     assert set(grads) == set(gref) and len(grads) == 29
     # end-to-end gradients are a sanity check only: the class terms' -w/|sim| slope and the max-over-prompts
     # routing amplify the ~1e-3 bf16 forward deviation (the strict kernel check is the backward-only test)
@@ -205,7 +251,8 @@ def test_train_step_matches_reference_fixture_f1(golden_dir, cname):
     model, crit, lg, grads, pb, ps = _step_hip(cfg, weights.make_weights(cfg), img, labels, boxes, g["scales"])
     assert np.array_equal(crit.last["target_classes"][0].cpu().numpy(), g["target_classes"])
     for k in LOSS_KEYS:
-        assert lg[k] == pytest.approx(float(g[k]), rel=2e-2, abs=1e-2), k
+        print(f"   {k}: {lg[k]:.6f} ref {float(g[k]):.6f} rel {abs(lg[k] - float(g[k])) / abs(float(g[k])):.2e}")
+        assert abs(lg[k] - float(g[k])) <= LOSS_REL_SMALLCFG * abs(float(g[k])), k
     ref = {k[5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("grad/")}
     worst, worst_cos = _grad_report(grads, ref, f"{cname} vs reference fixture")
     assert worst_cos > 0.99
@@ -286,30 +333,44 @@ def test_train_step_b16_matches_reference_fixture_f2(golden_dir):
     assert same == 1.0
     eb, es = _maxerr(pb, torch.from_numpy(g["pred_boxes"])), _maxerr(ps, torch.from_numpy(g["pred_sims"]))
     assert eb < TOL_BOXES and es < TOL_SIMS, (eb, es)
-    bound = _class_loss_bound(cfg, g, es)
     for k in LOSS_KEYS:
-        assert abs(lg[k] - float(g[k])) <= max(2e-2 * abs(float(g[k])), 1e-2, bound.get(k, 0.0)), (k, lg[k], float(g[k]), bound)
+        print(f"   {k}: {lg[k]:.6f} ref {float(g[k]):.6f} rel {abs(lg[k] - float(g[k])) / abs(float(g[k])):.2e}")
+        assert abs(lg[k] - float(g[k])) <= LOSS_REL * abs(float(g[k])), (k, lg[k], float(g[k]))
     near_tie = _near_tie(g, boxes)
-    big = max(float(g["gradnorm/" + n]) for n in grads)
-    worst_norm, worst_cos = 0.0, 1.0
-    for n, gr in grads.items():
-        ref_norm = float(g["gradnorm/" + n])
-        if ref_norm < 1e-5:
-            assert float(gr.double().norm()) < 1e-3, n          # k_proj.bias: true gradient is zero
-            continue
-        if near_tie and n.startswith("box_head"):
-            continue
-        worst_norm = max(worst_norm, abs(float(gr.double().norm()) / ref_norm - 1.0))
-        assert float(gr.double().norm()) == pytest.approx(ref_norm, rel=REL_NORM), n
-        if ref_norm < 1e-2 * big:
-            continue      # q/k projections: gradients are differences of near-equal terms (near-uniform softmax at random
-                          # init), 100x smaller than the rest -- a 64-element sample of them is bf16 noise; norm checked above
-        head = torch.from_numpy(g["gradhead/" + n])
-        cos = float((gr.reshape(-1)[:64] * head).sum() / (gr.reshape(-1)[:64].norm() * head.norm() + 1e-20))
-        worst_cos = min(worst_cos, cos)
-        assert cos > MIN_COS, (n, cos)    # 64-element sample of an end-to-end gradient (loss-amplified bf16 noise);
-                                      # the strict all-element check is test_backward_chain_...[owlvit-base-patch16-1]
-    print(f"B/16 end-to-end gradients vs F2: worst |norm ratio - 1| = {worst_norm:.3e}, worst 64-element cos = {worst_cos:.5f}")
+    assert near_tie                      # (the fixture's row 450; if the fixture changes, the box-fed band below goes back to the default)
+    _check_grads_vs_fixture(g, grads, "B/16 F2", dict(GRAD_BANDS_F2, **{"*": GRAD_BANDS_F2_BOX_FED}), skip=lambda n: near_tie and n.startswith("box_head"))
+
+
+@pytest.mark.parametrize("cname", ["owlvit-base-patch16", "owlvit-large-patch14", "small"])
+def test_loss_backward_at_the_operating_point(cname):
+    """What the end-to-end fixtures cannot pin when a matched box sits on a kink of the loss: d loss / d (pred_boxes, pred_sims) of the HIP criterion
+    against the oracle's autograd of the same loss evaluated AT THE HIP FORWARD'S OWN OUTPUTS (same inputs into both -> same decisions, same kinks).
+    Measured: 1.2e-7 / 1.9e-6 absolute on gradients of magnitude 2.0 / 15."""
+    cfg = get_config(cname)
+    B = 1 if cname.startswith("owlvit") else 3
+    img = synth.make_images(cfg, B)
+    labels, boxes = synth.make_targets(cfg, B, max_boxes=16)
+    scales = synth.class_scales(cfg, labels)
+    model = OwlViT(cfg, weights.make_weights(cfg), DEV)
+    crit = PushPullLoss(cfg.n_classes, scales)
+    pb, _, ps, _ = model(torch.from_numpy(img).to(DEV))
+    pb.retain_grad(); ps.retain_grad()
+    l = crit(ps, [torch.from_numpy(x).to(DEV) for x in labels], pb, [torch.from_numpy(x).to(DEV) for x in boxes])
+    (l["loss_ce"] + l["loss_bg"] + l["loss_bbox"] + l["loss_giou"]).backward()
+    sims = ps.detach().cpu().clone().requires_grad_(True); bx = pb.detach().cpu().clone().requires_grad_(True)
+    details = []
+    lo = O.push_pull_loss(sims, [torch.from_numpy(x) for x in labels], bx, [torch.from_numpy(x) for x in boxes], cfg.n_classes, torch.from_numpy(scales), details)
+    (lo["loss_ce"] + lo["loss_bg"] + lo["loss_bbox"] + lo["loss_giou"]).backward()
+    for b in range(B):
+        n = len(labels[b])
+        assert np.array_equal(crit.last["pred_idx"][b, :n].cpu().numpy(), details[b]["pred_idx"].numpy())
+        assert np.array_equal(crit.last["tgt_idx"][b, :n].cpu().numpy(), details[b]["tgt_idx"].numpy())
+        assert np.array_equal(crit.last["target_classes"][b].cpu().numpy(), details[b]["target_classes"].numpy())
+    for k in LOSS_KEYS:
+        assert float(l[k]) == pytest.approx(float(lo[k]), rel=2e-5, abs=1e-6), k
+    db, ds = float((pb.grad.cpu() - bx.grad).abs().max()), float((ps.grad.cpu() - sims.grad).abs().max())
+    print(f"{cname}: d_boxes max abs diff {db:.3e} (|.| max {float(bx.grad.abs().max()):.3e}), d_sims {ds:.3e} (|.| max {float(sims.grad.abs().max()):.3e})")
+    assert db <= 1e-5 * max(1.0, float(bx.grad.abs().max())) and ds <= 1e-5 * max(1.0, float(sims.grad.abs().max())), (db, ds)
 
 
 def test_l14_train_step_matches_reference_fixture_f4(golden_dir):
@@ -328,24 +389,17 @@ def test_l14_train_step_matches_reference_fixture_f4(golden_dir):
     print(f"L/14 vs reference fixture: max|d boxes|={eb:.3e} max|d sims|={es:.3e}; losses", lg,
           "ref", {k: float(g[k]) for k in LOSS_KEYS}, "target agreement", same)
     assert eb < TOL_BOXES and es < TOL_SIMS, (eb, es)
-    bound = _class_loss_bound(cfg, g, es)
     ref_l, n_swaps, n_rows = _reference_losses_for_decisions(cfg, g, labels, boxes, crit, eb, es)
     print("near-tie decisions differing from the fixture: assignment swaps", n_swaps, "label rows", n_rows,
           "-> reference losses under these decisions:", ref_l)
     for k in LOSS_KEYS:
         ref = ref_l[k] if (n_swaps or n_rows) else float(g[k])
-        assert abs(lg[k] - ref) <= max(2e-2 * abs(ref), 1e-2, bound.get(k, 0.0)), (k, lg[k], ref, bound)
+        print(f"   {k}: {lg[k]:.6f} ref {ref:.6f} rel {abs(lg[k] - ref) / abs(ref):.2e}")
+        assert abs(lg[k] - ref) <= LOSS_REL * abs(ref), (k, lg[k], ref)
     near_tie = _near_tie(g, boxes)      # (here row 610: x1 = 0.1997 vs 0.1996)
-    big = max(float(g["gradnorm/" + n]) for n in grads)
-    worst_norm = 0.0
-    for n, gr in grads.items():
-        ref_norm = float(g["gradnorm/" + n])
-        if ref_norm < 1e-2 * big or (near_tie and n.startswith("box_head")):
-            continue
-        worst_norm = max(worst_norm, abs(float(gr.double().norm()) / ref_norm - 1.0))
-        assert float(gr.double().norm()) == pytest.approx(ref_norm, rel=REL_NORM_L14), n
-    print(f"L/14 end-to-end gradients vs F4: worst |norm ratio - 1| = {worst_norm:.3e}")
     print("near-tie between a matched prediction and its target:", near_tie)
+    if not (n_swaps or n_rows):         # (other decisions: other gradients -- the losses above are compared like with like, the gradients cannot be)
+        _check_grads_vs_fixture(g, grads, "L/14 F4", GRAD_BANDS_F4, skip=lambda n: near_tie and n.startswith("box_head"))
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -355,7 +409,7 @@ def test_l14_train_step_matches_reference_fixture_f4(golden_dir):
 # The north star's bf16 bar (outputs within 1e-2) is the assertion; measured values are printed and quoted in DESIGN.md.
 # ---------------------------------------------------------------------------------------------------
 TOL_TRAINED = 1e-2                                  # the north star's bar
-# ... asserted at ~2x the measured deviation of the round-4 build (gpurun_out/r4_f10b.log): "trained_like" B/16 boxes 3.13e-3 (rms 6.3e-4) /
+# ... asserted at ~2x the measured deviation of the round-4 build (profiles/r04_parity_bands.md): "trained_like" B/16 boxes 3.13e-3 (rms 6.3e-4) /
 # sims 1.57e-4, tiny 4.2e-4 / 4.6e-5; slow-path tiles 6037 against 6064 predicted from the reference's own logits
 TOL_TRAINED_BOXES, TOL_TRAINED_SIMS = 6.5e-3, 4e-4
 
@@ -466,7 +520,7 @@ def test_backward_chain_trained_like_matches_oracle_given_same_upstream(cname, B
     torch.autograd.backward([rb, rs], [d_boxes, d_sims])
     gref = {n: ww[n].grad for n in names}
     worst, worst_cos = _grad_report(grads, gref, f"backward-only trained-like {cname} B={B}")
-    # measured (gpurun_out/r4_f10b.log): tiny 2.1e-2 / 0.99984; B/16 7.5e-2 / 0.99737, worst on layer 11's layer_norm1.weight (|ref| 0.19 beside
+    # measured (profiles/r04_parity_bands.md): tiny 2.1e-2 / 0.99984; B/16 7.5e-2 / 0.99737, worst on layer 11's layer_norm1.weight (|ref| 0.19 beside
     # v_proj.weight's 10.0) and its q / k projections (3.6-4.1e-2): P and dS in bf16 under a peaked softmax (logit std 8); at HF-init weights the same
     # chain measures <= 9.7e-3 (test_backward_chain_matches_oracle_given_same_upstream)
     assert worst < 0.15 and worst_cos > 0.995, (worst, worst_cos)
