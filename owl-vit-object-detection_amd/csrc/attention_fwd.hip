@@ -161,7 +161,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 1) void attn_fwd_kernel(Attn
     //    is 1.0 in contraction slot 0 and whose Q-side fragment holds -M there (M is kept bf16-exact, so the product is
     //    exact) -- S arrives as s*c - M and P = exp2(S) needs no VALU fma (the matrix pipe is 45 % busy, it has room);
     //  * no per-tile row maximum: the tile keeps the OLD M as long as P cannot overflow -- checked on the tile's row
-    //    sums (sum <= 2^40, also catches inf / NaN); only a tile that fails the check takes the
+    //    sums (sum <= 2^88, also catches inf / NaN); only a tile that fails the check takes the
     //    slow path: recompute S with C = 0, explicit maximum, rescale O and l, new splat;
     //  * the offset starts at ZERO (no offset MFMA at all: 16 instead of 18 MFMAs per tile) and is only set by the first tile
     //    that fails the check (overflow, or -- first tile -- a row about to underflow): scores of ordinary size never need one.
@@ -274,8 +274,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 1) void attn_fwd_kernel(Attn
                     s[t][r] = __builtin_amdgcn_exp2f(s[t][r]);
                     ts += s[t][r];
                 }
-            // 2^40: P may have overflowed (or is about to); first tile only: 2^-60, the whole row may be about to underflow
-            slow = __any(!(ts <= 1.0995116e12f) || (first && ts < 8.6736174e-19f));
+            // 2^88: P may have overflowed (or is about to); first tile only: 2^-60, the whole row may be about to underflow.
+            // (Rounds 1-3 used 2^40.  Nothing needs that much room: P is exact to bf16's 2^-9 at any magnitude, and 2^88 x 2^12 keys x |v| <= 2^20 still
+            // fits f32 -- while scores 28 nats above the offset a wave holds are ORDINARY for trained weights with attention sinks: fixture F10's
+            // logits reach 56 nats, every wave took this path once per layer, +7 % on the launch.  At 2^88 = 61 nats it is what it was meant to be:
+            // rare.  profiles/r04_attn_verdict.md)
+            slow = __any(!(ts <= ATTN_VERDICT_SUM) || (first && ts < 8.6736174e-19f));
         }
         if (slow) {                                              // wave-uniform
             qk(std::false_type{});                               // s = score*c
@@ -358,7 +362,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 1) void attn_fwd_kernel(Attn
         if constexpr (PEEL) {
             // Key 0 as the initial state, on the matrix pipe (the kernel is VALU-bound: as VALU dot products this cost two tiles' worth of
             // VALU issue per wave).  s0: four MFMAs against a K fragment whose only non-zero row is row 0 = k0 -> register 0 of the lanes
-            // with hi == 0.  Ordinary scores (|s0| <= 40) leave the offset at 0 like the first tile's fast path; anything else (or inf /
+            // with hi == 0.  Ordinary scores (|s0| <= 88) leave the offset at 0 like the first tile's fast path; anything else (or inf /
             // NaN) makes s0 the offset -- what the slow path of a first tile would do with a one-key tile.  O = v0 p0: two MFMAs with
             // contraction slot 0 (= key 0) the only live one.
             if (active) {
@@ -370,7 +374,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 1) void attn_fwd_kernel(Attn
                     s0t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kz), qf[kc], s0t, 0, 0, 0);
                 }
                 const float s0 = __shfl(s0t[0], lane & 31, 64);   // both half-waves carry the same offset
-                if (__any(!(fabsf(s0) <= 40.f)) || (p.dbg & 5)) {
+                if (__any(!(fabsf(s0) <= ATTN_VERDICT_LOG2)) || (p.dbg & 5)) {
                     M = bf2f(f2bf(s0));
                     have_m = true;
                     qn4.x = hi == 0 ? (unsigned)f2bf(-M) : 0u;

@@ -15,6 +15,12 @@ struct AttnFwdP {
     int* slow_tiles;                                    // optional device counter: += 1 per (wave, key tile) that leaves the fast path after a wave's first tile
 };
 
+// The stale-offset verdict of the forward sweep: a tile keeps the softmax offset its wave already holds as long as every row sum of the tile stays below
+// 2^88 (log2 domain: scores up to 88 above the offset = 61 nats); see attention_fwd.hip.  tests/golden/make_golden.py (attention_stats) simulates the
+// same rule on the reference's logits to predict the kernel's slow-path count -- keep the two in step.
+#define ATTN_VERDICT_LOG2 88.0f
+#define ATTN_VERDICT_SUM 3.0948501e26f          // 2^88
+
 __device__ __forceinline__ int swap23(int m) { return (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1); }
 
 // VROW = false: V arrives per head TRANSPOSED (V^T [B][heads*64][Tp], written by a transposing GEMM epilogue or a token transpose).

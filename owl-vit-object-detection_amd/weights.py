@@ -126,10 +126,11 @@ TRAINED_LIKE = dict(
     fc2_bias_layers={3: (20.0, 10.0, -30.0), 7: (-12.0, 25.0, 15.0)},   # branch outputs that carry large values
     ln_gain_log_range=(0.3, 3.0),                    # gamma log-uniform in this range (one decade) ...
     ln_gain_massive=0.3,                             # ... except on the massive channels (trained models damp them)
-    qk_gain=16.0,                                    # q_proj / k_proj weights x this: logit std ~ 8 at B/16 (tests/golden/make_golden.py f10 prints it)
+    qk_gain=18.0,                                    # q_proj / k_proj weights x this: logit std ~ 8 at B/16 (tests/golden/make_golden.py f10 prints it)
     sink_tokens=(0.55, 0.9, 0.995),                  # patch index as a fraction of P (late keys: the running offset is set before them)
-    sink_embed=60.0,                                 # position_embedding[sink, c0]: the sink tokens' massive activation
-    sink_k_col=3.0,                                  # k_proj.weight[:, c0] x this (all layers): sink keys stand out
+    sink_channel=0.45,                               # the sink tokens' own channel c_s (fraction of D; not one of the massive ones: gain 1 in every layer_norm1)
+    sink_embed=60.0,                                 # position_embedding[sink, c_s]: the sink tokens' massive activation
+    sink_k_col=5.0,                                  # k_proj.weight[:, c_s] x this (all layers): sink keys stand out
     class_align=((3, 5.5), (10, -2.0), (17, 1.0)),   # class_predictor.dense0.bias += a * |e|_typ * queries[j]
 )
 
@@ -149,30 +150,35 @@ def trained_like(cfg: OwlConfig, base: "OrderedDict[str, np.ndarray]", seed: int
     D, P = cfg.hidden, cfg.patches
     out = OrderedDict((k, v.copy()) for k, v in base.items())
     ch = [int(f * D) for f in t["massive_channels"]]
+    cs = int(t["sink_channel"] * D)
     lo, hi = np.log(t["ln_gain_log_range"][0]), np.log(t["ln_gain_log_range"][1])
     for name in out:
         if ("layernorm" in name or "layer_norm" in name) and name.endswith("weight"):
             u = rng.uniform(seed, cfg.name + "/tl/" + name, D)
             g = np.exp(lo + (hi - lo) * u)
             g[ch] = t["ln_gain_massive"]
+            if name.endswith("layer_norm1.weight"):
+                g[cs] = 1.0
             sign = np.where(rng.uniform(seed, cfg.name + "/tl/sign/" + name, D) < 0.1, -1.0, 1.0)     # a few negative gains, as trained models have
+            sign[cs] = 1.0
             out[name] = (g * sign).astype(np.float32)
     b = out["backbone.pre_layernorm.bias"]
     b[ch] = np.asarray(t["massive_bias"], np.float32)
-    out["backbone.pre_layernorm.weight"][ch] = 2.0                      # the sink tokens' activation passes pre_layernorm at full size
+    out["backbone.pre_layernorm.weight"][ch] = 2.0
+    out["backbone.pre_layernorm.weight"][cs] = 2.0                      # the sink tokens' activation passes pre_layernorm at full size
     for li, vals in t["fc2_bias_layers"].items():
         if li < cfg.layers:
             out[f"backbone.encoder.layers.{li}.mlp.fc2.bias"][ch] = np.asarray(vals, np.float32)
     pos = out["backbone.embeddings.position_embedding.weight"]
     for f in t["sink_tokens"]:
-        pos[1 + min(P - 1, int(f * P)), ch[0]] = t["sink_embed"]
+        pos[1 + min(P - 1, int(f * P)), cs] = t["sink_embed"]
     for i in range(cfg.layers):
         pre = f"backbone.encoder.layers.{i}.self_attn."
         out[pre + "q_proj.weight"] *= np.float32(t["qk_gain"])
         out[pre + "k_proj.weight"] *= np.float32(t["qk_gain"])
         out[pre + "q_proj.bias"] *= np.float32(t["qk_gain"])
         out[pre + "k_proj.bias"] *= np.float32(t["qk_gain"])
-        out[pre + "k_proj.weight"][:, ch[0]] *= np.float32(t["sink_k_col"])
+        out[pre + "k_proj.weight"][:, cs] *= np.float32(t["sink_k_col"])
     # class head: e = W f + b with |W f| ~ |f| (rows of std D^-0.5); feats are LayerNorm outputs, |f|^2 ~ sum gamma^2
     g_pp = out["post_post_layernorm.weight"].astype(np.float64)
     e_typ = float(np.sqrt((g_pp ** 2).sum() / D * cfg.text_dim))        # typical |W f|

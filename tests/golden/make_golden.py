@@ -242,8 +242,8 @@ def f2():
 def attention_stats(model, cfg, image):
     """Statistics of the reference's own attention logits on `image` (hooks on every layer's layer_norm1): per layer the std / max of the logits
     and a simulation of the HIP forward's softmax-offset logic on them -- the kernel (csrc/attention_fwd.hip) exponentiates a 64-key tile against
-    the offset it already holds and only recomputes (`slow path`) when a row sum of the tile exceeds 2^40; one wave = 32 consecutive queries, the class
-    token is peeled (key 0 is the initial state, |s0| > 40 sets the offset), tiles cover keys 1..T-1 in order.  `slow_tiles` = (wave, tile) pairs
+    the offset it already holds and only recomputes (`slow path`) when a row sum of the tile exceeds 2^88 (csrc/attention_fwd_common.h); one wave = 32 consecutive queries, the class
+    token is peeled (key 0 is the initial state, |s0| > 88 sets the offset), tiles cover keys 1..T-1 in order.  `slow_tiles` = (wave, tile) pairs
     that would take the slow path at this layer, all heads (the first tile of a wave does not count: it cannot overflow an empty state)."""
     hs = {}
     hooks = []
@@ -268,12 +268,12 @@ def attention_stats(model, cfg, image):
         nq = (T - 1) // 32 * 32
         n_slow = 0
         s0 = s2[:, :nq, 0]
-        M = torch.where(s0.abs() > 40, s0, torch.zeros_like(s0))           # [H, nq] per-query offset
+        M = torch.where(s0.abs() > 88, s0, torch.zeros_like(s0))           # [H, nq] per-query offset
         keys = s2[:, :nq, 1:]
         for t0 in range(0, keys.shape[-1] - 63, 64):
             tile = keys[:, :, t0:t0 + 64]
             rs = torch.exp2((tile - M[..., None]).double()).sum(-1)        # row sums against the held offset
-            trip = (rs > 2.0 ** 40).view(H, nq // 32, 32).any(-1)          # wave-uniform verdict
+            trip = (rs > 2.0 ** 88).view(H, nq // 32, 32).any(-1)          # wave-uniform verdict
             n_slow += int(trip.sum())
             tm = tile.max(-1).values
             upd = trip[..., None].expand(H, nq // 32, 32).reshape(H, nq)

