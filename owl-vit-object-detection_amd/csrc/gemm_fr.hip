@@ -45,7 +45,8 @@ __device__ __forceinline__ bf16x8 f_ldsr(unsigned addr) {
 
 // LINES: the W tile is staged with its rows permuted inside every 64-row group so that a lane's accumulators are 64 contiguous output bytes, and the
 // epilogue stores quad-contiguous (gemm_common.h, epi_lines_bf16): the bias epilogue.
-// ABL (OWL_TUNING builds, timing only -- results are wrong): bit 0 = no LDS-DMA requests after the prologue, bit 1 = fragments read once per tile
+// ABL (OWL_TUNING builds, timing only -- results are wrong): bit 0 = no LDS-DMA requests after the prologue, bit 1 = fragments read once per tile;
+// 8 = requests issued but never waited for (timing only); 4 = (correct results) the stage's six requests spread over the second MFMA half, one behind each of its first six MFMAs, instead of a burst behind the barrier
 template <int EPI, bool LINES, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void gemm_fr_kernel(GemmP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -76,8 +77,12 @@ __global__ __launch_bounds__(256, 2) void gemm_fr_kernel(GemmP p) {
     const bf16_t* w_base = nullptr;
     const float* b_base = nullptr;
     const bool has_bias = p.bias != nullptr;
-    auto stage = [&]() -> int {                      // 6 VMEM ops (7 with the tile's bias slice)
+    bool st_first = false;
+    const unsigned char* st_ga = nullptr; const unsigned char* st_gw = nullptr; unsigned char* st_base = nullptr;
+    const unsigned char* st_gp[6] = {};              // (ABL & 4: the six per-lane source addresses, formed before the MFMAs they are issued between)
+    auto stage_prep = [&]() {
         const bool first = c_k == 0;
+        st_first = first;
         if (first) {
             int tm, tn; decode(c_item, tm, tn);
             const int64_t m0 = (int64_t)tm * FBM, n0 = (int64_t)tn * FBN;
@@ -105,23 +110,41 @@ __global__ __launch_bounds__(256, 2) void gemm_fr_kernel(GemmP p) {
                 b_voff = (unsigned)((n - n0) * 4);
             }
         }
-        unsigned char* base = lds + c_buf * F_STAGE;
-        const unsigned char* ga = (const unsigned char*)(a_base + (int64_t)c_k * FBK);
-        const unsigned char* gw = (const unsigned char*)(w_base + (int64_t)c_k * FBK);
+        st_base = lds + c_buf * F_STAGE;
+        st_ga = (const unsigned char*)(a_base + (int64_t)c_k * FBK);
+        st_gw = (const unsigned char*)(w_base + (int64_t)c_k * FBK);
+        if constexpr ((ABL & 4) != 0) {
 #pragma unroll
-        for (int q = 0; q < 2; q++)
-            __builtin_amdgcn_global_load_lds(GPTR(ga + a_voff[q]), LPTR(base + (2 * wc + q) * 1024), 16, 0, 0);
+            for (int q = 0; q < 2; q++) st_gp[q] = st_ga + a_voff[q];
 #pragma unroll
-        for (int q = 0; q < 4; q++)
-            __builtin_amdgcn_global_load_lds(GPTR(gw + w_voff[q]), LPTR(base + F_A_BYTES + (4 * wc + q) * 1024), 16, 0, 0);
+            for (int q = 0; q < 4; q++) st_gp[2 + q] = st_gw + w_voff[q];
+#pragma unroll
+            for (int q = 0; q < 6; q++) asm volatile("" : "+v"(st_gp[q]));
+        }
+    };
+    auto stage_issue = [&](int q) {                  // request q of the stage: 0, 1 = A pieces, 2 .. 5 = W pieces
+        if constexpr ((ABL & 4) != 0) {
+            __builtin_amdgcn_global_load_lds(GPTR(st_gp[q]), LPTR(st_base + (q < 2 ? (2 * wc + q) * 1024 : F_A_BYTES + (4 * wc + q - 2) * 1024)), 16, 0, 0);
+            return;
+        }
+        if (q < 2) __builtin_amdgcn_global_load_lds(GPTR(st_ga + a_voff[q]), LPTR(st_base + (2 * wc + q) * 1024), 16, 0, 0);
+        else __builtin_amdgcn_global_load_lds(GPTR(st_gw + w_voff[q - 2]), LPTR(st_base + F_A_BYTES + (4 * wc + q - 2) * 1024), 16, 0, 0);
+    };
+    auto stage_finish = [&]() -> int {
         int n_ops = 6;
-        if (first && has_bias) {
+        if (st_first && has_bias) {
             __builtin_amdgcn_global_load_lds(GPTR((const unsigned char*)b_base + b_voff), LPTR(lds + F_BIAS_OFF + c_parity * 1024), 16, 0, 0);
             n_ops = 7;
         }
         c_buf = c_buf == F_NSTAGE - 1 ? 0 : c_buf + 1;
         if (++c_k == nk) { c_k = 0; c_item += item_step; c_parity ^= 1; }
         return n_ops;
+    };
+    auto stage = [&]() -> int {                      // 6 VMEM ops (7 with the tile's bias slice)
+        stage_prep();
+#pragma unroll
+        for (int q = 0; q < 6; q++) stage_issue(q);
+        return stage_finish();
     };
 
     // fragment addresses (absolute 32-bit LDS addresses; row = 32 i + (lane & 31): the swizzle key depends on the lane only)
@@ -188,6 +211,8 @@ __global__ __launch_bounds__(256, 2) void gemm_fr_kernel(GemmP p) {
             __builtin_amdgcn_sched_barrier(0);
             // F1 in registers; this wave's pieces of the NEXT stage landed: everything but the newest request -- and, for two K-steps after an
             // epilogue, its stores, which are younger than that stage's pieces (vmcnt is one in-order counter for loads and stores)
+            if constexpr ((ABL & 8) != 0) f_wait_lgkm();          // (ablation: requests issued, never waited for)
+            else
             switch (n_last + (store_age > 0 ? 16 : 0)) {
                 case 6: f_wait<6>(); break;
                 case 7: f_wait<7>(); break;
@@ -201,9 +226,24 @@ __global__ __launch_bounds__(256, 2) void gemm_fr_kernel(GemmP p) {
             n_last = 0;
             if (ABL & 1) {              // (ablation: the cursor advances, nothing is requested)
                 if (c_item < item_end) { c_buf = c_buf == F_NSTAGE - 1 ? 0 : c_buf + 1; if (++c_k == nk) { c_k = 0; c_item += item_step; c_parity ^= 1; } }
-            } else if (c_item < item_end) n_last = stage();
+            } else if (!(ABL & 4) && c_item < item_end) n_last = stage();
+            const bool spread = (ABL & 4) && c_item < item_end;      // requests spread over the second MFMA half: one behind each of its first six MFMAs
+            if (spread) stage_prep();
             if (kt + 1 < nk && !(ABL & 2)) rd(0, nxt);             // (the next TILE's first fragments are read after the epilogue: they would be 24 live registers in it)
-            mma(1);
+            if constexpr ((ABL & 4) != 0) {
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[1][j], fa[1][i], acc[i][j], 0, 0, 0);
+                        if (2 * i + j < 6 && spread) stage_issue(2 * i + j);
+                    }
+                __builtin_amdgcn_s_setprio(0);
+                if (spread) n_last = stage_finish();
+            } else {
+                mma(1);
+            }
             __builtin_amdgcn_sched_barrier(0);
             cur = nxt;
         }
@@ -278,6 +318,9 @@ static int launch_fr_k(hipStream_t s, const GemmP& p, int nitems) {
             case 1: return launch_fr_abl<EPI, LINES, 1>(s, p, nitems);
             case 2: return launch_fr_abl<EPI, LINES, 2>(s, p, nitems);
             case 3: return launch_fr_abl<EPI, LINES, 3>(s, p, nitems);
+            case 4: return launch_fr_abl<EPI, LINES, 4>(s, p, nitems);
+            case 8: return launch_fr_abl<EPI, LINES, 8>(s, p, nitems);
+            case 12: return launch_fr_abl<EPI, LINES, 12>(s, p, nitems);
             default: break;
         }
     }
