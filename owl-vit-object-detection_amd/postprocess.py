@@ -15,7 +15,7 @@ score, as ``torchvision.ops.batched_nms`` returns them).  Additions are keyword-
   runs (main.py:30,105-111): the coordinate trick up to 20 000 box coordinates past the threshold, i.e. always for
   OWL-ViT's <= 3600 boxes; ``"torchvision_cpu"`` mirrors the CPU path (per class above 1000 boxes); ``"per_class"`` /
   ``"coordinate_offset"`` pin one.  The routes only differ where the f32 rounding of the shifted coordinates moves an
-  IoU across the threshold (DESIGN.md section 8).
+  IoU across the threshold (DESIGN.md section 10).
 
 All arithmetic runs in ``owl_postprocess`` (csrc/postprocess.hip): one sort launch, one pair-mask launch, one scan
 launch.  No CPU fallback.

@@ -1,5 +1,5 @@
 """Is the small-batch forward launch-bound?  Eval forward at batch 1 / 2 / 8, eager against a hipGraph replay of the same launches (torch.cuda.graph; the model's
-side streams join the capture through their events).  Result (findings): no -- 1.947 vs 1.927 ms at batch 1."""
+side streams join the capture through their events).  Result: no -- 1.947 vs 1.927 ms at batch 1."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
