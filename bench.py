@@ -466,19 +466,24 @@ def main():
             if rank == 0:
                 line_inline["config"]["schedule_check"] = f"deferred-tail phase did not finish within {int(limit)} s: in-line schedule reported"
                 print(json.dumps(line_inline), flush=True)
-            os._exit(0 if rank == 0 else 3)
+            os._exit(0)
         limit = max(120.0, 40.0 * dt_in)
         dog = threading.Timer(limit, bail); dog.daemon = True; dog.start()
-        ok = preflight(args.targets)
-        if ok:
-            set_schedule(True)
-            dt, slow = timed_run(args.targets, args.steps, args.warmup, False)
-            eq = replicas_equal()
+        try:
+            ok = preflight(args.targets)
+            if ok:
+                set_schedule(True)
+                dt, slow = timed_run(args.targets, args.steps, args.warmup, False)
+                eq = replicas_equal()
+                if eq is False or eq_in is False:
+                    ok = False
             dog.cancel()
-            if eq is False or eq_in is False:
-                ok = False
-        else:
+        except Exception as e:                      # (a collective that failed on the side stream: the process group may be unusable -- report and leave)
             dog.cancel()
+            if rank == 0:
+                line_inline["config"]["schedule_check"] = f"deferred-tail phase raised {type(e).__name__}: {str(e)[:200]} -- in-line schedule reported"
+                print(json.dumps(line_inline), flush=True)
+            os._exit(0)
         if ok:
             extra["schedule_check"] = "pre-flight: 2 steps from one state, deferred tail == in-line bitwise (losses and parameters); in-line measured first"
             extra["images_per_sec_deferred_tail_schedule"] = round(B * world * args.steps / dt, 2)
