@@ -105,11 +105,12 @@ def test_four_step_trajectory_matches_the_oracle(profile):
     # wherever the gradient has a sign: the comparison is of update directions)
     worst = 1.0
     for n in names:
+        if n.endswith("k_proj.bias"):
+            continue                      # softmax is invariant to a key bias: the true gradient is zero and Adam turns its round-off into +-lr steps
         d_hip = model.p(n).detach().cpu().double() - torch.from_numpy(Wnp[n]).double()
         d_ref = w[n].double() - torch.from_numpy(Wnp[n]).double()
-        if float(d_ref.norm()) < 1e-9:
-            continue
         cos = float((d_hip * d_ref).sum() / (d_hip.norm() * d_ref.norm() + 1e-30))
+        print(f"     {n:58s} |update| {float(d_ref.norm()):.3e} cos {cos:.4f}")
         worst = min(worst, cos)
     print(f"{profile}: worst cosine between the four-step parameter updates = {worst:.4f}")
-    assert worst > 0.85, worst
+    assert worst > 0.94, worst         # measured: init 0.9696 (box head: the L1 kink of a matched row), trained_like 0.9951; losses within 5.1e-3 / 2e-5
