@@ -46,7 +46,7 @@ __device__ __forceinline__ bf16x8 f_ldsr(unsigned addr) {
 // LINES: the W tile is staged with its rows permuted inside every 64-row group so that a lane's accumulators are 64 contiguous output bytes, and the
 // epilogue stores quad-contiguous (gemm_common.h, epi_lines_bf16): the bias epilogue.
 // ABL (OWL_TUNING builds, timing only -- results are wrong): bit 0 = no LDS-DMA requests after the prologue, bit 1 = fragments read once per tile;
-// 8 = requests issued but never waited for (timing only); 4 = (correct results) the stage's six requests spread over the second MFMA half, one behind each of its first six MFMAs, instead of a burst behind the barrier
+// 16 = (timing only) the same bytes requested as whole-line pieces (8 rows x 128 B); 8 = requests issued but never waited for (timing only); 4 = (correct results) the stage's six requests spread over the second MFMA half, one behind each of its first six MFMAs, instead of a burst behind the barrier
 template <int EPI, bool LINES, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void gemm_fr_kernel(GemmP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -94,6 +94,10 @@ __global__ __launch_bounds__(256, 2) void gemm_fr_kernel(GemmP p) {
                 const int c = (lane & 3) ^ ((r >> 2) & 3);
                 int64_t am = m0 + r; if (am >= p.a_rows) am = p.a_rows - 1;
                 a_voff[q] = (unsigned)(((am - m0) * p.lda + c * 8) * 2);
+                if constexpr ((ABL & 16) != 0) {       // (timing only: the same bytes as WHOLE-line requests, 8 rows x 128 B -- what a BK = 64 image would cost)
+                    const int r8 = 32 * wc + 8 * q + (lane >> 3);
+                    a_voff[q] = (unsigned)((r8 * p.lda + (lane & 7) * 8) * 2);
+                }
             }
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -103,6 +107,10 @@ __global__ __launch_bounds__(256, 2) void gemm_fr_kernel(GemmP p) {
                 const int rs = LINES ? ((r & ~63) | (((r >> 2) & 1) << 5) | (((r >> 5) & 1) << 4) | (((r >> 3) & 3) << 2) | (r & 3)) : r;
                 int64_t wn = n0 + rs; if (wn >= p.w_rows) wn = p.w_rows - 1;
                 w_voff[q] = (unsigned)(((wn - n0) * p.ldw + c * 8) * 2);
+                if constexpr ((ABL & 16) != 0) {
+                    const int r8 = 64 * wc + 8 * q + (lane >> 3);
+                    w_voff[q] = (unsigned)((r8 * p.ldw + (lane & 7) * 8) * 2);
+                }
             }
             if (has_bias) {
                 int64_t n = n0 + lane * 4; if (n + 4 > p.N) n = p.N - 4;
@@ -321,6 +329,8 @@ static int launch_fr_k(hipStream_t s, const GemmP& p, int nitems) {
             case 4: return launch_fr_abl<EPI, LINES, 4>(s, p, nitems);
             case 8: return launch_fr_abl<EPI, LINES, 8>(s, p, nitems);
             case 12: return launch_fr_abl<EPI, LINES, 12>(s, p, nitems);
+            case 16: return launch_fr_abl<EPI, LINES, 16>(s, p, nitems);
+            case 20: return launch_fr_abl<EPI, LINES, 20>(s, p, nitems);
             default: break;
         }
     }

@@ -25,7 +25,7 @@ for name, N, K, epi in (("QKV", 2304, 768, ops.EPI_BIAS_BF16), ("fc1", 3072, 768
     ref = torch.zeros_like(o); ops.gemm(epi, A, W, ref, bias=b, M=M, tile=256)
     _lib.call("owl_gemm_fr_ablate", 4); chk = torch.zeros_like(o); ops.gemm(epi, A, W, chk, bias=b, M=M, tile=5); torch.cuda.synchronize()
     print("   spread-request variant bits == reference:", bool(torch.equal(chk, ref)))
-    for abl, label in ((0, "fr"), (4, "fr requests spread over the MFMAs"), (8, "fr requests never waited for"), (12, "spread + never waited for"), (1, "fr no DMA"), (2, "fr no fragment reads"), (3, "fr neither")):
+    for abl, label in ((0, "fr"), (4, "fr requests spread over the MFMAs"), (8, "fr requests never waited for"), (16, "fr, same bytes as WHOLE-line requests"), (20, "whole-line + spread"), (1, "fr no DMA"), (2, "fr no fragment reads"), (3, "fr neither")):
         _lib.call("owl_gemm_fr_ablate", abl)
         res[label] = t(lambda: ops.gemm(epi, A, W, o, bias=b, M=M, tile=5))
     _lib.call("owl_gemm_fr_ablate", 0)
