@@ -14,17 +14,20 @@ import torch
 from . import _lib, ops
 
 
+def _grads_attached(model) -> bool:
+    """Every trainable parameter's .grad is its view of model.flat_grad."""
+    for n, off in model.flat_offsets.items():
+        g = model._byname[n].grad
+        if g is None or g.data_ptr() != model.flat_grad.data_ptr() + 4 * off:
+            return False
+    return True
+
+
 def _attach_grads(model):
     """Make every trainable parameter's .grad a view of model.flat_grad.  If an optimizer set them to
-    None (zero_grad(set_to_none=True)) the bucket is zeroed first -- None means zero."""
-    attached = True
-    for n, off in model.flat_offsets.items():
-        p = model._byname[n]
-        g = p.grad
-        if g is None or g.data_ptr() != model.flat_grad.data_ptr() + 4 * off:
-            attached = False
-            break
-    if attached:
+    None (zero_grad(set_to_none=True)) the bucket is zeroed first -- None means zero.  (Callers with a deferred tail order the
+    current stream behind it first: optim.FusedAdamW._attach.)"""
+    if _grads_attached(model):
         return
     keep = {}
     for n in model.flat_offsets:

@@ -9,7 +9,7 @@ ordinary f32 leaves); this class is the fast path.
 import torch
 
 from . import _lib, ops
-from .autograd import _attach_grads
+from .autograd import _attach_grads, _grads_attached
 
 
 class FusedAdamW:
@@ -31,9 +31,9 @@ class FusedAdamW:
         """Re-attach detached `.grad` views (nn.Module.zero_grad(set_to_none=True) drops them).  Attaching zero-fills the bucket on the CURRENT
         stream: behind a deferred tail that may still be reading / zeroing it."""
         m = self.model
-        if any(p.grad is None for p in m.parameters() if p.requires_grad):
+        if not _grads_attached(m):          # (detached, or foreign .grad tensors: re-attaching zero-fills / copies into the bucket)
             self._sync_tail()
-        _attach_grads(m)
+            _attach_grads(m)
 
     def _sync_tail(self):
         """Order the current stream behind everything the tail stream holds (deferred backward / all-reduce / AdamW / zeroing)."""
