@@ -111,6 +111,9 @@ def parse():
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="nccl = RCCL (the product path).  gloo: test-only -- lets several ranks share one visible GPU (tests/test_ddp_rccl_gpu.py runs the "
                          "multi-rank flow of this file on a 1-GPU box); never a benchmark result")
+    ap.add_argument("--inject-fault", choices=("mismatch", "raise", "hang"), default=None,
+                    help="test-only: make the deferred-tail phase of the multi-rank flow fail that way (tests/test_ddp_rccl_gpu.py checks that the in-line line survives)")
+    ap.add_argument("--watchdog-seconds", type=float, default=None, help="limit for the deferred-tail phase (default: max(120, 40 x the in-line measurement))")
     ap.add_argument("--no-kernel-events", action="store_true", help="no HIP events around the GEMM / attention launches (overhead A/B)")
     ap.add_argument("--encoder-streams", type=int, default=2,
                     help="sub-batches of the encoder forward / dX-only backward, one HIP stream each (OwlViT(encoder_streams=...)); 1 = one stream "
@@ -473,10 +476,16 @@ def main():
                 line_inline["config"]["schedule_check"] = f"deferred-tail phase did not finish within {int(limit)} s: in-line schedule reported"
                 print(json.dumps(line_inline), flush=True)
             os._exit(0)
-        limit = max(120.0, 40.0 * dt_in)
+        limit = args.watchdog_seconds if args.watchdog_seconds else max(120.0, 40.0 * dt_in)
         dog = threading.Timer(limit, bail); dog.daemon = True; dog.start()
         try:
             ok = preflight(args.targets)
+            if args.inject_fault == "mismatch":
+                ok = False
+            elif args.inject_fault == "raise":
+                raise RuntimeError("injected fault (test)")
+            elif args.inject_fault == "hang":
+                time.sleep(limit + 30.0)
             if ok:
                 set_schedule(True)
                 dt, slow = timed_run(args.targets, args.steps, args.warmup, False)
