@@ -84,19 +84,21 @@ def test_bench_multi_rank_flow_keeps_the_inline_line_when_the_deferred_phase_fai
 
 
 @pytest.mark.timeout(900)
-def test_bench_two_gloo_ranks_on_one_gpu_run_the_multi_rank_flow():
-    """bench.py's flow for more than one rank with two REAL ranks on the one visible GPU (gloo moves the bucket; `--backend gloo` is
-    test-only): in-line measurement first, pre-flight deferred == in-line bitwise, deferred measurement, replicas equal after both."""
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "4", "--warmup", "1",
-                        "--arch", "small", "--batch", "4", "--no-cpu-baseline", "--no-compare"], capture_output=True, text=True, env=_env(), timeout=800)
+@pytest.mark.parametrize("world,arch", [(2, "small"), (8, "tiny")])
+def test_bench_two_gloo_ranks_on_one_gpu_run_the_multi_rank_flow(world, arch):
+    """bench.py's flow for more than one rank with REAL ranks on the one visible GPU (gloo moves the bucket; `--backend gloo` is
+    test-only): in-line measurement first, pre-flight deferred == in-line bitwise, deferred measurement, replicas equal after both.  Two ranks on the
+    `small` config, and the driver's rank count -- eight -- on the `tiny` one."""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--backend", "gloo", "--steps", "4", "--warmup", "1",
+                        "--arch", arch, "--batch", "4", "--no-cpu-baseline", "--no-compare"], capture_output=True, text=True, env=_env(), timeout=800)
     assert r.returncode == 0, r.stderr[-3000:]
     out = _last_json(r.stdout)
-    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["backend"].startswith("gloo")
+    assert out["n_gpus"] == world and out["rccl_ranks"] == world and out["backend"].startswith("gloo")
     assert out["replicas_equal"] is True
     assert out["config"]["schedule_check"].startswith("pre-flight: 2 steps from one state, deferred tail == in-line bitwise"), out["config"]
     assert out["config"]["optimizer_schedule"].startswith("backward + all-reduce + AdamW on the tail stream")
-    assert out["config"]["global_batch"] == 8 and out["value"] > 0
+    assert out["config"]["global_batch"] == 4 * world and out["value"] > 0
 
 
 
