@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from owl_vit_object_detection_amd import ops
 M = 32 * 2312
-for name, N, K, epi in (("out-proj", 768, 768, ops.EPI_BIAS_BF16), ("fc2", 768, 3072, ops.EPI_BIAS_BF16), ("dX K=2304", 768, 2304, ops.EPI_BIAS_BF16), ("QKV", 2304, 768, ops.EPI_BIAS_BF16)):
+for name, N, K, epi in (("out-proj", 768, 768, ops.EPI_BIAS_BF16), ("fc2", 768, 3072, ops.EPI_BIAS_BF16), ("dX K=2304", 768, 2304, ops.EPI_BIAS_BF16), ("QKV", 2304, 768, ops.EPI_BIAS_BF16), ("fc1", 3072, 768, ops.EPI_QGELU_BF16)):
     torch.manual_seed(1)
     A = torch.randn(ops.pad_rows(M), K, device="cuda").bfloat16(); W = (torch.randn(N, K, device="cuda") * 0.05).bfloat16(); b = torch.randn(N, device="cuda")
     o = torch.zeros(ops.pad_rows(M), N, device="cuda", dtype=torch.bfloat16); ref = torch.zeros_like(o)
