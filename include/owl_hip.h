@@ -142,14 +142,13 @@ int owl_postprocess(void* stream, const float* boxes, const float* sims, void* w
 /* ---- device input pipeline (ref src/dataset.py:69-71: HF OwlViTImageProcessor = PIL bicubic resize -> x(1/255) ->
  * (x-mean)/std).  owl_bicubic_coeffs is HOST-side (all pointers host): Pillow's Resample.c tap tables for one axis,
  * bounds[2*out] = {first tap, tap count}, kk[out*ksize] 22-bit fixed point; kk_capacity in ints; ksize returned.
- * owl_preprocess_u8 (device pointers): src RGB u8 [H,W,3] -> horizontal pass into tmp u8 [H,out_w,3] -> vertical pass
+ * owl_preprocess_u8_batch (device pointers), per image: src RGB u8 [H,W,3] -> horizontal pass into tmp u8 [H,out_w,3] -> vertical pass
  * -> lut[3][256] (the reference's rescale+normalize value of each u8 level) -> out [3,out_h,out_w] f32 or bf16.      */
 int owl_bicubic_coeffs(int64_t in_size, int64_t out_size, int* bounds, int* kk, int64_t kk_capacity, int* ksize_out);
-/* batched form (one launch pair for a ragged batch): desc = n_images x 10 int64 in DEVICE memory, per image
+/* one launch pair for a ragged batch: desc = n_images x 10 int64 in DEVICE memory, per image
  * {src ptr, H, W, bounds_x ptr, kk_x ptr, ksize_x, bounds_y ptr, kk_y ptr, ksize_y, byte offset of its intermediate in tmp};
  * out [n_images,3,out_h,out_w]                                                                                        */
 int owl_preprocess_u8_batch(void* stream, const void* desc, int64_t n_images, int64_t max_h, unsigned char* tmp, const float* lut, void* out, int out_bf16, int64_t out_h, int64_t out_w);
-int owl_preprocess_u8(void* stream, const unsigned char* src_hwc, int64_t H, int64_t W, const int* bounds_x, const int* kk_x, int64_t ksize_x, const int* bounds_y, const int* kk_y, int64_t ksize_y, unsigned char* tmp, const float* lut, void* out, int out_bf16, int64_t out_h, int64_t out_w);
 
 /* ---- query-bank initialisation: the CLIP-style text tower run once by ref src/models.py:155-169 (HF5:603-663, 945-970).
  * Linear / LayerNorm layers reuse owl_gemm_nt_bf16 / owl_layernorm_fwd; these are the text-only pieces:
