@@ -17,9 +17,11 @@
 // The price: B is no longer shared by 256 rows -- 1.5x the LDS-DMA bytes per FLOP of the 256 x 256 tile on the CU's 64 B / clk L1 path.
 //
 // RESULT (profiles/r04_gemm_fr.md): bit-identical to every other kernel on the first run -- and 18-45 % SLOWER than what ships (QKV 303 vs 234 us, fc1 469 vs
-// 350, fc2 420 vs 290).  The ablation says why: without its LDS-DMA requests the same loop runs QKV in 214 us (21 % FASTER than the shipped kernel: the
-// epilogue does hide), the requests cost 106 us -- the K-loop is bound by the LDS-DMA path, both kernels move ~9 TB/s through it, and this one needs
-// 1.5x the bytes.  Not shipped; kept for OWL_TUNING builds (tile = 5, tools/gemm_fr_bench.py, tools/gemm_fr_ablate.py).
+// 350, fc2 420 vs 290).  The ablations say why: without its LDS-DMA requests the same loop runs 13-22 % FASTER than the shipped kernel (the epilogue does hide),
+// the requests cost 100-170 us whether they are waited for or not and however they are spread -- a request costs by the cache lines it touches, BK = 32 rows are
+// half lines, and at this kernel's 16 MFMAs per 6 requests the bare half-line stream reaches 9.4 TB/s / 900 TFLOP/s (tools/probe/lds_dma_rate.hip): the kernel
+// sits on that rate.  Re-pointed at whole lines (a BK = 64 image) it is still 15-20 % behind: 1.5x the staging bytes per FLOP cost more than the hidden epilogue
+// returns.  Not shipped; kept for OWL_TUNING builds (tile = 5, tools/gemm_fr_bench.py, tools/gemm_fr_ablate.py).
 #ifdef OWL_TUNING
 #include "gemm_common.h"
 #include <type_traits>
