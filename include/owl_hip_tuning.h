@@ -23,6 +23,7 @@ int owl_gemm_pp2_slots(int n);
 int owl_gemm_pp2_nostore(int on);
 int owl_gemm_pp2_block_width(int epi, int bw);   /* tile order of the two-phase GEMM: epi 0 bias / 1 quick-GELU; bw 0 = the launcher's rule, else column blocks of the largest divisor of tiles_n up to bw */
 int owl_gemm_pp2_lines(int on);              /* quad-contiguous epilogue stores: 0 off, 1 bias epilogue (default, = the product), 2 quick-GELU epilogue too */
+int owl_gemm_pp2_ablate(int a);              /* timing-only ablations of the shipped two-phase GEMM: bit 0 no LDS-DMA requests after the prologue, bit 1 fragments read once per tile, bit 2 no epilogue */
 int owl_gemm_pp2_trace(void* buf);
 /* ... which of workgroup 0's tiles is stamped (0 = its first; later tiles see the sustained clock and warm queues) */
 int owl_gemm_pp2_trace_tile(int n);

@@ -60,6 +60,14 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
         item = xcd_remap(blockIdx.x, nitems); item_end = item + 1; item_step = 1;
     }
     if (item >= item_end) return;
+    // (OWL_TUNING builds, timing only -- results are wrong: p.dbg bit 16 = no LDS-DMA requests after the prologue, bit 17 = fragments read in a tile's first
+    //  K-tile only, bit 18 = no epilogue; tools/gemm_pp2_ablate.py, profiles/r04_gemm_fr.md section 5)
+#ifdef OWL_TUNING
+    const bool abl_nodma = (p.dbg >> 16) & 1, abl_noread = (p.dbg >> 17) & 1, abl_noepi = (p.dbg >> 18) & 1;
+    bool abl_prologue = true;
+#else
+    constexpr bool abl_nodma = false, abl_noread = false, abl_noepi = false, abl_prologue = true;
+#endif
 
     // ---- two DMA cursors over the K-tiles in consumption order (across the persistent tile loop) ----------------------------
     int a_item = item, a_k = 0, a_buf = 0;                     // A pieces: one K-tile ahead
@@ -103,11 +111,13 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
             koff = ((int64_t)ch * p.S + ky) * p.S;
         }
         const unsigned char* g = (const unsigned char*)(a_base + koff);
+        if (!abl_nodma || abl_prologue) {
 #pragma unroll
         for (int h = 0; h < 2; h++)
 #pragma unroll
             for (int q = 0; q < 2; q++)
                 __builtin_amdgcn_global_load_lds(GPTR(g + a_voff[h][q]), LPTR(base + (h * 128 + (w * 2 + q) * 8) * 128), 16, 0, 0);
+        }
         a_buf ^= 1;
         if (++a_k == nk) { a_k = 0; a_item += item_step; }
     };
@@ -136,15 +146,18 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
         }
         unsigned char* base = lds + b_buf * Q_STAGE + Q_A_BYTES;
         const unsigned char* g = (const unsigned char*)(w_base + (int64_t)b_k * QBK);
+        int n_ops = 0;
+        if (!abl_nodma || abl_prologue) {
 #pragma unroll
         for (int h = 0; h < 2; h++)
 #pragma unroll
             for (int q = 0; q < 2; q++)
                 __builtin_amdgcn_global_load_lds(GPTR(g + w_voff[h][q]), LPTR(base + (h * 128 + (w * 2 + q) * 8) * 128), 16, 0, 0);
-        int n_ops = 4;
+        n_ops = 4;
         if (first && has_bias) {
             __builtin_amdgcn_global_load_lds(GPTR((const unsigned char*)b_base + b_voff), LPTR(lds + Q_BIAS_OFF + b_parity * 1024), 16, 0, 0);
             n_ops = 5;
+        }
         }
         b_buf ^= 1;
         if (++b_k == nk) { b_k = 0; b_item += item_step; b_parity ^= 1; }
@@ -159,6 +172,9 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
     stage_B(); stage_A(); stage_B();
     q_wait<4>();
     q_bar();
+#ifdef OWL_TUNING
+    abl_prologue = false;
+#endif
 
     int cur = 0, tile_parity = 0;
     const bool tr_wg = TRACE && blockIdx.x == 0;
@@ -231,11 +247,13 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
             };
             // ---- phase A ----
             stamp(0);
+            if (!abl_noread || kt == 0) {
 #pragma unroll
             for (int j = 0; j < 2; j++)
 #pragma unroll
                 for (int kc = 0; kc < 4; kc++) fb[j][kc] = *(const bf16x8*)(tb + b_base_off + j * 4096 + (((kc * 2 + hi) ^ b_swz) << 4));
             ld_a(0);
+            }
             if (a_early) a_early = false;             // (requested ahead of the previous tile's epilogue)
             else if (a_item < item_end) stage_A();    // A rows of the OTHER buffer: released by both groups' LOAD B of the previous K-tile
             stamp(1);
@@ -248,7 +266,7 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
             q_bar();
             stamp(5);
             // ---- phase B ----
-            ld_a(1);
+            if (!abl_noread || kt == 0) ld_a(1);
             int n_new = 0;
             if (b_item < item_end) n_new = stage_B();   // B rows of THIS buffer: both groups have run LOAD A
             stamp(6);
@@ -338,7 +356,15 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
             }
             }
         };
-        if (inner) run(std::false_type{}); else run(std::true_type{});
+        if (!abl_noepi) {
+            if (inner) run(std::false_type{}); else run(std::true_type{});
+        } else {
+            pending_stores = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) asm volatile("" :: "v"(acc[i][j]));
+        }
         tile_stamp(4);                               // (conversion done, every store of the tile issued)
         if (STAGGERED_EPI) q_bar();                  // the epilogue interval
         tile_stamp(3);
@@ -380,6 +406,8 @@ static int g_pp2_slots = 256;            // persistent grid size (tools/: does a
 extern "C" int owl_gemm_pp2_slots(int n) { g_pp2_slots = n; return 0; }
 static int g_pp2_bw[2] = {0, 0};         // column-block width of the tile order for the bias / quick-GELU epilogue: 0 = the launcher's rule, else the largest divisor of tiles_n up to this
 extern "C" int owl_gemm_pp2_block_width(int epi, int bw) { if (epi < 0 || epi > 1) return -1; g_pp2_bw[epi] = bw; return 0; }
+static int g_pp2_abl = 0;                // timing-only ablations: bit 0 no LDS-DMA requests after the prologue, bit 1 fragments read once per tile, bit 2 no epilogue
+extern "C" int owl_gemm_pp2_ablate(int a) { g_pp2_abl = a; return 0; }
 static int g_pp2_lines = 1;              // quad-contiguous stores: 0 off, 1 bias epilogue (the product's choice), 2 quick-GELU epilogue too
 extern "C" int owl_gemm_pp2_lines(int on) { g_pp2_lines = on; return 0; }
 #else
@@ -394,6 +422,9 @@ static int launch_pp2(hipStream_t s, GemmP p) {
     });
     p.tiles_m = (int)((p.M + QBM - 1) / QBM); p.tiles_n = (int)((p.N + QBN - 1) / QBN);
     p.dbg = 0;
+#ifdef OWL_TUNING
+    p.dbg = g_pp2_abl << 16;
+#endif
     // column-block width of the tile order (see `decode`): the largest divisor of tiles_n up to 4 for the forward epilogues (same-process A/B at
     // M = 73 984: QKV -3 %, half-batch fc1 -4 %, others +-0); the plain row-major order (one block) elsewhere -- dX through quick-GELU' measured
     // 5 % slower blocked (its A panel is then fetched three times, beside the 455 MB of pre-activations it already streams), and so did the
