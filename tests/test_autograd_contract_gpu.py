@@ -247,3 +247,37 @@ def test_evicted_then_rebuilt_workspace_cannot_collide_with_an_old_graph():
         _loss(crit, ps_old, lab[:1], pb_old, box[:1]).backward()
     _loss(crit, ps_new, lab[:1], pb_new, box[:1]).backward()     # the live graph still works
     assert torch.isfinite(model.flat_grad).all()
+
+
+def test_deferred_tail_survives_detached_grads_and_optimizer_state_io():
+    """with the deferred tail on, (a) `nn.Module.zero_grad()` (set_to_none=True) detaches the .grad views and the next
+    `FusedAdamW.zero_grad()` / `step()` re-attaches them -- zero-filling the bucket the tail stream may still be reading; (b) `FusedAdamW.state_dict()` /
+    `load_state_dict()` read / overwrite moments a deferred AdamW may still be writing.  Both order themselves behind the tail now: same bits as the
+    in-line schedule doing the same things."""
+    def train(overlap, steps=5):
+        cfg, model, img, lab, box, crit = _setup("small", 2)
+        opt = FusedAdamW(model, lr=1e-3, weight_decay=0.1, overlap=overlap)
+        g = torch.Generator(device="cpu").manual_seed(3)
+        imgs = [img] + [torch.randn(img.shape, generator=g).to(img.device, img.dtype) for _ in range(steps)]
+        hist, saved = [], None
+        for s in range(steps):
+            if s % 2 == 1:
+                model.zero_grad()                        # nn.Module's: .grad = None on every parameter
+            opt.zero_grad()
+            pb, _, ps, _ = model(imgs[s])
+            loss = _loss(crit, ps, lab, pb, box)
+            loss.backward()
+            opt.step()
+            if s == 1:                                   # right behind a (possibly deferred) step: the moments as of that step
+                saved = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in opt.state_dict().items()}
+            if s == 3:                                   # roll the optimizer back to step 1's state, right behind another step
+                opt.load_state_dict(saved)
+            hist.append(loss.detach())
+        model.finish()
+        torch.cuda.synchronize()
+        return model.flat_param.clone(), torch.stack(hist).cpu(), opt.exp_avg.clone(), saved["exp_avg"].clone()
+
+    p0, h0, m0, s0 = train(False)
+    p1, h1, m1, s1 = train(True)
+    assert torch.equal(s0, s1)                           # the snapshot taken behind a deferred step holds the finished moments
+    assert torch.equal(h0, h1) and torch.equal(m0, m1) and torch.equal(p0, p1)
