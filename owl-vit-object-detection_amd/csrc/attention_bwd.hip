@@ -429,13 +429,13 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnBwdP p) {
     }
 }
 
-extern "C" int owl_attention_bwd_workspace_bytes(int64_t B, int64_t H, int64_t Tp, int64_t* bytes) {
+OWL_API int owl_attention_bwd_workspace_bytes(int64_t B, int64_t H, int64_t Tp, int64_t* bytes) {
     OWL_CHECK_ARG(bytes && B > 0 && H > 0 && Tp > 0, "owl_attention_bwd_workspace_bytes: bad arguments");
     *bytes = B * H * Tp * (int64_t)sizeof(float);          // dvec_ws: one f32 per (image, head, token)
     return 0;
 }
 
-extern "C" int owl_attention_bwd_bf16(void* stream, const void* qkv, const void* dO, const void* O,
+OWL_API int owl_attention_bwd_bf16(void* stream, const void* qkv, const void* dO, const void* O,
                                       const float* lse, float* dvec_ws, void* dqkv, int64_t B, int64_t H, int64_t T, int64_t Tp,
                                       float scale) {
     OWL_CHECK_ARG(qkv && dO && O && lse && dvec_ws && dqkv, "owl_attention_bwd_bf16: null pointer");

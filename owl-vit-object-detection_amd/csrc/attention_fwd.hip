@@ -437,7 +437,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 1) void attn_fwd_kernel(Attn
 
 #ifdef OWL_TUNING   // tuning / race-hunting switches exist only in an OWL_TUNING build (include/owl_hip_tuning.h)
 static int g_attn_dbg = 0;
-extern "C" int owl_attention_debug(int flags) { g_attn_dbg = flags; return 0; }
+OWL_API int owl_attention_debug(int flags) { g_attn_dbg = flags; return 0; }
 #else
 static constexpr int g_attn_dbg = 0;
 #endif
@@ -509,7 +509,7 @@ static int attn_fwd_launch(void* stream, const void* q, const void* k, int64_t l
 }
 
 // fused attention forward, V read where the QKV GEMM leaves it: row-major [B*Tp, ld_qkv], head h at column h*64 of `v` (no V^T copy exists)
-extern "C" int owl_attention_fwd_vrow_bf16(void* stream, const void* q, const void* k, const void* v, int64_t ld_qkv, void* out,
+OWL_API int owl_attention_fwd_vrow_bf16(void* stream, const void* q, const void* k, const void* v, int64_t ld_qkv, void* out,
                                            int64_t ld_out, float* lse, int64_t B, int64_t H, int64_t T, int64_t Tp, float scale, int variant, int* slow_tiles) {
     return attn_fwd_launch(stream, q, k, ld_qkv, v, 1, 0, out, ld_out, lse, B, H, T, Tp, scale, variant, nullptr, slow_tiles);
 }
@@ -517,16 +517,16 @@ extern "C" int owl_attention_fwd_vrow_bf16(void* stream, const void* q, const vo
 #ifdef OWL_TUNING
 // tuning builds (include/owl_hip_tuning.h): the round-1 form with V^T per head as written by the transposing GEMM epilogue; the one-wave-per-SIMD / 12-wave
 // experiments (variant 3, 4, 5) with their redo scratch
-extern "C" int owl_attention_fwd_bf16(void* stream, const void* q, const void* k, int64_t ld_qk, const void* vt,
+OWL_API int owl_attention_fwd_bf16(void* stream, const void* q, const void* k, int64_t ld_qk, const void* vt,
                                       int64_t vt_img_stride, void* out, int64_t ld_out, float* lse, int64_t B,
                                       int64_t H, int64_t T, int64_t Tp, float scale) {
     return attn_fwd_launch(stream, q, k, ld_qk, vt, 0, vt_img_stride, out, ld_out, lse, B, H, T, Tp, scale, 0);
 }
-extern "C" int owl_attention_fwd_w64_bf16(void* stream, const void* q, const void* k, const void* v, int64_t ld_qkv, void* out,
+OWL_API int owl_attention_fwd_w64_bf16(void* stream, const void* q, const void* k, const void* v, int64_t ld_qkv, void* out,
                                           int64_t ld_out, float* lse, int64_t B, int64_t H, int64_t T, int64_t Tp, float scale, int variant, int* redo_ws) {
     return attn_fwd_launch(stream, q, k, ld_qkv, v, 1, 0, out, ld_out, lse, B, H, T, Tp, scale, variant, redo_ws, nullptr);
 }
-extern "C" int owl_attention_fwd_workspace_bytes(int64_t B, int64_t H, int64_t T, int64_t* bytes) {
+OWL_API int owl_attention_fwd_workspace_bytes(int64_t B, int64_t H, int64_t T, int64_t* bytes) {
     OWL_CHECK_ARG(bytes && B > 0 && H > 0 && T > 0, "owl_attention_fwd_workspace_bytes: bad arguments");
     *bytes = B * H * ((T - 1 + 255) / 256 + 1) * (int64_t)sizeof(int);
     return 0;

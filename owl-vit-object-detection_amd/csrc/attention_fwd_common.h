@@ -36,11 +36,11 @@ __device__ __forceinline__ int swap23(int m) { return (m & ~12) | ((m & 4) << 1)
 //               checks -- and removed again: -5..10 % / +0.5 %, profiles/r02_attn_fwd_experiments.md; the code is in history at 22922f6.)
 
 // Query row 0 of one (image, head) against all T keys, on the VALU.  8 lanes per key row (one 16-byte feature chunk each), so the 256
-// threads form 32 row groups; group g runs an online softmax over rows g, g + 32, ... in ONE pass over K and V (6 rows of each per batch,
-// the next batch's 12 loads issued before the current one is consumed: the workgroup is L2-latency-bound, nothing else), then the 32
+// threads form 32 row groups; group g runs an online softmax over rows g, g + 32, ... in ONE pass over K and V (5 rows of each per batch -- 6 spilled 5 VGPRs into scratch at the kernel's 168-register budget --,
+// the next batch's 10 loads issued before the current one is consumed: the workgroup is L2-latency-bound, nothing else), then the 32
 // partial states (m, l, O[64]) are merged through LDS in a fixed order: same bits every launch.
 __device__ __forceinline__ void attn_cls_row(const AttnFwdP& p, int b, int h, unsigned char* lds) {
-    constexpr int U = 6;
+    constexpr int U = 5;
     const int tid = threadIdx.x, sub = tid & 7, grp = tid >> 3;
     const int T = p.T;
     const int64_t ld = p.ld_qk;

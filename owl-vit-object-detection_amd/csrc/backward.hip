@@ -51,7 +51,7 @@ static int partials_reduce(hipStream_t s, const float* part, ReduceOuts outs, in
 
 // f32 elements of partial-sum scratch that serve every row-reduction entry below for activations of `groups` images x
 // `rows_per_group` rows x up to C columns (C = the widest reduced matrix, e.g. the MLP width for the fc1 bias gradient)
-extern "C" int owl_rowreduce_workspace_bytes(int64_t groups, int64_t rows_per_group, int64_t C, int64_t* bytes) {
+OWL_API int owl_rowreduce_workspace_bytes(int64_t groups, int64_t rows_per_group, int64_t C, int64_t* bytes) {
     OWL_CHECK_ARG(bytes && groups >= 1 && rows_per_group >= 1 && C >= 4, "owl_rowreduce_workspace_bytes: bad arguments");
     *bytes = groups * ((rows_per_group + 63) / 64) * 5 * C * (int64_t)sizeof(float);
     return 0;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     }
 }
 
-extern "C" int owl_layernorm_bwd(void* stream, const void* dy, int dy_bf16, const float* x, const float* stats, const float* gamma,
+OWL_API int owl_layernorm_bwd(void* stream, const void* dy, int dy_bf16, const float* x, const float* stats, const float* gamma,
                                  const float* dres, float* dx, float* dgamma, float* dbeta, int64_t rows, int64_t D, void* dx_bf16,
                                  float* partials, int64_t partials_floats, float* dx_colsum) {
     OWL_CHECK_ARG(dy && x && stats && gamma, "owl_layernorm_bwd: null pointer");
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(64) void cls_ln_bwd_kernel(const float* __restrict_
     }
 }
 
-extern "C" int owl_merge_ln_bwd(void* stream, const float* dfeats, const float* x, const float* cls_ln, const float* stats1,
+OWL_API int owl_merge_ln_bwd(void* stream, const float* dfeats, const float* x, const float* cls_ln, const float* stats1,
                                 const float* stats2, const float* g1, const float* b1, const float* g2, float* dx, float* dcls_ws,
                                 float* dg1, float* db1, float* dg2, float* db2, int64_t B, int64_t P, int64_t Tp, int64_t D,
                                 float* partials, int64_t partials_floats, void* dx_bf16, float* dx_colsum) {
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(64) void qhat_bwd_kernel(const float* __restrict__ 
     }
 }
 
-extern "C" int owl_class_sims_bwd(void* stream, const float* dsims, const float* sims, const unsigned char* argmax, const float* inv_norm,
+OWL_API int owl_class_sims_bwd(void* stream, const float* dsims, const float* sims, const unsigned char* argmax, const float* inv_norm,
                                   const float* e, const float* qhat32, void* de_bf16, void* g_bf16, void* e_bf16, int64_t rows,
                                   int64_t Dt, int64_t C) {
     OWL_CHECK_ARG(dsims && sims && argmax && inv_norm && e && qhat32 && de_bf16 && g_bf16 && e_bf16, "owl_class_sims_bwd: null pointer");
@@ -451,7 +451,7 @@ extern "C" int owl_class_sims_bwd(void* stream, const float* dsims, const float*
 }
 
 // dqueries += d(qhat -> Q) of dqhat (f32 [32, Dt], rows < nq used)
-extern "C" int owl_query_normalize_bwd(void* stream, const float* dqhat, const float* queries, float* dqueries, int64_t nq, int64_t Dt) {
+OWL_API int owl_query_normalize_bwd(void* stream, const float* dqhat, const float* queries, float* dqueries, int64_t nq, int64_t Dt) {
     OWL_CHECK_ARG(dqhat && queries && dqueries && nq >= 1 && nq <= 32, "owl_query_normalize_bwd: bad args");
     hipLaunchKernelGGL(qhat_bwd_kernel, dim3((unsigned)nq), dim3(64), 0, (hipStream_t)stream, dqhat, queries, dqueries, (int)Dt);
     OWL_LAUNCH_CHECK();
@@ -563,9 +563,9 @@ static int box_bwd_rpb(int64_t rows) {
     int64_t r = (rows + 511) / 512;
     return (int)(r < 8 ? 8 : (r > 64 ? 64 : r));
 }
-extern "C" int owl_box_final_bwd_blocks(int64_t rows) { const int rpb = box_bwd_rpb(rows); return (int)((rows + rpb - 1) / rpb); }
+OWL_API int owl_box_final_bwd_blocks(int64_t rows) { const int rpb = box_bwd_rpb(rows); return (int)((rows + rpb - 1) / rpb); }
 
-extern "C" int owl_box_final_bwd(void* stream, const float* dboxes, const float* sig, const void* h1_bf16, const void* u1_bf16,
+OWL_API int owl_box_final_bwd(void* stream, const float* dboxes, const float* sig, const void* h1_bf16, const void* u1_bf16,
                                  const float* w2, void* du1_bf16, float* partials, float* dw2_db2, int64_t rows, int64_t D, float* du1_colsum) {
     OWL_CHECK_ARG(dboxes && sig && h1_bf16 && u1_bf16 && w2 && du1_bf16 && partials && dw2_db2, "owl_box_final_bwd: null pointer");
     OWL_CHECK_ARG(D <= 1024 && D % 4 == 0, "owl_box_final_bwd: D <= 1024, D %% 4");
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(256) void transpose_colsum_kernel(const bf16_t* __r
     }
 }
 
-extern "C" int owl_transpose_colsum_bf16(void* stream, const void* in, int64_t ld_in, void* out_t, int64_t ld_out, float* colsum,
+OWL_API int owl_transpose_colsum_bf16(void* stream, const void* in, int64_t ld_in, void* out_t, int64_t ld_out, float* colsum,
                                          int64_t R, int64_t C, float* partials, int64_t partials_floats) {
     OWL_CHECK_ARG(in && (out_t || colsum) && R > 0 && C > 0, "owl_transpose_colsum_bf16: bad args");
     OWL_CHECK_ARG(ld_in % 8 == 0 && (!out_t || ld_out % 8 == 0), "owl_transpose_colsum_bf16: leading dimensions must be multiples of 8");
@@ -678,7 +678,7 @@ __global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict
     if (cc < C) colsum[(int64_t)blockIdx.y * C + cc] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
-extern "C" int owl_colsum_f32(void* stream, const float* in, float* colsum, int64_t R, int64_t C, float* partials, int64_t partials_floats) {
+OWL_API int owl_colsum_f32(void* stream, const float* in, float* colsum, int64_t R, int64_t C, float* partials, int64_t partials_floats) {
     OWL_CHECK_ARG(in && colsum && partials && R > 0 && C > 0 && C % 4 == 0, "owl_colsum_f32: bad arguments (C %% 4 == 0)");
     const int gy = (int)((R + 255) / 256);
     OWL_CHECK_ARG(partials_floats >= (int64_t)gy * C, "owl_colsum_f32: needs %lld floats of partial-sum scratch", (long long)gy * C);
@@ -715,7 +715,7 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
     }
 }
 
-extern "C" int owl_colsum_bf16(void* stream, const void* in_bf16, int64_t ld, float* colsum, int64_t R, int64_t C, float* partials, int64_t partials_floats) {
+OWL_API int owl_colsum_bf16(void* stream, const void* in_bf16, int64_t ld, float* colsum, int64_t R, int64_t C, float* partials, int64_t partials_floats) {
     OWL_CHECK_ARG(in_bf16 && colsum && partials && R > 0 && C > 0 && C % 8 == 0 && ld % 8 == 0, "owl_colsum_bf16: bad arguments (C, ld %% 8 == 0)");
     const int gy = (int)((R + 255) / 256);
     OWL_CHECK_ARG(partials_floats >= (int64_t)gy * C, "owl_colsum_bf16: needs %lld floats of partial-sum scratch", (long long)gy * C);

@@ -3,7 +3,8 @@
 set -e
 cd "$(dirname "$0")"
 ARCH=${OWL_ARCH:-gfx950}
-FLAGS="--offload-arch=${ARCH} -O3 -std=c++17 -fPIC -Wno-unused-value"
+# -fvisibility=hidden: only the OWL_API entry points (common.h) reach the dynamic symbol table
+FLAGS="--offload-arch=${ARCH} -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-value"
 # OWL_TUNING=1: also export the process-global tuning switches of include/owl_hip_tuning.h (tools/ only; never the shipped build)
 # Objects of a tuning build and of the shipped build live in different directories: staleness is judged by file times alone, so one shared
 # directory would let a default build re-use -DOWL_TUNING objects (and ship the process-global setters), or the reverse.
@@ -33,6 +34,6 @@ done
 fail=0
 for pid in $pids; do wait $pid || fail=1; done
 if [ $fail = 1 ]; then echo "build.sh: a HIP source failed to compile" >&2; exit 1; fi
-g++ -O2 -fPIC -std=c++17 -ffp-contract=off -c runtime.cpp -o $BUILD/runtime.o
-hipcc --offload-arch=${ARCH} -shared -fPIC -o ../libowlhip.so $objs $BUILD/runtime.o
+g++ -O2 -fPIC -fvisibility=hidden -std=c++17 -ffp-contract=off -c runtime.cpp -o $BUILD/runtime.o
+hipcc --offload-arch=${ARCH} -shared -fPIC -Wl,--version-script=libowlhip.map -o ../libowlhip.so $objs $BUILD/runtime.o
 echo "built $(cd .. && pwd)/libowlhip.so"

@@ -4,6 +4,10 @@
 #include <stdint.h>
 #include <stdio.h>
 
+// The shared library is linked with -fvisibility=hidden: the dynamic symbol table holds the C ABI of include/owl_hip.h (+ owl_hip_tuning.h in a tuning
+// build) and nothing else -- no kernel stubs, no C++ helpers (tests/test_abi.py).
+#define OWL_API extern "C" __attribute__((visibility("default")))
+
 typedef unsigned short bf16_t;  // raw bf16 bits
 typedef __attribute__((ext_vector_type(8))) short bf16x8;     // MFMA A/B fragment (8 bf16, 4 VGPR)
 typedef __attribute__((ext_vector_type(4))) float f32x4;

@@ -27,11 +27,11 @@ static constexpr int BK = 64;
 // prototypes in include/owl_hip_tuning.h), where tools/ uses them for A/B experiments.
 #ifdef OWL_TUNING
 static int g_persistent = 1;      // persistent scheduling (one workgroup per CU walks tiles with cross-tile prefetch)
-extern "C" int owl_gemm_set_persistent(int on) { g_persistent = on; return 0; }
+OWL_API int owl_gemm_set_persistent(int on) { g_persistent = on; return 0; }
 static int g_debug_slots = 0;     // override the persistent grid size
-extern "C" int owl_gemm_debug_slots(int n) { g_debug_slots = n; return 0; }
+OWL_API int owl_gemm_debug_slots(int n) { g_debug_slots = n; return 0; }
 static int g_debug_nostore = 0;   // 1: run the main loop but skip every epilogue store; 8: ping-pong trace run
-extern "C" int owl_gemm_debug_nostore(int on) { g_debug_nostore = on; return 0; }
+OWL_API int owl_gemm_debug_nostore(int on) { g_debug_nostore = on; return 0; }
 #else
 static constexpr int g_persistent = 1, g_debug_slots = 0, g_debug_nostore = 0;
 #endif
@@ -313,7 +313,7 @@ static int launch(hipStream_t s, const GemmP& p, int splits, int g_force_tile = 
     return launch_cfg<EPI, 128, 128, 64, 64>(s, p, splits);
 }
 
-extern "C" int owl_gemm_nt_bf16(void* stream, int epi, const void* A, int64_t lda, int64_t a_rows, const void* W,
+OWL_API int owl_gemm_nt_bf16(void* stream, int epi, const void* A, int64_t lda, int64_t a_rows, const void* W,
                                 int64_t ldw, int64_t w_rows, const float* bias, void* out, int64_t ldo,
                                 const float* resid, void* aux, int64_t ld_aux, int64_t M, int64_t N, int64_t K,
                                 float alpha, int splits, int64_t Tp, int tile) {
@@ -435,7 +435,7 @@ extern "C" int owl_gemm_nt_bf16(void* stream, int epi, const void* A, int64_t ld
 }
 
 // number of split-K slabs the call above will actually write for (K, splits): callers size the slab buffer with it
-extern "C" int owl_gemm_effective_splits(int64_t K, int splits) {
+OWL_API int owl_gemm_effective_splits(int64_t K, int splits) {
     const int nk = (int)(K / BK);
     if (splits > nk) splits = nk;
     if (splits < 1) splits = 1;
@@ -443,7 +443,7 @@ extern "C" int owl_gemm_effective_splits(int64_t K, int splits) {
     return (nk + per - 1) / per;
 }
 
-extern "C" int owl_gemm_slab_workspace_bytes(int64_t M, int64_t ldo, int64_t K, int splits, int64_t* bytes) {
+OWL_API int owl_gemm_slab_workspace_bytes(int64_t M, int64_t ldo, int64_t K, int splits, int64_t* bytes) {
     OWL_CHECK_ARG(bytes && M > 0 && ldo > 0 && K >= BK, "owl_gemm_slab_workspace_bytes: bad arguments");
     *bytes = (int64_t)owl_gemm_effective_splits(K, splits) * M * ldo * (int64_t)sizeof(float);
     return 0;
@@ -476,7 +476,7 @@ int owl_slab_reduce_impl(hipStream_t s, const float* slabs, float* out, int64_t 
     return 0;
 }
 
-extern "C" int owl_slab_reduce(void* stream, const float* slabs, float* out, int64_t n, int64_t slab_stride, int nsplit, int accumulate) {
+OWL_API int owl_slab_reduce(void* stream, const float* slabs, float* out, int64_t n, int64_t slab_stride, int nsplit, int accumulate) {
     OWL_CHECK_ARG(slabs && out && n > 0 && n % 4 == 0 && nsplit >= 1, "owl_slab_reduce: bad args (n %% 4 == 0)");
     return owl_slab_reduce_impl((hipStream_t)stream, slabs, out, n, slab_stride, nsplit, accumulate);
 }
@@ -503,12 +503,13 @@ __global__ __launch_bounds__(256) void im2row_kernel(const bf16_t* __restrict__ 
 // Power-of-two patch sizes: im2row-free (the A loader gathers 16-byte runs of patch rows straight from the image).
 // Otherwise: `scratch` (bf16 [B*P (row-padded to 128), Kpad]) receives an explicit im2row and w_pe must be [D, Kpad]
 // with zero columns beyond 3*ps*ps; Kpad = 3*ps*ps rounded up to 64.
-extern "C" int owl_patch_embed_bf16(void* stream, const void* image_bf16, const void* w_pe, const float* pos,
+OWL_API int owl_patch_embed_bf16(void* stream, const void* image_bf16, const void* w_pe, const float* pos,
                                     float* x_out, void* scratch, int64_t B, int64_t S, int64_t ps, int64_t D, int64_t Tp, int tile) {
     OWL_CHECK_ARG(image_bf16 && w_pe && pos && x_out, "owl_patch_embed_bf16: null pointer");
     OWL_CHECK_ARG(S % ps == 0, "owl_patch_embed_bf16: image side must be a multiple of the patch size");
     const int64_t G = S / ps, P = G * G, K = 3 * ps * ps;
     OWL_CHECK_ARG(D % 8 == 0 && Tp >= P + 1, "owl_patch_embed_bf16: D %% 8, Tp");
+    OWL_CHECK_ARG(B * 3 * S * S * 2 < (1LL << 32) && B * P < (1LL << 31), "owl_patch_embed_bf16: image batch beyond 4 GiB (32-bit gather offsets)");
     const bool fused = ps >= 8 && (ps & (ps - 1)) == 0 && K % BK == 0;
     GemmP p{};
     p.bias = nullptr; p.out = x_out; p.ldo = D; p.M = B * P; p.N = D; p.alpha = 1.f;

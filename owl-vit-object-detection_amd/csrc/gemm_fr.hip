@@ -307,11 +307,11 @@ __global__ __launch_bounds__(256, 2) void gemm_fr_kernel(GemmP p) {
 }
 
 static int g_fr_abl = 0;
-extern "C" int owl_gemm_fr_ablate(int a) { g_fr_abl = a; return 0; }
+OWL_API int owl_gemm_fr_ablate(int a) { g_fr_abl = a; return 0; }
 static int g_fr_slots = 512;             // persistent grid size
-extern "C" int owl_gemm_fr_slots(int n) { g_fr_slots = n; return 0; }
+OWL_API int owl_gemm_fr_slots(int n) { g_fr_slots = n; return 0; }
 static int g_fr_bw[2] = {0, 0};
-extern "C" int owl_gemm_fr_block_width(int epi, int bw) { if (epi < 0 || epi > 1) return -1; g_fr_bw[epi] = bw; return 0; }
+OWL_API int owl_gemm_fr_block_width(int epi, int bw) { if (epi < 0 || epi > 1) return -1; g_fr_bw[epi] = bw; return 0; }
 
 template <int EPI, bool LINES, int ABL>
 static int launch_fr_abl(hipStream_t s, const GemmP& p, int nitems) {

@@ -94,10 +94,12 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
                     const int c = (lane & 7) ^ ((r >> 1) & 7);
                     int64_t am = m0 + r; if (am >= p.a_rows) am = p.a_rows - 1;
                     if constexpr (GATHER) {
-                        const int64_t b = am / p.P, pp = am - b * p.P;
-                        const int64_t py = pp / p.G, px = pp - py * p.G;
-                        const int ky = (c * 8) >> p.ps_log2, kx = (c * 8) & ((1 << p.ps_log2) - 1);
-                        a_voff[h][q] = (unsigned)(((((b * 3) * p.S + py * p.ps + ky) * p.S) + px * p.ps + kx) * 2);
+                        // (32-bit arithmetic: the 64-bit divisions here cost 14 spilled VGPRs inside the K loop; the host checks that the image fits 2^31 bytes)
+                        const unsigned P32 = (unsigned)p.P, G32 = (unsigned)p.G, S32 = (unsigned)p.S, ps32 = (unsigned)p.ps;
+                        const unsigned b = (unsigned)am / P32, pp = (unsigned)am - b * P32;
+                        const unsigned py = pp / G32, px = pp - py * G32;
+                        const unsigned ky = (unsigned)(c * 8) >> p.ps_log2, kx = (unsigned)(c * 8) & ((1u << p.ps_log2) - 1u);
+                        a_voff[h][q] = ((((b * 3u) * S32 + py * ps32 + ky) * S32) + px * ps32 + kx) * 2u;
                     } else {
                         a_voff[h][q] = (unsigned)(((am - m0) * p.lda + c * 8) * 2);
                     }
@@ -312,11 +314,13 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
         auto run = [&](auto guard_tag) {
             constexpr bool G = decltype(guard_tag)::value;
             estamp(0);
-            constexpr bool AUX_IN = (EPI == EPI_DQGELU_BF16);     // saved pre-activations of all eight 32x32 tiles requested up front (gemm_pp.hip)
-            uint4 auxr[AUX_IN ? 4 : 1][2][2];
+            // saved pre-activations: a rolling two-row-block prefetch (row blocks i and i + 1 in flight while block i - 1 is converted).  All eight 32 x 32
+            // tiles requested up front (64 registers beside the 128 accumulators) spilled 8 VGPRs into scratch.
+            constexpr bool AUX_IN = (EPI == EPI_DQGELU_BF16);
+            uint4 auxr[AUX_IN ? 2 : 1][2][2];
             if constexpr (AUX_IN) {
 #pragma unroll
-                for (int i = 0; i < 4; i++)
+                for (int i = 0; i < 2; i++)
 #pragma unroll
                     for (int j = 0; j < 2; j++) epi_aux_load<G>(p, cm0 + grp * 128 + i * 32, cn0 + wc * 64 + j * 32, lane, auxr[i][j]);
             }
@@ -347,7 +351,8 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
                         epi_tile_patch<G>(p, acc[i][j], mt, nt, lane);
                     } else {
                         uint4 c0, c1;
-                        epi_tile_bf16<EPI, G>(p, acc[i][j], mt, nt, lane, c0, c1, lbias + j * 32, AUX_IN ? auxr[AUX_IN ? i : 0][j] : nullptr, BIAS_PRE ? bq[j] : nullptr);
+                        epi_tile_bf16<EPI, G>(p, acc[i][j], mt, nt, lane, c0, c1, lbias + j * 32, AUX_IN ? auxr[AUX_IN ? (i & 1) : 0][j] : nullptr, BIAS_PRE ? bq[j] : nullptr);
+                        if constexpr (AUX_IN) { if (i + 2 < 4) epi_aux_load<G>(p, mt + 64, nt, lane, auxr[i & 1][j]); }    // row block i + 2 into the slot just consumed
                         epi_store_chunk<EPI, G>(p, c0, mt, nt, 0, lane);
                         epi_store_chunk<EPI, G>(p, c1, mt, nt, 1, lane);
                     }
@@ -401,15 +406,15 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
 
 #ifdef OWL_TUNING
 static int g_pp2_nostore = 0;            // 1: every epilogue store skipped (upper bound on what the store path costs)
-extern "C" int owl_gemm_pp2_nostore(int on) { g_pp2_nostore = on; return 0; }
+OWL_API int owl_gemm_pp2_nostore(int on) { g_pp2_nostore = on; return 0; }
 static int g_pp2_slots = 256;            // persistent grid size (tools/: does a GEMM on half the CUs beside the other stream's kernel pay?)
-extern "C" int owl_gemm_pp2_slots(int n) { g_pp2_slots = n; return 0; }
+OWL_API int owl_gemm_pp2_slots(int n) { g_pp2_slots = n; return 0; }
 static int g_pp2_bw[2] = {0, 0};         // column-block width of the tile order for the bias / quick-GELU epilogue: 0 = the launcher's rule, else the largest divisor of tiles_n up to this
-extern "C" int owl_gemm_pp2_block_width(int epi, int bw) { if (epi < 0 || epi > 1) return -1; g_pp2_bw[epi] = bw; return 0; }
+OWL_API int owl_gemm_pp2_block_width(int epi, int bw) { if (epi < 0 || epi > 1) return -1; g_pp2_bw[epi] = bw; return 0; }
 static int g_pp2_abl = 0;                // timing-only ablations: bit 0 no LDS-DMA requests after the prologue, bit 1 fragments read once per tile, bit 2 no epilogue
-extern "C" int owl_gemm_pp2_ablate(int a) { g_pp2_abl = a; return 0; }
+OWL_API int owl_gemm_pp2_ablate(int a) { g_pp2_abl = a; return 0; }
 static int g_pp2_lines = 1;              // quad-contiguous stores: 0 off, 1 bias epilogue (the product's choice), 2 quick-GELU epilogue too
-extern "C" int owl_gemm_pp2_lines(int on) { g_pp2_lines = on; return 0; }
+OWL_API int owl_gemm_pp2_lines(int on) { g_pp2_lines = on; return 0; }
 #else
 static constexpr int g_pp2_slots = 256;
 #endif
@@ -479,9 +484,9 @@ static int launch_pp2(hipStream_t s, GemmP p) {
 #ifdef OWL_TUNING
 static void* g_pp2_trace = nullptr;      // device buffer of 128 x u64: the next bias-epilogue launch runs the stamped kernel (tools/pp2_trace.py)
 static int g_pp2_trace_tile = 0, g_pp2_trace_kt = 4;
-extern "C" int owl_gemm_pp2_trace(void* buf) { g_pp2_trace = buf; return 0; }
-extern "C" int owl_gemm_pp2_trace_tile(int n) { g_pp2_trace_tile = n; return 0; }
-extern "C" int owl_gemm_pp2_trace_ktile(int n) { g_pp2_trace_kt = n; return 0; }
+OWL_API int owl_gemm_pp2_trace(void* buf) { g_pp2_trace = buf; return 0; }
+OWL_API int owl_gemm_pp2_trace_tile(int n) { g_pp2_trace_tile = n; return 0; }
+OWL_API int owl_gemm_pp2_trace_ktile(int n) { g_pp2_trace_kt = n; return 0; }
 #endif
 
 // called from gemm.hip's dispatcher; returns 1 if this variant does not handle `epi`

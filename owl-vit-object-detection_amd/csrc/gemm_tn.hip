@@ -345,7 +345,7 @@ __global__ __launch_bounds__(512) void gemm_tn_pp_kernel(TnP p) {
     }
 }
 
-extern "C" int owl_gemm_tn_slab_workspace_bytes(int64_t M, int64_t N, int64_t K, int splits, int64_t* bytes) {
+OWL_API int owl_gemm_tn_slab_workspace_bytes(int64_t M, int64_t N, int64_t K, int splits, int64_t* bytes) {
     OWL_CHECK_ARG(bytes && M > 0 && N > 0 && K > 0 && splits >= 1, "owl_gemm_tn_slab_workspace_bytes: bad arguments");
     const int nk = (int)((M + TBK - 1) / TBK);
     if (splits > nk) splits = nk;
@@ -354,7 +354,7 @@ extern "C" int owl_gemm_tn_slab_workspace_bytes(int64_t M, int64_t N, int64_t K,
     return 0;
 }
 
-extern "C" int owl_gemm_tn_slab_bf16(void* stream, const void* dY, int64_t ldy, const void* X, int64_t ldx, const void* zero_row,
+OWL_API int owl_gemm_tn_slab_bf16(void* stream, const void* dY, int64_t ldy, const void* X, int64_t ldx, const void* zero_row,
                                      float* slab, int64_t M, int64_t N, int64_t K, int splits, int* splits_used, int variant) {
     OWL_CHECK_ARG(dY && X && zero_row && slab && splits_used, "owl_gemm_tn_slab_bf16: null pointer");
     OWL_CHECK_ARG(M > 0 && N >= 8 && K >= 8 && N % 8 == 0 && K % 8 == 0, "owl_gemm_tn_slab_bf16: bad M=%lld N=%lld K=%lld (N, K %% 8 == 0)", (long long)M, (long long)N, (long long)K);

@@ -21,7 +21,7 @@ __global__ __launch_bounds__(64) void qhat_kernel(const float* __restrict__ q, f
     for (int k = lane; k < Dt; k += 64) qhat[(int64_t)j * Dt + k] = q[(int64_t)j * Dt + k] / n + 1e-6f;
 }
 
-extern "C" int owl_query_normalize(void* stream, const float* queries, float* qhat32, float* qnorm, int64_t nq, int64_t Dt) {
+OWL_API int owl_query_normalize(void* stream, const float* queries, float* qhat32, float* qnorm, int64_t nq, int64_t Dt) {
     OWL_CHECK_ARG(queries && qhat32 && nq >= 1 && nq <= 32, "owl_query_normalize: need 1 <= queries <= 32 (got %lld)", (long long)nq);
     hipLaunchKernelGGL(qhat_kernel, dim3(32), dim3(64), 0, (hipStream_t)stream, queries, qhat32, qnorm, (int)nq, (int)Dt);
     OWL_LAUNCH_CHECK();
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void class_sims_kernel(const float* __restrict
     }
 }
 
-extern "C" int owl_class_sims_fwd(void* stream, const float* e, const float* qhat32, float* sims, unsigned char* argmax,
+OWL_API int owl_class_sims_fwd(void* stream, const float* e, const float* qhat32, float* sims, unsigned char* argmax,
                                   float* inv_norm, int64_t rows, int64_t Dt, int64_t C) {
     OWL_CHECK_ARG(e && qhat32 && sims, "owl_class_sims_fwd: null pointer");
     OWL_CHECK_ARG(Dt % 64 == 0 && 3 * C <= 32 && C >= 1, "owl_class_sims_fwd: Dt %% 64 == 0 and 3*C <= 32 required (Dt=%lld C=%lld)", (long long)Dt, (long long)C);
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void box_final_kernel(const bf16_t* __restrict
     }
 }
 
-extern "C" int owl_box_final_fwd(void* stream, const void* h_bf16, const float* w2, const float* b2, const float* box_bias,
+OWL_API int owl_box_final_fwd(void* stream, const void* h_bf16, const float* w2, const float* b2, const float* box_bias,
                                  float* boxes, float* sig_out, int64_t rows, int64_t P, int64_t D) {
     OWL_CHECK_ARG(h_bf16 && w2 && b2 && box_bias && boxes, "owl_box_final_fwd: null pointer");
     OWL_CHECK_ARG(D % 8 == 0, "owl_box_final_fwd: D %% 8");

@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void box_pairwise_kernel(const float* __restri
     out[i] = iou; out[N * M + i] = uni; out[2 * N * M + i] = g;
 }
 
-extern "C" int owl_box_pairwise(void* stream, const float* boxes1, const float* boxes2, float* out3, int64_t N, int64_t M) {
+OWL_API int owl_box_pairwise(void* stream, const float* boxes1, const float* boxes2, float* out3, int64_t N, int64_t M) {
     OWL_CHECK_ARG(boxes1 && boxes2 && out3, "owl_box_pairwise: null pointer");
     if (N * M == 0) return 0;
     hipLaunchKernelGGL(box_pairwise_kernel, dim3((unsigned)((N * M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, boxes1, boxes2, out3, N, M);
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void pack_targets_kernel(const int64_t* __rest
     }
 }
 
-extern "C" int owl_pack_targets(void* stream, const int64_t* labels_cat, const float* boxes_cat, const int* offsets, int64_t* labels,
+OWL_API int owl_pack_targets(void* stream, const int64_t* labels_cat, const float* boxes_cat, const int* offsets, int64_t* labels,
                                 float* boxes, int* counts, int64_t B, int64_t Nmax) {
     OWL_CHECK_ARG(labels_cat && boxes_cat && offsets && labels && boxes && counts, "owl_pack_targets: null pointer");
     OWL_CHECK_ARG(B >= 1 && Nmax >= 1, "owl_pack_targets: need B >= 1 and Nmax >= 1");
@@ -417,7 +417,7 @@ extern "C" int owl_pack_targets(void* stream, const int64_t* labels_cat, const f
 }
 
 // ---------------------------------------------------------------------------------------------------
-extern "C" int owl_match_cost(void* stream, const float* sims, const float* boxes, const int64_t* labels, const float* tgt_boxes,
+OWL_API int owl_match_cost(void* stream, const float* sims, const float* boxes, const int64_t* labels, const float* tgt_boxes,
                               const int* counts, float* costT, int64_t B, int64_t P, int64_t C, int64_t Nmax, float w_class, float w_bbox, float w_giou) {
     OWL_CHECK_ARG(sims && boxes && labels && tgt_boxes && counts && costT, "owl_match_cost: null pointer");
     hipLaunchKernelGGL(match_cost_kernel, dim3((unsigned)((P + 255) / 256), (unsigned)B), dim3(256), 0, (hipStream_t)stream,
@@ -426,7 +426,7 @@ extern "C" int owl_match_cost(void* stream, const float* sims, const float* boxe
     return 0;
 }
 
-extern "C" int owl_hungarian(void* stream, const float* costT, const int64_t* labels, const int* counts, int64_t* pred_idx,
+OWL_API int owl_hungarian(void* stream, const float* costT, const int64_t* labels, const int* counts, int64_t* pred_idx,
                              int64_t* tgt_idx, int64_t* target_classes, int64_t B, int64_t P, int64_t Nmax, int64_t bg) {
     OWL_CHECK_ARG(costT && labels && counts && pred_idx && tgt_idx && target_classes, "owl_hungarian: null pointer");
     OWL_CHECK_ARG(Nmax >= 1 && Nmax <= P, "owl_hungarian: need 1 <= Nmax <= P (more targets than predictions is unsupported)");
@@ -441,7 +441,7 @@ extern "C" int owl_hungarian(void* stream, const float* costT, const int64_t* la
     return 0;
 }
 
-extern "C" int owl_spread_labels(void* stream, const float* boxes, int64_t* target_classes, int64_t B, int64_t P, int64_t bg, float thr) {
+OWL_API int owl_spread_labels(void* stream, const float* boxes, int64_t* target_classes, int64_t B, int64_t P, int64_t bg, float thr) {
     OWL_CHECK_ARG(boxes && target_classes, "owl_spread_labels: null pointer");
     const size_t sh = (size_t)P * 20;
     OWL_CHECK_ARG(sh <= 156 * 1024 && P <= 8192, "owl_spread_labels: P too large");
@@ -452,7 +452,7 @@ extern "C" int owl_spread_labels(void* stream, const float* boxes, int64_t* targ
     return 0;
 }
 
-extern "C" int owl_push_pull_loss(void* stream, const float* sims, const float* boxes, const int64_t* target_classes,
+OWL_API int owl_push_pull_loss(void* stream, const float* sims, const float* boxes, const int64_t* target_classes,
                                   const float* scales, const float* tgt_boxes, const int64_t* pred_idx, const int64_t* tgt_idx,
                                   const int* counts, float* per_image, float* losses, float* dsims, float* dl1, float* dgiou,
                                   int64_t B, int64_t P, int64_t C, int64_t Nmax, int64_t bg) {
@@ -468,7 +468,7 @@ extern "C" int owl_push_pull_loss(void* stream, const float* sims, const float* 
     return 0;
 }
 
-extern "C" int owl_push_pull_loss_bwd(void* stream, const float* g4, const int64_t* target_classes, const float* dsims, const float* dl1,
+OWL_API int owl_push_pull_loss_bwd(void* stream, const float* g4, const int64_t* target_classes, const float* dsims, const float* dl1,
                                       const float* dgiou, float* out_sims, float* out_boxes, int64_t B, int64_t P, int64_t C, int64_t bg) {
     OWL_CHECK_ARG(g4 && target_classes && dsims && dl1 && dgiou && out_sims && out_boxes, "owl_push_pull_loss_bwd: null pointer");
     const int64_t rows = B * P;

@@ -15,7 +15,7 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ in,
     }
 }
 
-extern "C" int owl_cast_f32_bf16(void* stream, const float* in, void* out, int64_t n) {
+OWL_API int owl_cast_f32_bf16(void* stream, const float* in, void* out, int64_t n) {
     OWL_CHECK_ARG(in && out && n >= 0, "owl_cast_f32_bf16: null pointer");
     OWL_CHECK_ARG(((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0, "owl_cast_f32_bf16: pointers must be 16-byte aligned");
     if (n == 0) return 0;
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
     }
 }
 
-extern "C" int owl_transpose_bf16(void* stream, const void* in, int64_t ld_in, void* out, int64_t ld_out, int64_t R, int64_t C) {
+OWL_API int owl_transpose_bf16(void* stream, const void* in, int64_t ld_in, void* out, int64_t ld_out, int64_t R, int64_t C) {
     OWL_CHECK_ARG(in && out && R > 0 && C > 0, "owl_transpose_bf16: bad args");
     dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64));
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out, R, C);

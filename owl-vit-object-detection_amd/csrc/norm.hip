@@ -87,14 +87,14 @@ static int ln_launch(void* stream, const float* x, const void* delta, float* x_o
     return 0;
 }
 
-extern "C" int owl_layernorm_fwd(void* stream, const float* x, const float* gamma, const float* beta, void* out,
+OWL_API int owl_layernorm_fwd(void* stream, const float* x, const float* gamma, const float* beta, void* out,
                                  int out_bf16, float* stats, int64_t rows, int64_t D, float eps) {
     return ln_launch(stream, x, nullptr, nullptr, gamma, beta, out, out_bf16, stats, rows, D, eps);
 }
 
 // s = x + delta (+ delta2), bf16 branch outputs;  out = LN(s);  x_out = s unless x_out is null (the sum is then re-formed, from the
 // same operands in the same order, by the next call -- saves writing 4 bytes per element where nobody else reads the sum)
-extern "C" int owl_add_layernorm_fwd(void* stream, const float* x, const void* delta_bf16, float* x_out, const float* gamma,
+OWL_API int owl_add_layernorm_fwd(void* stream, const float* x, const void* delta_bf16, float* x_out, const float* gamma,
                                      const float* beta, void* out, int out_bf16, float* stats, int64_t rows, int64_t D, float eps,
                                      const void* delta2_bf16) {
     OWL_CHECK_ARG(delta_bf16, "owl_add_layernorm_fwd: null delta");
@@ -110,7 +110,7 @@ __global__ void cls_rows_kernel(float* x, const float* cls, const float* pos, in
     x[b * Tp * D + d] = cls[d] + pos[d];
 }
 
-extern "C" int owl_cls_rows(void* stream, float* x, const float* cls, const float* pos, int64_t B, int64_t Tp, int64_t D) {
+OWL_API int owl_cls_rows(void* stream, float* x, const float* cls, const float* pos, int64_t B, int64_t Tp, int64_t D) {
     OWL_CHECK_ARG(x && cls && pos, "owl_cls_rows: null pointer");
     hipLaunchKernelGGL(cls_rows_kernel, dim3((unsigned)((B * D + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, cls, pos, B, Tp, (int)D);
     OWL_LAUNCH_CHECK();
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(64) void cls_ln_kernel(const float* x, const bf16_t
     }
 }
 
-extern "C" int owl_merge_ln_fwd(void* stream, const float* x, const void* delta_bf16, float* x_out, const float* g1, const float* b1,
+OWL_API int owl_merge_ln_fwd(void* stream, const float* x, const void* delta_bf16, float* x_out, const float* g1, const float* b1,
                                 const float* g2, const float* b2, float* cls_ln, void* feats_bf16, float* stats1, float* stats2,
                                 int64_t B, int64_t P, int64_t Tp, int64_t D, float eps) {
     OWL_CHECK_ARG(x && g1 && b1 && g2 && b2 && cls_ln && feats_bf16, "owl_merge_ln_fwd: null pointer");

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
 }
 
-extern "C" int owl_adamw_step(void* stream, float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
+OWL_API int owl_adamw_step(void* stream, float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
                               float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale) {
     OWL_CHECK_ARG(p && g && m && v && n > 0 && n % 4 == 0 && step >= 1, "owl_adamw_step: bad args (n %% 4 == 0, step >= 1)");
     const float bc1 = 1.f - powf(beta1, (float)step);

@@ -185,13 +185,13 @@ static int64_t pp_ws_bytes(int64_t B, int64_t P) {
     return B * P * (16 + 4 + 4 + 4) + 256 + B * P * W * 8 + B * 4 + B * 4 + 256;
 }
 
-extern "C" int owl_postprocess_workspace(int64_t B, int64_t P, int64_t* bytes) {
+OWL_API int owl_postprocess_workspace(int64_t B, int64_t P, int64_t* bytes) {
     OWL_CHECK_ARG(B > 0 && P > 0 && P <= 8192 && bytes, "owl_postprocess_workspace: need B > 0, 0 < P <= 8192 (B=%lld P=%lld)", (long long)B, (long long)P);
     *bytes = pp_ws_bytes(B, P);
     return 0;
 }
 
-extern "C" int owl_postprocess(void* stream, const float* boxes, const float* sims, void* workspace, int64_t ws_bytes,
+OWL_API int owl_postprocess(void* stream, const float* boxes, const float* sims, void* workspace, int64_t ws_bytes,
                                float* out_boxes, float* out_scores, int64_t* out_classes, int64_t* out_patch, int* out_count,
                                int64_t B, int64_t P, int64_t C, int64_t max_out, float conf_thr, float iou_thr, int route) {
     OWL_CHECK_ARG(boxes && sims && workspace && out_boxes && out_scores && out_classes && out_patch && out_count, "owl_postprocess: null pointer");

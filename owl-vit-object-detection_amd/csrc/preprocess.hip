@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void pp_resize_v_batch_kernel(const PreDesc* _
     }
 }
 
-extern "C" int owl_preprocess_u8_batch(void* stream, const void* desc, int64_t n_images, int64_t max_h, unsigned char* tmp, const float* lut,
+OWL_API int owl_preprocess_u8_batch(void* stream, const void* desc, int64_t n_images, int64_t max_h, unsigned char* tmp, const float* lut,
                                        void* out, int out_bf16, int64_t out_h, int64_t out_w) {
     OWL_CHECK_ARG(desc && tmp && lut && out, "owl_preprocess_u8_batch: null pointer");
     OWL_CHECK_ARG(n_images > 0 && n_images < 65536 && max_h > 0 && max_h < 65536 && out_h > 0 && out_h < 65536 && out_w > 0,

@@ -2,6 +2,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include "../../include/owl_hip.h"
+#define OWL_API extern "C" __attribute__((visibility("default")))   // (as in common.h: the library is linked with -fvisibility=hidden)
 
 static thread_local char g_err[512] = "";
 
@@ -12,8 +13,8 @@ void owl_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" const char* owl_last_error(void) { return g_err; }
-extern "C" int owl_abi_version(void) { return OWL_ABI_VERSION; }
+OWL_API const char* owl_last_error(void) { return g_err; }
+OWL_API int owl_abi_version(void) { return OWL_ABI_VERSION; }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Host side of the device input pipeline (ref src/dataset.py:69-71 -> HF OwlViTImageProcessor
@@ -33,7 +34,7 @@ static inline double pil_bicubic(double x) {
 }
 
 // bounds[2*out] = {first tap, tap count}; kk[out*ksize] fixed-point weights (zero padded).  HOST pointers.
-extern "C" int owl_bicubic_coeffs(int64_t in_size, int64_t out_size, int* bounds, int* kk, int64_t kk_capacity, int* ksize_out) {
+OWL_API int owl_bicubic_coeffs(int64_t in_size, int64_t out_size, int* bounds, int* kk, int64_t kk_capacity, int* ksize_out) {
     if (in_size <= 0 || out_size <= 0 || !bounds || !kk || !ksize_out) {
         owl_set_error("owl_bicubic_coeffs: bad arguments (in=%lld out=%lld)", (long long)in_size, (long long)out_size);
         return -1;

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void text_pool_kernel(const float* __restrict_
     for (int p = tid; p < Pdim; p += 256) out[(int64_t)n * Pdim + p] = o[p] / nrm;
 }
 
-extern "C" int owl_text_embed(void* stream, const int64_t* ids, const float* tok_emb, const float* pos_emb, float* x, int64_t N,
+OWL_API int owl_text_embed(void* stream, const int64_t* ids, const float* tok_emb, const float* pos_emb, float* x, int64_t N,
                               int64_t S, int64_t W, int64_t vocab) {
     OWL_CHECK_ARG(ids && tok_emb && pos_emb && x && N > 0 && S > 0 && W > 0 && vocab > 0, "owl_text_embed: bad arguments");
     hipLaunchKernelGGL(text_embed_kernel, dim3((unsigned)(N * S)), dim3(256), 0, (hipStream_t)stream, ids, tok_emb, pos_emb, x, (int)S,
@@ -116,7 +116,7 @@ extern "C" int owl_text_embed(void* stream, const int64_t* ids, const float* tok
     return 0;
 }
 
-extern "C" int owl_causal_attention_small(void* stream, const void* qkv_bf16, void* out_bf16, int64_t N, int64_t S, int64_t heads,
+OWL_API int owl_causal_attention_small(void* stream, const void* qkv_bf16, void* out_bf16, int64_t N, int64_t S, int64_t heads,
                                           float scale) {
     OWL_CHECK_ARG(qkv_bf16 && out_bf16 && N > 0 && heads > 0, "owl_causal_attention_small: bad arguments");
     OWL_CHECK_ARG(S > 0 && S <= 64, "owl_causal_attention_small: sequence length %lld not in 1..64", (long long)S);
@@ -126,7 +126,7 @@ extern "C" int owl_causal_attention_small(void* stream, const void* qkv_bf16, vo
     return 0;
 }
 
-extern "C" int owl_text_pool_project(void* stream, const float* x, const int64_t* ids, const float* gamma, const float* beta,
+OWL_API int owl_text_pool_project(void* stream, const float* x, const int64_t* ids, const float* gamma, const float* beta,
                                      const float* wproj, float* out, int64_t N, int64_t S, int64_t W, int64_t Pdim, float eps) {
     OWL_CHECK_ARG(x && ids && gamma && beta && wproj && out && N > 0 && S > 0 && W > 0 && Pdim > 0, "owl_text_pool_project: bad arguments");
     const size_t lds = (size_t)(W + Pdim + 8) * sizeof(float);

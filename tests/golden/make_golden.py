@@ -239,6 +239,192 @@ def f2():
     _full("owlvit-base-patch16", "f2_b16")
 
 
+# ---------------------------------------------------------------------------------------------------
+# F2b / F4b / F10b (+ F2c): full-size fixtures whose every DISCRETE decision and every kink of the loss has margin.
+#
+# F2 / F4 / F10 draw their targets from synth.make_targets.  On every one of them a matched coordinate sits within 3e-3 of its target (F2 1.6e-4, F4 7.7e-5,
+# F10 5.2e-4): sign(pred - tgt) of the L1 term (ref src/losses.py:57) flips under the bf16 forward's ~2e-3 deviation, that row carries the image's largest box
+# gradient, and the end-to-end gradient comparison of every box-fed tensor is then loose / skipped.  This is the expected case, not bad luck: at HF-init weights
+# a seeded target (0.02-0.37 wide) is 2-20x wider than the predictions (0.01-0.13), every prediction that lies inside a target has the SAME L1 cost (tw - pw) and
+# nearly the same GIoU, so the assignment's runner-up gap is head noise and the winner hugs an edge: over the 11 376 of 20 000 seeds with n >= 8 (`search_seeds`) the gap has median
+# 1.1e-3 (max 3.5e-2), 76 seeds have a coordinate margin >= 5e-3, 26 pass criteria 1, 2, 4, 5 -- and the best runner-up gap among those is 6.2e-3 (seed 2347, n = 8).  So:
+#   * F2c = the best a SEED search reaches (criteria 1, 2, 4 hold, runner-up gap as large as the search finds; `search_seeds` below, margins stored in the file);
+#   * F2b / F4b / F10b = targets CONSTRUCTED around predictions of the reference itself (`anchored_targets`): n anchor rows spread over the grid, target =
+#     the anchor's predicted box with every edge moved by 25-45 % of the box's extent (>= 6e-3; patterns grow / shift left / shift right per axis, never shrink),
+#     label drawn until |sim[anchor, label]| >= 2e-2.  All four criteria then hold with room, and `decision_margins` VERIFIES them on the reference's own outputs
+#     before anything is written:
+#       1. every matched coordinate >= 5e-3 from its target                              (L1 kink, ref src/losses.py:57)
+#       2. every min / max / clamp selection of the matched pairs' GIoU has >= 5e-3      (ref src/matcher.py:25-44: intersection / hull corners select between a
+#          prediction's and its target's coordinate -- criterion 1 -- and the intersection's clamp(min=0) needs |extent| >= 5e-3)
+#       3. runner-up assignment (each matched pair forbidden in turn, scipy re-solved) costs >= 2.5e-2 more = 10x the measured forward error (2.1e-3 ... 2.4e-3)
+#       4. no |IoU - 0.85| < 2e-2 between a positive row and any row in the spreading scan (ref src/losses.py:100-106)
+#       5. (added) |sim| of every positive row at its label >= 2e-2: the class term's slope is -w / |sim| (ref src/losses.py:21,34)
+# ---------------------------------------------------------------------------------------------------
+def decision_margins(cfg, pb, ps, labels, boxes):
+    """Margins of the reference's outputs (pb [P,4], ps [P,C]) for targets (labels [n], boxes [n,4]) against the five criteria above, with the reference's own
+    matcher arithmetic (src/matcher.py) and scipy."""
+    from scipy.optimize import linear_sum_assignment
+    from src.matcher import box_iou, generalized_box_iou
+    pbt, pst = torch.from_numpy(pb), torch.from_numpy(ps)
+    lab, tgt = torch.from_numpy(labels).long(), torch.from_numpy(boxes).float()
+    C = (torch.cdist(pbt, tgt, p=1) - pst.softmax(-1)[:, lab] - generalized_box_iou(pbt, tgt)).double().numpy()     # src/matcher.py:106-124, unit weights
+    r, c = linear_sum_assignment(C)
+    best = C[r, c].sum()
+    gap = np.inf
+    for k in range(len(r)):
+        C2 = C.copy(); C2[r[k], c[k]] = 1e9
+        r2, c2 = linear_sum_assignment(C2)
+        gap = min(gap, C2[r2, c2].sum() - best)
+    src, dst = pb[r], boxes[c]
+    coord = float(np.abs(src - dst).min())
+    iw = np.minimum(src[:, 2], dst[:, 2]) - np.maximum(src[:, 0], dst[:, 0])
+    ih = np.minimum(src[:, 3], dst[:, 3]) - np.maximum(src[:, 1], dst[:, 1])
+    inter = float(min(np.abs(iw).min(), np.abs(ih).min()))
+    tc = torch.full((pb.shape[0],), cfg.n_classes, dtype=torch.long)
+    tc[torch.from_numpy(r)] = lab[torch.from_numpy(c)]
+    iou_margin = 1.0
+    for p in range(pb.shape[0]):                                   # the spreading scan (src/losses.py:100-106), margins taken on the way
+        if tc[p] == cfg.n_classes:
+            continue
+        iou = box_iou(pbt[p:p + 1], pbt)[0][0]
+        iou_margin = min(iou_margin, float((iou - 0.85).abs().min()))
+        tc[iou > 0.85] = tc[p]
+    pos = torch.nonzero(tc != cfg.n_classes).flatten()
+    return dict(n=int(len(r)), gap=float(gap), coord=coord, inter=inter, iou=iou_margin, simpos=float(pst[pos, tc[pos]].abs().min()), npos=int(len(pos)),
+                pred_idx=r[np.argsort(c)])
+
+
+MARGIN_BARS = dict(coord=5e-3, inter=5e-3, gap=2.5e-2, iou=2e-2, simpos=2e-2)
+
+
+def anchored_targets(cfg, pb, ps, seed, n=12, column_margin=4e-2):
+    """n targets constructed around predictions of the reference (see the block comment above).  Deterministic in (seed, reference outputs).  A candidate
+    anchor is kept only if its own prediction wins its target's cost column by `column_margin` (another, larger prediction nearby may fit the moved box
+    better): the assignment is then the column-wise argmin and its runner-up gap is at least that margin."""
+    from owl_vit_object_detection_amd import rng
+    from src.matcher import generalized_box_iou
+    G = cfg.grid
+    w, h = pb[:, 2] - pb[:, 0], pb[:, 3] - pb[:, 1]
+    pbt, prob = torch.from_numpy(pb), torch.from_numpy(ps).softmax(-1)
+    order = np.argsort(rng.uniform(seed, "anchor/order", cfg.patches))
+    anchors, labels, boxes = [], [], []
+    for p in order:
+        p = int(p)
+        py, px = divmod(p, G)
+        if not (2 <= px < G - 2 and 2 <= py < G - 2) or min(w[p], h[p]) < 0.0125:
+            continue
+        if any(max(abs(py - qy), abs(px - qx)) < 6 for qy, qx in (divmod(q, G) for q in anchors)):
+            continue
+        u = rng.uniform(seed, f"anchor/{p}", 8)
+        d = np.zeros(4)
+        for ax, ext in ((0, w[p]), (1, h[p])):
+            m0 = np.clip((0.25 + 0.2 * u[2 * ax]) * ext, 6e-3, ext - 6e-3)
+            m1 = np.clip((0.25 + 0.2 * u[2 * ax + 1]) * ext, 6e-3, ext - 6e-3)
+            pat = int(u[4 + ax] * 3)                      # 0 grow, 1 shift towards +, 2 shift towards -
+            d[ax], d[ax + 2] = ((-m0, m1), (m0, m1), (-m0, -m1))[pat]
+        box = (pb[p].astype(np.float64) + d).astype(np.float32)
+        cand = [int(c) for c in rng.randint(seed, f"anchor/label/{p}", 32, cfg.n_classes) if abs(ps[p, c]) >= 2.5e-2]
+        if not cand:
+            continue
+        t = torch.from_numpy(box)[None]
+        col = (torch.cdist(pbt, t, p=1) - prob[:, cand[0]:cand[0] + 1] - generalized_box_iou(pbt, t))[:, 0].double().numpy()
+        others = np.delete(col, p)
+        if col[p] + column_margin > others.min():
+            continue
+        anchors.append(p); labels.append(cand[0]); boxes.append(box)
+        if len(anchors) == n:
+            break
+    assert len(anchors) == n, len(anchors)
+    return np.array(labels, np.int64), np.stack(boxes).astype(np.float32), np.array(anchors, np.int64)
+
+
+def _check_margins(m, tag, bars=MARGIN_BARS):
+    print(tag, "decision margins:", {k: (round(v, 5) if isinstance(v, float) else v) for k, v in m.items() if k != "pred_idx"})
+    for k, bar in bars.items():
+        assert m[k] >= bar, (tag, k, m[k], bar)
+
+
+def _full_margins(cname, src_tag, tag, profile="init", n=12, targets=None, bars=MARGIN_BARS, seed=1234):
+    """One reference step at batch 1 on targets with margins; the targets themselves are stored (tgt_labels / tgt_boxes): the GPU-side test needs neither
+    the reference nor this generator."""
+    cfg = get_config(cname)
+    src = np.load(os.path.join(HERE, f"{src_tag}.npz"))
+    pb, ps = src["pred_boxes"][0], src["pred_sims"][0]
+    if targets is None:
+        labels, boxes, anchors = anchored_targets(cfg, pb, ps, seed=77, n=n)
+    else:
+        labels, boxes = targets
+        anchors = None
+    m = decision_margins(cfg, pb, ps, labels, boxes)
+    _check_margins(m, tag, bars)
+    if anchors is not None:
+        assert sorted(m["pred_idx"].tolist()) == sorted(anchors.tolist()), "an anchor lost its own target"
+    model, _ = build_reference_model(cfg, seed, profile=profile)
+    img = synth.make_images(cfg, 1, seed)
+    scales = synth.class_scales(cfg, [labels])
+    out, grads = run_reference_step(model, cfg, img, labels, boxes, scales)
+    assert np.array_equal(out["pred_boxes"], src["pred_boxes"]) and np.array_equal(out["pred_sims"], src["pred_sims"]), "the source fixture is not this model's output"
+    m2 = decision_margins(cfg, out["pred_boxes"][0], out["pred_sims"][0], labels, boxes)
+    assert np.array_equal(np.sort(m2["pred_idx"]), np.sort(out["pred_idx"]))
+    out["target_classes"] = recover_spread_labels(cfg, out)
+    out["scales"] = scales
+    out["tgt_labels"], out["tgt_boxes"] = labels, boxes
+    for k in ("gap", "coord", "inter", "iou", "simpos"):
+        out["margin/" + k] = np.float64(m[k])
+    out["pred_boxes"] = out["pred_boxes"].astype(np.float32)
+    out.update(grad_summary(grads, full=False))
+    np.savez_compressed(os.path.join(HERE, f"{tag}.npz"), **out)
+    print(tag, {k: float(out[k]) for k in ("loss_ce", "loss_bg", "loss_bbox", "loss_giou")}, "positives after spreading", int((out["target_classes"] != cfg.n_classes).sum()))
+
+
+def f2b():
+    _full_margins("owlvit-base-patch16", "f2_b16", "f2b_b16_margins")
+
+
+def f4b():
+    _full_margins("owlvit-large-patch14", "f4_l14", "f4b_l14_margins")
+
+
+def f10b():
+    _full_margins("owlvit-base-patch16", "f10_b16_trained", "f10b_b16_trained_margins", profile="trained_like")
+
+
+def search_seeds(cname="owlvit-base-patch16", src_tag="f2_b16", n_seeds=20000, min_boxes=8):
+    """The seed search VERDICT r04 #1 asks for, over synth.make_targets' seed on the reference's stored outputs: criteria 1, 2, 4, 5 as bars, criterion 3
+    (runner-up gap) maximised.  Prints the distribution so that the docstring above can be checked."""
+    cfg = get_config(cname)
+    src = np.load(os.path.join(HERE, f"{src_tag}.npz"))
+    pb, ps = src["pred_boxes"][0], src["pred_sims"][0]
+    rows = []
+    for seed in range(1, n_seeds + 1):
+        labels, boxes = synth.make_targets(cfg, 1, seed, max_boxes=16)
+        if len(labels[0]) < min_boxes:
+            continue
+        m = decision_margins(cfg, pb, ps, labels[0], boxes[0])
+        rows.append((m["gap"], m["coord"], m["inter"], m["iou"], m["simpos"], seed, m["n"]))
+    gaps = np.array([r[0] for r in rows])
+    ok = [r for r in rows if r[1] >= 5e-3 and r[2] >= 5e-3 and r[3] >= 2e-2 and r[4] >= 1e-2]
+    print(f"search_seeds: {len(rows)} seeds with n >= {min_boxes}: runner-up gap median {np.median(gaps):.2e} max {gaps.max():.2e}; "
+          f"{sum(r[1] >= 5e-3 for r in rows)} with coordinate margin >= 5e-3; {len(ok)} pass criteria 1, 2, 4, 5")
+    ok.sort(reverse=True)
+    print("   best by gap:", ok[:5])
+    return ok[0][5] if ok else None
+
+
+F2C_SEED = 2347        # = search_seeds()'s result (20 000 seeds, 4.5 minutes); f2c(seed=0) re-runs the search
+
+
+def f2c(seed=None):
+    cfg = get_config("owlvit-base-patch16")
+    seed = seed if seed else (search_seeds() if seed == 0 else F2C_SEED)
+    labels, boxes = synth.make_targets(cfg, 1, seed, max_boxes=16)
+    bars = dict(MARGIN_BARS, gap=0.0, simpos=1e-2)
+    _full_margins("owlvit-base-patch16", "f2_b16", "f2c_b16_seed_search", targets=(labels[0], boxes[0]), bars=bars)
+    g = dict(np.load(os.path.join(HERE, "f2c_b16_seed_search.npz")))
+    g["target_seed"] = np.int64(seed)
+    np.savez_compressed(os.path.join(HERE, "f2c_b16_seed_search.npz"), **g)
+
+
 def attention_stats(model, cfg, image):
     """Statistics of the reference's own attention logits on `image` (hooks on every layer's layer_norm1): per layer the std / max of the logits
     and a simulation of the HIP forward's softmax-offset logic on them -- the kernel (csrc/attention_fwd.hip) exponentiates a 64-key tile against

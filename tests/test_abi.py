@@ -92,3 +92,75 @@ def test_product_package_never_imports_the_oracle():
             if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
                 offenders.append(fn)
     assert offenders == []
+
+
+def test_dynamic_symbol_table_holds_only_the_c_abi(built):
+    """the library is built with -fvisibility=hidden + a linker version script (csrc/libowlhip.map): its dynamic symbol table DEFINES the
+    entry points of include/owl_hip.h and nothing else -- no `__device_stub__` kernel stubs, no kernel handles, no C++ helpers."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    defined = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    declared = set(_lib.parse_header())
+    stray = sorted(n for n in defined if not n.startswith("owl_"))
+    assert stray == [], stray[:10]
+    if os.environ.get("OWL_TUNING", "0") != "1":
+        assert defined == declared, (sorted(defined - declared), sorted(declared - defined))
+
+
+# ---- register budget of the hot kernels (no GPU needed: the code objects' metadata) -------------------------------------------------------
+_LLVM = "/opt/rocm/lib/llvm/bin"
+# kernel (mangled-name pattern) -> VGPRs allowed in scratch.  0 everywhere on the hot path; the one exception says why.
+_SPILL_FREE = {
+    "gemm_pp2.o": [r"gemm_pp2_kernelILi0ELb0ELb0E", r"gemm_pp2_kernelILi0ELb0ELb1E", r"gemm_pp2_kernelILi1ELb0ELb0E", r"gemm_pp2_kernelILi8ELb0ELb0E", r"gemm_pp2_kernelILi7ELb0ELb0E",
+                   r"gemm_pp2_kernelILi2E", r"gemm_pp2_kernelILi9E", r"gemm_pp2_kernelILi4E", r"gemm_pp2_kernelILi10E", r"gemm_pp2_kernelILi12E"],
+    "gemm_pph.o": [r"gemm_pph_kernelILi0E"],
+    "attention_fwd.o": [r"attn_fwd_kernelILb1ELb1ELi4E", r"attn_fwd_kernelILb1ELb0ELi4E"],
+    "attention_bwd.o": [r"attn_bwd_dq_kernel", r"attn_dvec_kernel"],
+    "gemm_tn.o": [r"gemm_tn_pp_kernel"],
+    "norm.o": [r"ln_fwd_kernel", r"merge_ln_kernel"],
+    "backward.o": [r"ln_bwd_kernel"],
+}
+# attn_bwd_dkdv: two lane-id-derived values (l31, 8 * hi) are parked in scratch BEFORE the query-tile loop and reloaded AFTER it for the output addresses
+# (one scratch_store pair in the prologue, one scratch_load pair in the epilogue; nothing inside the loop -- checked on the assembly, VERDICT r04 weak #7)
+_SPILL_ALLOWED = {"attention_bwd.o": {r"attn_bwd_dkdv_kernel": 2}}
+
+
+def _kernel_notes(obj):
+    """{kernel name: {spill, scratch, vgpr}} from the gfx950 code object bundled in a host object (its AMDGPU metadata note is YAML)."""
+    import subprocess
+    import tempfile
+    import yaml
+    with tempfile.TemporaryDirectory() as td:
+        fat, co = os.path.join(td, "fat.bin"), os.path.join(td, "k.co")
+        subprocess.run([f"{_LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", obj], check=True)
+        subprocess.run([f"{_LLVM}/clang-offload-bundler", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}", f"--output={co}", "--unbundle"], check=True)
+        notes = subprocess.run([f"{_LLVM}/llvm-readelf", "--notes", co], capture_output=True, text=True, check=True).stdout
+    doc = notes[notes.index("---"):]
+    doc = doc[:doc.index("\n...")] if "\n..." in doc else doc
+    meta = yaml.safe_load(doc)
+    return {k[".name"]: dict(spill=int(k[".vgpr_spill_count"]), scratch=int(k[".private_segment_fixed_size"]), vgpr=int(k[".vgpr_count"])) for k in meta["amdhsa.kernels"]}
+
+
+def test_hot_kernels_do_not_spill(built):
+    """VERDICT r04 #2 rider: `vgpr_spill_count == 0` for the GEMM / attention / LayerNorm kernels of the train step, read from the metadata of the very
+    objects libowlhip.so is linked from (round 4 shipped gemm_pp2<8> with 8 and <7> with 14 spilled VGPRs, attn_fwd with 5)."""
+    import re
+    bdir = os.path.join(os.path.dirname(_lib.LIB_PATH), "csrc", "build")
+    if not os.path.exists(os.path.join(bdir, "gemm_pp2.o")):
+        import __graft_entry__ as g
+        g.build()
+    for obj, pats in _SPILL_FREE.items():
+        ks = _kernel_notes(os.path.join(bdir, obj))
+        assert ks, obj
+        for pat in pats:
+            hits = {k: v for k, v in ks.items() if re.search(pat, k)}
+            assert hits, (obj, pat, sorted(ks))
+            for k, v in hits.items():
+                assert v["spill"] == 0 and v["scratch"] == 0, (k, v)
+    for obj, allowed in _SPILL_ALLOWED.items():
+        ks = _kernel_notes(os.path.join(bdir, obj))
+        for pat, cap in allowed.items():
+            hits = {k: v for k, v in ks.items() if re.search(pat, k)}
+            assert hits, (obj, pat)
+            for k, v in hits.items():
+                assert v["spill"] <= cap, (k, v)

@@ -341,6 +341,60 @@ def test_train_step_b16_matches_reference_fixture_f2(golden_dir):
     _check_grads_vs_fixture(g, grads, "B/16 F2", dict(GRAD_BANDS_F2, **{"*": GRAD_BANDS_F2_BOX_FED}), skip=lambda n: near_tie and n.startswith("box_head"))
 
 
+# ---------------------------------------------------------------------------------------------------
+# F2b / F4b / F10b (+ F2c): the end-to-end gradient pin against the REFERENCE at full size, on fixtures whose decisions and loss kinks have margin
+# (VERDICT r04 #1).  F2 / F4 / F10 above all have a matched coordinate within 3e-3 of its target, so box_head.* is skipped there and every box-fed
+# tensor takes the loose band; here nothing is skipped and every one of the 29 tensors is held to GRAD_BANDS_DEFAULT.  The generator
+# (tests/golden/make_golden.py: anchored_targets / decision_margins) verifies on the reference's own outputs: matched coordinates >= 5e-3 from their
+# targets, GIoU selections >= 5e-3, runner-up assignment >= 2.5e-2 (= 10x the forward error) more expensive, no |IoU - 0.85| < 2e-2 in the spreading
+# scan, |sim| >= 2e-2 on every positive row; the margins travel in the fixture (margin/*) and the targets too (tgt_labels / tgt_boxes).
+# F2c is what a pure SEED search over synth.make_targets reaches (criteria 1, 2, 4 hold; the runner-up gap does not reach the bar -- at HF-init weights every
+# prediction inside a seeded target costs the same): asserted the same way when its decisions agree, like with like otherwise.
+# ---------------------------------------------------------------------------------------------------
+MARGIN_FIXTURES = [("owlvit-base-patch16", "f2b_b16_margins", "init"), ("owlvit-large-patch14", "f4b_l14_margins", "init"),
+                   ("owlvit-base-patch16", "f10b_b16_trained_margins", "trained_like"), ("owlvit-base-patch16", "f2c_b16_seed_search", "init")]
+# trained-like weights: 2x (2e-2, 0.995)-class measurements of F10's class-only tensors do not transfer to box-fed ones; measured on the round-5 build
+# (profiles/r05_parity_bands.md) and asserted at ~2x
+GRAD_BANDS_TRAINED = (3e-2, 0.99)
+
+
+@pytest.mark.parametrize("cname,tag,profile", MARGIN_FIXTURES)
+def test_train_step_matches_reference_margin_fixture(golden_dir, cname, tag, profile):
+    path = os.path.join(golden_dir, f"{tag}.npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{tag}.npz not generated")
+    cfg = get_config(cname)
+    g = np.load(path)
+    img = synth.make_images(cfg, 1)
+    labels, boxes = [g["tgt_labels"]], [g["tgt_boxes"]]
+    model, crit, lg, grads, pb, ps = _step_hip(cfg, weights.make_weights(cfg, profile=profile), img, labels, boxes, g["scales"])
+    eb, es = _maxerr(pb, torch.from_numpy(g["pred_boxes"])), _maxerr(ps, torch.from_numpy(g["pred_sims"]))
+    n = len(labels[0])
+    same_tc = bool((crit.last["target_classes"][0].cpu() == torch.from_numpy(g["target_classes"])).all())
+    same_idx = np.array_equal(crit.last["pred_idx"][0, :n].cpu().numpy(), g["pred_idx"]) and np.array_equal(crit.last["tgt_idx"][0, :n].cpu().numpy(), g["tgt_idx"])
+    print(f"{tag}: max|d boxes|={eb:.3e} max|d sims|={es:.3e}; margins of the fixture: " + ", ".join(f"{k} {float(g['margin/' + k]):.3e}" for k in ("coord", "inter", "gap", "iou", "simpos"))
+          + f"; assignment identical {same_idx}, labels after spreading identical {same_tc}")
+    trained = profile != "init"
+    assert eb < (TOL_TRAINED_BOXES if trained else TOL_BOXES) and es < (TOL_TRAINED_SIMS if trained else TOL_SIMS), (eb, es)
+    assert not _near_tie(dict(pred_boxes=g["pred_boxes"], pred_idx=g["pred_idx"], tgt_idx=g["tgt_idx"]), boxes)
+    seed_search = tag.startswith("f2c")
+    if not seed_search:
+        assert same_idx and same_tc          # a runner-up 10x the forward error away: the decisions cannot differ
+    if not (same_idx and same_tc):           # (F2c only: runner-up gap below the bar -- losses like with like, gradients not comparable)
+        ref_l, n_swaps, n_rows = _reference_losses_for_decisions(cfg, g, labels, boxes, crit, eb, es)
+        for k in LOSS_KEYS:
+            assert abs(lg[k] - ref_l[k]) <= LOSS_REL * abs(ref_l[k]), (k, lg[k], ref_l[k])
+        pytest.skip(f"{tag}: {n_swaps} assignment swaps across a cost near-tie (runner-up gap {float(g['margin/gap']):.2e}): gradients not comparable")
+    bound = _class_loss_bound(cfg, g, es)
+    for k in LOSS_KEYS:
+        rel = abs(lg[k] - float(g[k])) / abs(float(g[k]))
+        print(f"   {k}: {lg[k]:.6f} ref {float(g[k]):.6f} rel {rel:.2e}")
+        assert abs(lg[k] - float(g[k])) <= max((2e-2 if trained else LOSS_REL) * abs(float(g[k])), bound.get(k, 0.0) if trained else 0.0), (k, lg[k], float(g[k]))
+    # all 29 tensors, nothing skipped
+    assert len(grads) == 29
+    _check_grads_vs_fixture(g, grads, tag, {"*": GRAD_BANDS_TRAINED} if trained else {})
+
+
 @pytest.mark.parametrize("cname", ["owlvit-base-patch16", "owlvit-large-patch14", "small"])
 def test_loss_backward_at_the_operating_point(cname):
     """What the end-to-end fixtures cannot pin when a matched box sits on a kink of the loss: d loss / d (pred_boxes, pred_sims) of the HIP criterion
