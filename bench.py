@@ -55,6 +55,8 @@ TRAFFIC_SOURCE = "profiles/r04_hbm_traffic.md"
 LABEL_BIAS = "gemm op <bias> (gemm_pp2_kernel + gemm_pph_kernel remainder)"
 LABEL_QGELU = "gemm_pp2_kernel<qgelu>"
 LABEL_ATTN = "attn_fwd_kernel<VROW>"
+LABEL_DQGELU = "gemm_pp2_kernel<dX through quick-GELU'>"
+LABEL_ATTN_BWD = "attention backward (attn_dvec + attn_bwd_dkdv + attn_bwd_dq kernels)"
 TRAFFIC_ALL = {}            # workload key ("<arch>/<batch per GPU>") -> {label: bytes per op}
 TRAFFIC_NOTE = None
 
@@ -149,7 +151,8 @@ def synth_batches(cfg, B, device, rank, n_batches=2, seed=1234):
         lab_l = [torch.from_numpy(l).to(device) for l in labels]          # ref main.py:78-79: labels.to(device), boxes.to(device)
         box_l = [torch.from_numpy(b).to(device) for b in boxes]
         tg = PackedTargets(lab_l, box_l, device, cfg.n_classes)
-        out.append(dict(img=img.contiguous(), packed=tg, labels=lab_l, boxes=box_l, labels_np=labels))
+        img_host = torch.from_numpy(synth.make_images(cfg, B, seed + rank, first=k * B)).pin_memory()      # what a DataLoader(pin_memory=True) hands over
+        out.append(dict(img=img.contiguous(), img_host=img_host, packed=tg, labels=lab_l, boxes=box_l, labels_np=labels))
     return out
 
 
@@ -197,7 +200,8 @@ def cpu_baseline(cfg, steps, batch8=False):
            "batch1_images_per_sec": round(1.0 / m1, 4),
            "cpu": f"{_cpu_model_string()} ({total} logical cores, {cores} torch threads used)",
            "sample": f"fp32 train steps (fwd+matcher+loss+bwd) of {cfg.name} on the CPU oracle at the reference's batch size of 1: median {m1:.2f} s/step "
-                     f"over {n1} steps after {w1} warm-ups; the reference itself: 0.32 img/s on 8 vCPUs (BASELINE.md section 2)"}
+                     f"over {n1} steps after {w1} warm-ups; {cores} of {total} threads = the fastest setting on this CPU (thread study: profiles/r03_cpu_threads.md); "
+                     f"the reference itself: 0.32 img/s on 8 vCPUs (BASELINE.md section 2)"}
     if 8 in res:
         m8, n8, w8 = res[8]
         out["batch8_images_per_sec"] = round(8.0 / m8, 4)
@@ -288,19 +292,23 @@ def main():
     kt.traffic = {} if (args.forward_only or args.weights != "init") else TRAFFIC_ALL.get(f"{cfg.name}/{B}", {})
 
     def classify_gemm(epi, A, W, out, bias=None, resid=None, aux=None, M=None, N=None, K=None, **kw):
-        if epi not in (ops.EPI_BIAS_BF16, ops.EPI_QGELU_BF16):
+        if epi not in (ops.EPI_BIAS_BF16, ops.EPI_QGELU_BF16, ops.EPI_DQGELU_BF16):
             return None
         K = K if K is not None else A.shape[-1]; N = N if N is not None else W.shape[0]; M = M if M is not None else A.shape[0]
         if not (K % 128 == 0 and M >= 512 and N >= 256):
             return None                                            # not the ping-pong kernel (csrc/gemm.hip dispatch)
-        return (LABEL_BIAS if epi == ops.EPI_BIAS_BF16 else LABEL_QGELU, 2.0 * M * N * K)
+        return ({ops.EPI_BIAS_BF16: LABEL_BIAS, ops.EPI_QGELU_BF16: LABEL_QGELU, ops.EPI_DQGELU_BF16: LABEL_DQGELU}[epi], 2.0 * M * N * K)
 
     def classify_attn(q, k, v, ld, out, ld_out, lse, B_, H, T, Tp, scale):
         return (LABEL_ATTN, 4.0 * B_ * H * T * T * 64)   # QK^T + PV per launch
 
+    def classify_attn_bwd(qkv, dO, O, lse, dvec, dqkv, B_, H, T, Tp, scale):
+        return (LABEL_ATTN_BWD, 10.0 * B_ * H * T * T * 64)   # the algorithmic five matmuls (S, dP, dV, dK, dQ); the kernels execute seven (P recomputed in both)
+
     if not args.no_kernel_events:
         ops.gemm = kt.wrap(ops.gemm, classify_gemm)
         ops.attention_fwd_vrow = kt.wrap(ops.attention_fwd_vrow, classify_attn)
+        ops.attention_bwd = kt.wrap(ops.attention_bwd, classify_attn_bwd)
 
     ar_events = []
     if world > 1 or os.environ.get("OWL_FORCE_DIST", "0") == "1":
@@ -315,14 +323,17 @@ def main():
             return r
         ddp.allreduce_flat = timed_ar
 
+    h2d = [False]          # True: the step starts from f32 images in pinned HOST memory and copies them itself, as ref main.py:77 `image.to(device)` does
+
     def step(i, mode):
         bt = batches[i % len(batches)]
+        img = bt["img_host"].to(dev, non_blocking=True) if h2d[0] else bt["img"]
         if args.forward_only:
             with torch.no_grad():
-                model(bt["img"])
+                model(img)
             return None
         opt.zero_grad()
-        pred_boxes, _, pred_sims, _ = model(bt["img"])
+        pred_boxes, _, pred_sims, _ = model(img)
         if mode == "lists":
             losses = crit(pred_sims, bt["labels"], pred_boxes, bt["boxes"])       # ref main.py:83
         else:
@@ -366,10 +377,12 @@ def main():
             dist.barrier()
         dt = time.perf_counter() - t0
         kt.on = False
-        if world > 1:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        timed_run.rank_seconds = (dt, dt)                  # (fastest, slowest) rank of this run; the reported time is the slowest's
+        if dist_active and dist.is_initialized():
+            t = torch.tensor([dt, -dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+            dt = float(t[0].item())
+            timed_run.rank_seconds = (-float(t[1].item()), dt)
         return dt, int(slow_tiles.item())
 
     # ---- more than one rank (or one forced rank): make the run unloseable ---------------------------------------------
@@ -381,10 +394,14 @@ def main():
     def replicas_equal():
         if not dist_active:
             return None
-        c = model.flat_param.view(torch.int32).to(torch.int64).sum()          # exact: any differing bit moves it
-        t = torch.stack([c, -c])
+        # two integer checksums of the parameter BITS (exact arithmetic in int64: no rounding) -- the plain sum, which a pair of compensating differences
+        # could leave unchanged, and a position-weighted sum, which the same pair cannot also leave unchanged; MIN and MAX over ranks must agree
+        bits = model.flat_param.view(torch.int32).to(torch.int64)
+        wgt = (torch.arange(bits.numel(), device=bits.device, dtype=torch.int64) % 1000003) + 1
+        c = torch.stack([bits.sum(), (bits * wgt).sum()])
+        t = torch.cat([c, -c])
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        return bool(int(t[0]) == -int(t[1]))
+        return bool(int(t[0]) == -int(t[2]) and int(t[1]) == -int(t[3]))
 
     def snapshot():
         dp.finish(); torch.cuda.synchronize()
@@ -439,17 +456,28 @@ def main():
             "backend": (dist.get_backend() + (" (RCCL over xGMI)" if dist.get_backend() == "nccl" else " (TEST ONLY: not a benchmark)")) if dist.is_initialized() else "none (single process)",
         }
         out["config"].update(extra_cfg)
+        if dist_active:
+            lo, hi = timed_run.rank_seconds                # per-rank throughput of THIS run: the slowest rank sets `value`
+            out["images_per_sec_per_rank_min"] = round(B * args.steps / hi, 2)
+            out["images_per_sec_per_rank_max"] = round(B * args.steps / lo, 2)
+            out["schedule"] = schedule
+        # HIP-event fields (roofline*, allreduce_ms) are recorded during ONE phase only -- the in-line one when both schedules are measured (an event
+        # pair around a launch on the tail stream would time the other stream's kernels too): the line says which
+        events_phase = "in-line schedule" if (schedule == "in-line" or events_from_inline[0]) else schedule
         if ar_events:
             out["allreduce_ms"] = round(float(np.mean([a.elapsed_time(b) for a, b in ar_events])), 4)
             out["allreduce_bytes"] = int(model.flat_numel * 4)
+            out["allreduce_measured_under"] = events_phase
         main_r, others = None, []
-        for label in (LABEL_BIAS, LABEL_QGELU, LABEL_ATTN):
+        for label in (LABEL_BIAS, LABEL_QGELU, LABEL_ATTN, LABEL_DQGELU, LABEL_ATTN_BWD):     # (the last two: the kernels furthest below their roofline)
             r = kt.summary(label)
             if r is None:
                 continue
             r["ms_total_per_step"] = round(r["ms_per_launch"] * r["launches_timed"] / len(range(0, args.steps, EVENT_EVERY)), 3)
             r["measured_on"] = (f"every {EVENT_EVERY}th timed step, which runs the one-stream schedule (whole-batch launches, the kernel alone on the chip); "
                                 f"the other steps run {args.encoder_streams} sub-batch streams")
+            if dist_active:
+                r["measured_under"] = events_phase
             if main_r is None:
                 main_r = r
             else:
@@ -459,6 +487,7 @@ def main():
             out["roofline_other"] = others
         return out
 
+    events_from_inline = [False]      # set once the in-line phase of the two-schedule flow has recorded the HIP events the deferred line re-uses
     SCHED_TAIL = "backward + all-reduce + AdamW on the tail stream under the next step's frozen prefix (bitwise the in-line schedule)"
     extra = {}
     line = None
@@ -470,10 +499,13 @@ def main():
         extra["images_per_sec_inline_schedule"] = round(B * world * args.steps / dt_in, 2)
         line_inline = report(dt_in, slow_in, "in-line", dict(extra))
         line_inline["replicas_equal"] = eq_in
+        line_inline["deferred_phase"] = "not run"
+        events_from_inline[0] = True
 
         def bail():            # the deferred phase did not come back: the in-line measurement is the result
             if rank == 0:
                 line_inline["config"]["schedule_check"] = f"deferred-tail phase did not finish within {int(limit)} s: in-line schedule reported"
+                line_inline["deferred_phase"] = "watchdog fired"
                 print(json.dumps(line_inline), flush=True)
             os._exit(0)
         limit = args.watchdog_seconds if args.watchdog_seconds else max(120.0, 40.0 * dt_in)
@@ -497,6 +529,7 @@ def main():
             dog.cancel()
             if rank == 0:
                 line_inline["config"]["schedule_check"] = f"deferred-tail phase raised {type(e).__name__}: {str(e)[:200]} -- in-line schedule reported"
+                line_inline["deferred_phase"] = "raised"
                 print(json.dumps(line_inline), flush=True)
             os._exit(0)
         if ok:
@@ -504,9 +537,11 @@ def main():
             extra["images_per_sec_deferred_tail_schedule"] = round(B * world * args.steps / dt, 2)
             line = report(dt, slow, SCHED_TAIL, extra)
             line["replicas_equal"] = bool(eq and eq_in)
+            line["deferred_phase"] = "ok"
         else:
             set_schedule(False)
             line_inline["config"]["schedule_check"] = "pre-flight MISMATCH between the deferred-tail and the in-line schedule (or replicas diverged): in-line schedule reported"
+            line_inline["deferred_phase"] = "mismatch"
             line = line_inline
     else:
         set_schedule(want_overlap and not args.forward_only and model.flat_grad.is_cuda)
@@ -519,6 +554,16 @@ def main():
         dt_o, _ = timed_run(other_mode, args.steps, 1, False)
         line["config"]["images_per_sec_" + other_mode + "_targets"] = round(B * world * args.steps / dt_o, 2)
 
+    if not args.no_compare:
+        # the same step with the host-to-device copy of the images INSIDE it (ref main.py:77; 7.08 MB f32 per B/16 image over PCIe): reported beside the
+        # HBM-resident headline, never as `value`
+        h2d[0] = True
+        dt_h, _ = timed_run(args.targets, args.steps, 1, False)
+        h2d[0] = False
+        line["config"]["images_per_sec_incl_h2d"] = round(B * world * args.steps / dt_h, 2)
+        line["config"]["h2d_note"] = "f32 images in pinned host memory, image.to(device, non_blocking=True) inside the timed step (ref main.py:77)"
+
+    ops.ATTN_SLOW_TILES = None          # (process-global statistic hook: not left armed behind the measurement)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_steps, args.cpu_batch8)

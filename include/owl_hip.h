@@ -32,9 +32,9 @@ extern "C" {
 
 /* ---- runtime ---------------------------------------------------------------------------------- */
 /* Bumped whenever a prototype, an argument's meaning or a caller-provided scratch layout changes (1 = round 1; 2 = round 2: per-call `tile` /
- * `variant` arguments, partial-sum scratch of the row reductions, 5D+4 box_final_bwd partials; 3 = round 3; 4 = round 4: `slow_tiles` statistic of the attention forward; the V^T attention form, attention variants 3-5, GEMM epilogues 5 / 6 and tiles 8 / 9 / 5 / 4 moved to OWL_TUNING builds).  owl_abi_version() returns the value
+ * `variant` arguments, partial-sum scratch of the row reductions, 5D+4 box_final_bwd partials; 3 = round 3; 4 = round 4: `slow_tiles` statistic of the attention forward; 5 = round 5: owl_patch_embed_bf16's weight layout for patch sizes that are not 2^n (gathered, no im2row); the V^T attention form, attention variants 3-5, GEMM epilogues 5 / 6 and tiles 8 / 9 / 5 / 4 moved to OWL_TUNING builds).  owl_abi_version() returns the value
  * the library was BUILT with: a binding compares it with the header it was generated from and refuses a mismatch (_lib.load() does). */
-#define OWL_ABI_VERSION 4
+#define OWL_ABI_VERSION 5
 const char* owl_last_error(void);
 int owl_abi_version(void);
 
@@ -59,10 +59,15 @@ int owl_gemm_slab_workspace_bytes(int64_t M, int64_t ldo, int64_t K, int splits,
 int owl_slab_reduce(void* stream, const float* slabs, float* out, int64_t n, int64_t slab_stride, int nsplit, int accumulate);
 
 /* ---- patch embedding (HF5:282-288 Conv2d k=s=patch, no bias; HF5:336-343 flatten + positions) ----
- * im2row-free: the A-operand loader gathers 16-byte runs of each patch row straight from the
- * bf16 image [B,3,S,S] into LDS.  x_out[b*Tp + 1 + p, :] = W_pe . vec(patch) + pos[1+p, :].      */
-/* patch sizes that are not a power of two (L/14): pass `scratch` = bf16 [rows128(B*P), Kpad] for an explicit im2row and
- * w_pe as [D, Kpad] (Kpad = 3*ps*ps rounded up to 64, zero columns beyond); otherwise scratch may be NULL.
+ * im2row-free for EVERY patch size 8 <= ps <= 64: the A-operand loader gathers 16-byte runs of each patch row straight from the
+ * bf16 image [B,3,S,S] into LDS.  x_out[b*Tp + 1 + p, :] = W_pe . vec(patch) + pos[1+p, :].
+ *   ps = 2^n      : w_pe = the conv weight [D, 3*ps*ps] as it lies.
+ *   other ps (14) : the K index pads a patch row to psp = 2^n >= ps positions; position `pos` of a row holds pixel
+ *                   min(8*(pos/8), ps - 8) + pos%8 -- the last 16-byte chunk of a row OVERLAPS its predecessor instead of leaving the
+ *                   patch -- and w_pe is [D, Kg], Kg = 3*ps*psp rounded up to 64, with the conv weight at each pixel's FIRST position
+ *                   and zeros elsewhere (Python: weights.patch_weight_gather_layout).  (ABI 5; ABI <= 4 took an explicit im2row there.)
+ * scratch: bf16 [rows128(B*P), Kg], needed only when a single-phase reference kernel (tile 256 / 128, or a problem too small for the
+ *          ping-pong kernel) meets a patch size that is not 2^n (explicit im2row in the same K order: identical bits); else NULL.
  * tile: 0 = automatic (two-phase ping-pong kernel for big problems), 7 / 256 / 128 pin a kernel (tests); same bits.       */
 int owl_patch_embed_bf16(void* stream, const void* image_bf16, const void* w_pe, const float* pos, float* x_out, void* scratch, int64_t B, int64_t S, int64_t ps, int64_t D, int64_t Tp, int tile);
 /* class-token rows x[b*Tp, :] = class_embedding + pos[0, :]  (HF5:338-343)                        */

@@ -386,6 +386,12 @@ OWL_API int owl_gemm_nt_bf16(void* stream, int epi, const void* A, int64_t lda, 
         // dense (GELU epilogue), +0.8 % out-proj (K = 768); nothing for wide outputs (QKV N = 2304: -0.1 %, fc1: does not fit one round), where
         // the half-height tiles -- latency-bound, ~0.85 of a full tile's time, not 0.56 -- only just pay for the second launch.  Hence the
         // automatic rule: narrow outputs only (N <= 1024); tile = 9 forces the split wherever it fits, tile = 8 never splits.
+        // Small problems (the reference's own batch size of 1: QKV = 90 tiles, fc1 = 120 on 256 CUs): no more 256 x 256 tiles than HALF the CUs -> every tile
+        // goes out as two half-height tiles (gemm_pph.hip), one partial round of ~0.85 tile times on twice the CUs.  Same K order and epilogue: bit-identical.
+        if (g_force_tile == 0 && a_rows >= M && 2 * ((M + 255) / 256) * ((N + 255) / 256) <= 256) {
+            const int rc = owl_gemm_pph_launch(s, epi, p);
+            if (rc <= 0) return rc;      // 1 = epilogue not handled by the half-height kernel: the 256 x 256 kernel below
+        }
         if ((g_force_tile == 9 || (g_force_tile == 0 && N <= 1024)) && epi != EPI_TRANS_BF16 && epi != EPI_F32 && epi != EPI_ACC_F32 && a_rows >= M) {
             const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256, items = tm * tn;
             const int64_t full_rounds = items / 256;
@@ -481,61 +487,62 @@ OWL_API int owl_slab_reduce(void* stream, const float* slabs, float* out, int64_
     return owl_slab_reduce_impl((hipStream_t)stream, slabs, out, n, slab_stride, nsplit, accumulate);
 }
 
-// im2row for patch sizes the fused loader cannot take (L/14: 14-pixel rows are 28 bytes, not 16-byte chunks):
-// patches[b*P + p, k] = image[b, c, py*ps + ky, px*ps + kx], k = (c*ps + ky)*ps + kx, zero-padded to Kpad.
-__global__ __launch_bounds__(256) void im2row_kernel(const bf16_t* __restrict__ img, bf16_t* __restrict__ out, int64_t B, int S, int ps,
-                                                     int G, int K, int Kpad) {
+// Explicit im2row in the gather's K order (below) -- only for the single-phase REFERENCE kernels (tile = 256 / 128) on patch sizes that are not 2^n:
+// patches[b*P + p, (c*ps + ky)*psp + pos] = image[b, c, py*ps + ky, px*ps + min(8*(pos/8), ps - 8) + pos%8], zero-padded to Kg.
+__global__ __launch_bounds__(256) void im2row_kernel(const bf16_t* __restrict__ img, bf16_t* __restrict__ out, int64_t B, int S, int ps, int psp,
+                                                     int G, int K, int Kg) {
     const int64_t row = blockIdx.x;                  // b*P + p
     const int64_t P = (int64_t)G * G;
     const int64_t b = row / P; const int pp = (int)(row - b * P);
     const int py = pp / G, px = pp - py * G;
-    for (int k = threadIdx.x; k < Kpad; k += 256) {
+    for (int k = threadIdx.x; k < Kg; k += 256) {
         bf16_t v = 0;
         if (k < K) {
-            const int c = k / (ps * ps), rem = k - c * ps * ps, ky = rem / ps, kx = rem - ky * ps;
+            const int r = k / psp, pos = k - r * psp, c = r / ps, ky = r - c * ps;
+            const int kx = min((pos >> 3) << 3, ps - 8) + (pos & 7);
             v = img[((b * 3 + c) * S + py * ps + ky) * (int64_t)S + px * ps + kx];
         }
-        out[row * Kpad + k] = v;
+        out[row * Kg + k] = v;
     }
 }
 
-// Patch-embed: X[b*Tp + 1 + p, :] = W_pe . vec(patch(b,p)) + pos[1+p]   (no bias; HF5:282-288,336-343)
-// Power-of-two patch sizes: im2row-free (the A loader gathers 16-byte runs of patch rows straight from the image).
-// Otherwise: `scratch` (bf16 [B*P (row-padded to 128), Kpad]) receives an explicit im2row and w_pe must be [D, Kpad]
-// with zero columns beyond 3*ps*ps; Kpad = 3*ps*ps rounded up to 64.
+// Patch-embed: X[b*Tp + 1 + p, :] = W_pe . vec(patch(b,p)) + pos[1+p]   (no bias; HF5:282-288,336-343), im2row-free: the A loader gathers 16-byte runs of
+// patch rows straight from the image (gemm_pp2.hip, stage_A) for every patch size >= 8.
+//   ps = 2^n       : w_pe = the conv weight [D, 3*ps*ps] as it lies.
+//   other ps (14)  : the K index pads a patch row to psp = 2^n >= ps positions; position `pos` of a row holds pixel min(8*(pos/8), ps - 8) + pos%8 (the last
+//                    16-byte chunk overlaps its predecessor instead of leaving the row) and w_pe [D, Kg], Kg = 3*ps*psp rounded up to 64, holds the conv weight
+//                    at each pixel's FIRST position and zeros elsewhere (Python: weights.patch_weight_gather_layout).
+// `scratch` (bf16 [B*P (row-padded to 128), Kg]) is needed only when a single-phase reference kernel (tile = 256 / 128, or a problem too small for the ping-pong
+// kernel) meets a patch size that is not 2^n: it then receives an explicit im2row in the same K order (identical bits).
 OWL_API int owl_patch_embed_bf16(void* stream, const void* image_bf16, const void* w_pe, const float* pos,
                                     float* x_out, void* scratch, int64_t B, int64_t S, int64_t ps, int64_t D, int64_t Tp, int tile) {
     OWL_CHECK_ARG(image_bf16 && w_pe && pos && x_out, "owl_patch_embed_bf16: null pointer");
-    OWL_CHECK_ARG(S % ps == 0, "owl_patch_embed_bf16: image side must be a multiple of the patch size");
-    const int64_t G = S / ps, P = G * G, K = 3 * ps * ps;
+    OWL_CHECK_ARG(S % ps == 0 && ps >= 8 && ps <= 64, "owl_patch_embed_bf16: image side must be a multiple of the patch size, 8 <= patch size <= 64");
+    const int64_t G = S / ps, P = G * G;
+    int64_t psp = 8; while (psp < ps) psp *= 2;
+    const int64_t K = 3 * ps * psp, Kg = (K + BK - 1) / BK * BK;
     OWL_CHECK_ARG(D % 8 == 0 && Tp >= P + 1, "owl_patch_embed_bf16: D %% 8, Tp");
     OWL_CHECK_ARG(B * 3 * S * S * 2 < (1LL << 32) && B * P < (1LL << 31), "owl_patch_embed_bf16: image batch beyond 4 GiB (32-bit gather offsets)");
-    const bool fused = ps >= 8 && (ps & (ps - 1)) == 0 && K % BK == 0;
+    OWL_CHECK_ARG(tile == 0 || tile == 7 || tile == 256 || tile == 128, "owl_patch_embed_bf16: tile must be 0 (auto), 7, 256 or 128");
+    const bool pow2 = psp == ps;
     GemmP p{};
     p.bias = nullptr; p.out = x_out; p.ldo = D; p.M = B * P; p.N = D; p.alpha = 1.f;
     p.Tp = Tp; p.P = P; p.G = G; p.ps = ps; p.S = S; p.pos = pos;
     p.W = (const bf16_t*)w_pe; p.w_rows = D; p.a_rows = B * P;
-    if (fused) {
-        p.A = (const bf16_t*)image_bf16; p.lda = 0; p.ldw = K; p.K = K;
-        p.ps_log2 = 0; while ((1LL << p.ps_log2) < ps) p.ps_log2++;
-        p.kt_per_split = (int)(K / BK);
-        p.nsplit = 1;
-        // big problems: the two-phase ping-pong kernel (same bits); tile = 256 / 128 pins the single-phase kernels, 7 the ping-pong one
-        const bool pp2 = tile == 7 || (tile == 0 && p.M >= 512 && D >= 256 && K >= 128 && ((p.M + 255) / 256) * ((D + 255) / 256) >= 48);
-        OWL_CHECK_ARG(tile == 0 || tile == 7 || tile == 256 || tile == 128, "owl_patch_embed_bf16: tile must be 0 (auto), 7, 256 or 128");
-        if (pp2 && K >= 128) return owl_gemm_pp2_launch((hipStream_t)stream, EPI_PATCH_F32, p);
-        return launch<EPI_PATCH_F32>((hipStream_t)stream, p, 1, tile);
-    }
-    OWL_CHECK_ARG(scratch, "owl_patch_embed_bf16: patch size %lld needs the im2row scratch buffer", (long long)ps);
-    const int64_t Kpad = (K + BK - 1) / BK * BK;
-    hipLaunchKernelGGL(im2row_kernel, dim3((unsigned)(B * P)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)image_bf16, (bf16_t*)scratch,
-                       B, (int)S, (int)ps, (int)G, (int)K, (int)Kpad);
-    OWL_LAUNCH_CHECK();
-    p.A = (const bf16_t*)scratch; p.lda = Kpad; p.ldw = Kpad; p.K = Kpad;
-    p.kt_per_split = (int)(Kpad / BK);
+    p.ps_log2 = 0; while ((1LL << p.ps_log2) < psp) p.ps_log2++;
+    p.ps_magic = (int)(65536 / ps + 1);
+    p.A = (const bf16_t*)image_bf16; p.lda = 0; p.ldw = Kg; p.K = Kg;
+    p.kt_per_split = (int)(Kg / BK);
     p.nsplit = 1;
-    OWL_CHECK_ARG(tile == 0 || tile == 7 || tile == 256 || tile == 128, "owl_patch_embed_bf16: tile must be 0 (auto), 7, 256 or 128");
+    // big problems: the two-phase ping-pong kernel (same bits); tile = 256 / 128 pins the single-phase kernels, 7 the ping-pong one
     const bool pp2 = tile == 7 || (tile == 0 && p.M >= 512 && D >= 256 && ((p.M + 255) / 256) * ((D + 255) / 256) >= 48);
-    if (pp2 && Kpad >= 128) return owl_gemm_pp2_launch((hipStream_t)stream, EPI_PATCHM_F32, p);
+    if (pp2 && Kg >= 128) return owl_gemm_pp2_launch((hipStream_t)stream, EPI_PATCH_F32, p);
+    if (pow2) return launch<EPI_PATCH_F32>((hipStream_t)stream, p, 1, tile);           // (the single-phase kernels gather 2^n patch rows themselves)
+    OWL_CHECK_ARG(scratch, "owl_patch_embed_bf16: patch size %lld on a single-phase kernel (tile %d, or a problem too small for the ping-pong kernel) needs the im2row scratch buffer",
+                  (long long)ps, tile);
+    hipLaunchKernelGGL(im2row_kernel, dim3((unsigned)(B * P)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)image_bf16, (bf16_t*)scratch,
+                       B, (int)S, (int)ps, (int)psp, (int)G, (int)K, (int)Kg);
+    OWL_LAUNCH_CHECK();
+    p.A = (const bf16_t*)scratch; p.lda = Kg;
     return launch<EPI_PATCHM_F32>((hipStream_t)stream, p, 1, tile);
 }

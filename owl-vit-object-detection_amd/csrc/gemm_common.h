@@ -11,12 +11,12 @@ enum {
     EPI_F32 = 4,         // out f32 = alpha*acc (+ bias)
     EPI_ATOMIC_F32 = 5,  // atomicAdd(out f32, alpha*acc)            (split-K)
     EPI_TRANS_BF16 = 6,  // out_t[b][n][t] bf16 = acc + bias, m = b*Tp + t   (per-head transposed)
-    EPI_PATCH_F32 = 7,   // A gathered from image patches; out f32 [b*Tp + 1 + p][n] = acc + pos[1+p][n]
+    EPI_PATCH_F32 = 7,   // A gathered from image patches (any patch size >= 8: rows padded to 2^n in the K index only); out f32 [b*Tp + 1 + p][n] = acc + pos[1+p][n]
     EPI_DQGELU_BF16 = 8, // out bf16 = acc * quick_gelu'(aux u)
     EPI_DGELU_BF16 = 9,  // out bf16 = acc * gelu_erf'(aux u)
     EPI_ACC_F32 = 10,    // out f32 += acc   (resid == out)
     EPI_SLAB_F32 = 11,   // split-K partial: out f32 [split][M][N] = alpha*acc   (reduced by owl_slab_reduce)
-    EPI_PATCHM_F32 = 12, // as EPI_PATCH_F32 but A is an explicit im2row matrix (patch sizes that are not 2^n, e.g. L/14)
+    EPI_PATCHM_F32 = 12, // as EPI_PATCH_F32 but A is an explicit im2row matrix in the same padded-row K order (the single-phase REFERENCE kernels for patch sizes that are not 2^n, e.g. L/14)
 };
 
 struct GemmP {
@@ -31,7 +31,8 @@ struct GemmP {
     float alpha;
     int64_t Tp;            // EPI_TRANS: rows per image
     int64_t P, G, ps, S;   // EPI_PATCH: patches / grid / patch size / image side
-    int ps_log2;
+    int ps_log2;           // log2 of the PADDED patch-row length psp (= ps for power-of-two patch sizes)
+    int ps_magic;          // 65536 / ps + 1: R / ps == (R * ps_magic) >> 16 for the gather's row index R < 3 ps + 8 (patch sizes that are not 2^n)
     const float* pos;      // [T, N]
     int64_t slab_stride;   // EPI_SLAB: elements per split slab
     int dbg;               // read by the kernels of an OWL_TUNING build only: bit 1 = stores wrapped into a cache-resident window, bit 2 = non-temporal bf16 stores

@@ -77,10 +77,17 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
     const bf16_t* w_base = nullptr;
     const float* b_base = nullptr;
     const bool has_bias = p.bias != nullptr;
-    // EPI_PATCH_F32: A is gathered straight from the image (power-of-two patch sizes): row m = (b, py, px), k = (channel, ky, kx); a 16-byte chunk
-    // is 8 pixels of one patch row and a K-tile is 64 / ps patch rows of one channel -- the lane's part of the address (patch origin + the chunk's
-    // row / column inside the K-tile) is K-tile-invariant, the K-tile's part (channel, first row) is wave-uniform: same scheme as a plain A matrix.
+    // EPI_PATCH_F32: A is gathered straight from the image: row m = (b, py, px), k = (channel, ky, kx); a 16-byte chunk is 8 pixels of one patch row.
+    // Power-of-two patch sizes: a K-tile is 64 / ps patch rows of ONE channel -- the lane's part of the address (patch origin + the chunk's row / column
+    // inside the K-tile) is K-tile-invariant, the K-tile's part (channel, first row) is wave-uniform: same scheme as a plain A matrix.
+    // Other patch sizes (L/14: 14-pixel rows = 28 bytes): the K index pads every patch row to psp = 2^n positions (14 -> 16, K = 3 * 14 * 16 = 672 -> 704) and
+    // chunk cc of a row starts at pixel min(8 cc, ps - 8): the last chunk OVERLAPS its predecessor instead of running past the row (positions 8, 9 of a 14-pixel
+    // row are pixels 6, 7 again) and the weight matrix holds zeros at the duplicated positions (weights.patch_weight_gather_layout) -- no read outside the
+    // patch, no garbage-times-zero.  A K-tile's 64 / psp rows may straddle two channels, so the row part of the address (channel, ky) is formed per K-tile and
+    // lane from the row index R = K-tile * rows + lane's row (R / ps by multiply-shift).  The 16-byte pieces are only 4-byte aligned in HBM (28 px + 12 bytes).
     constexpr bool GATHER = (EPI == EPI_PATCH_F32);
+    const bool np2 = GATHER && p.ps != (int64_t(1) << p.ps_log2);      // (uniform)
+    int a_j[2] = {0, 0};                                        // np2: the lane's row inside a K-tile, per q (the chunk swizzle depends on q, not on the half)
     auto stage_A = [&]() {                                     // 4 VMEM ops
         if (a_k == 0) {
             int tm, tn_unused; decode(a_item, tm, tn_unused);
@@ -98,7 +105,8 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
                         const unsigned P32 = (unsigned)p.P, G32 = (unsigned)p.G, S32 = (unsigned)p.S, ps32 = (unsigned)p.ps;
                         const unsigned b = (unsigned)am / P32, pp = (unsigned)am - b * P32;
                         const unsigned py = pp / G32, px = pp - py * G32;
-                        const unsigned ky = (unsigned)(c * 8) >> p.ps_log2, kx = (unsigned)(c * 8) & ((1u << p.ps_log2) - 1u);
+                        unsigned ky = (unsigned)(c * 8) >> p.ps_log2, kx = (unsigned)(c * 8) & ((1u << p.ps_log2) - 1u);
+                        if (np2) { a_j[q] = (int)ky; ky = 0; kx = min(kx, ps32 - 8u); }        // (row part added per K-tile; the last chunk overlaps instead of overrunning)
                         a_voff[h][q] = ((((b * 3u) * S32 + py * ps32 + ky) * S32) + px * ps32 + kx) * 2u;
                     } else {
                         a_voff[h][q] = (unsigned)(((am - m0) * p.lda + c * 8) * 2);
@@ -107,10 +115,22 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
         }
         unsigned char* base = lds + a_buf * Q_STAGE;
         int64_t koff = (int64_t)a_k * QBK;                     // elements from a_base to the K-tile
+        unsigned roff[2] = {0u, 0u};                           // np2: byte offset of the lane's patch row (channel, ky) of this K-tile, per q
         if constexpr (GATHER) {
-            const int k = a_k * QBK;
-            const int ch = k >> (2 * p.ps_log2), ky = (k & ((1 << (2 * p.ps_log2)) - 1)) >> p.ps_log2;
-            koff = ((int64_t)ch * p.S + ky) * p.S;
+            if (np2) {
+                koff = 0;
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    unsigned R = (unsigned)(a_k * (QBK >> p.ps_log2) + a_j[q]);
+                    R = min(R, 3u * (unsigned)p.ps - 1u);                     // (the K padding's rows: any row of the patch, their weights are zero)
+                    const unsigned ch = (R * (unsigned)p.ps_magic) >> 16, ky = R - ch * (unsigned)p.ps;
+                    roff[q] = ((ch * (unsigned)p.S + ky) * (unsigned)p.S) * 2u;
+                }
+            } else {
+                const int k = a_k * QBK;
+                const int ch = k >> (2 * p.ps_log2), ky = (k & ((1 << (2 * p.ps_log2)) - 1)) >> p.ps_log2;
+                koff = ((int64_t)ch * p.S + ky) * p.S;
+            }
         }
         const unsigned char* g = (const unsigned char*)(a_base + koff);
         if (!abl_nodma || abl_prologue) {
@@ -118,7 +138,7 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
         for (int h = 0; h < 2; h++)
 #pragma unroll
             for (int q = 0; q < 2; q++)
-                __builtin_amdgcn_global_load_lds(GPTR(g + a_voff[h][q]), LPTR(base + (h * 128 + (w * 2 + q) * 8) * 128), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(GPTR(g + (a_voff[h][q] + roff[q])), LPTR(base + (h * 128 + (w * 2 + q) * 8) * 128), 16, 0, 0);
         }
         a_buf ^= 1;
         if (++a_k == nk) { a_k = 0; a_item += item_step; }

