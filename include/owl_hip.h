@@ -49,7 +49,8 @@ int owl_abi_version(void);
  * tile: kernel choice, per call (no global state): 0 = automatic (large shapes: 256x256x64 tiles on the two-phase ping-pong schedule, 8 waves,
  *       gemm_pp2.hip -- for narrow outputs with the remainder round on half-height 128x256 tiles, gemm_pph.hip --; 128x128x64 otherwise); tests pin one
  *       kernel with 128 | 256 (the single-phase REFERENCE kernel every other one is held to, bit for bit) | 7 (two-phase ping-pong on the whole
- *       problem).  All give identical bits.  (8, 9, 5, 4: the round-1 four-phase ping-pong, the round-4 free-running and the four-wave experiments,
+ *       problem) | 6 (= 0, plus: a problem of at most 128 tiles of 256 x 256 -- half a round of the 256 CUs -- runs every tile as two half-height tiles;
+ *       for callers that know nothing else is in flight: batch 1 / 2, one stream).  All give identical bits.  (8, 9, 5, 4: the round-1 four-phase ping-pong, the round-4 free-running and the four-wave experiments,
  *       OWL_TUNING builds only.)                                                                                                                   */
 int owl_gemm_nt_bf16(void* stream, int epi, const void* A, int64_t lda, int64_t a_rows, const void* W, int64_t ldw, int64_t w_rows, const float* bias, void* out, int64_t ldo, const float* resid, void* aux, int64_t ld_aux, int64_t M, int64_t N, int64_t K, float alpha, int splits, int64_t Tp, int tile);
 /* epi 11 = split-K partial slabs out[split][M][ldo] (f32, no atomics); reduce them with owl_slab_reduce */

@@ -60,6 +60,12 @@ class OwlLibError(RuntimeError):
 
 _lib = None
 _protos = None
+_TUNING_PROBE = "owl_gemm_set_persistent"          # exported by OWL_TUNING builds only (csrc/gemm.hip)
+
+
+def is_tuning_build() -> bool:
+    """True if the loaded libowlhip.so is an OWL_TUNING build (tools/ experiments); the shipped library is not."""
+    return hasattr(load(), _TUNING_PROBE)
 
 
 def load():
@@ -72,7 +78,12 @@ def load():
             "(or owl-vit-object-detection_amd/csrc/build.sh). There is no CPU fallback.")
     lib = ctypes.CDLL(LIB_PATH)
     _protos = parse_header()
-    if os.environ.get("OWL_TUNING", "0") == "1":
+    # The tuning entries (include/owl_hip_tuning.h) are bound when the LOADED library is a tuning build -- decided from what it exports, not from the
+    # environment (OWL_TUNING=1 beside a shipped build used to die on a missing symbol, the reverse refused calls the library has)
+    tuning = hasattr(lib, _TUNING_PROBE)
+    if os.environ.get("OWL_TUNING", "0") == "1" and not tuning:
+        raise OwlLibError(f"OWL_TUNING=1 but {LIB_PATH} is the shipped build (no `{_TUNING_PROBE}`): rebuild it with OWL_TUNING=1 bash csrc/build.sh, or unset OWL_TUNING")
+    if tuning:
         _protos.update(parse_header(TUNING_HEADER))
     for name, (ret, args) in _protos.items():
         try:

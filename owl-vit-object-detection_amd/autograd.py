@@ -246,15 +246,15 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
                 r0, Mc = b0 * Tp, nb * Tp
                 R = lambda t: t[r0:r0 + Mc]
                 with torch.cuda.stream(s_):
-                    ops.gemm(ops.EPI_DQGELU_BF16, R(bw["dxb"]), fz[f"{i}.w2T"], R(bw["du"]), aux=R(Ls["u"]), M=Mc, N=I, K=D)
-                    ops.gemm(ops.EPI_BIAS_BF16, R(bw["du"]), fz[f"{i}.w1T"], R(bw["dh"]), M=Mc, N=D, K=I)
+                    ops.gemm(ops.EPI_DQGELU_BF16, R(bw["dxb"]), fz[f"{i}.w2T"], R(bw["du"]), aux=R(Ls["u"]), M=Mc, N=I, K=D, concurrency=len(chunks))
+                    ops.gemm(ops.EPI_BIAS_BF16, R(bw["du"]), fz[f"{i}.w1T"], R(bw["dh"]), M=Mc, N=D, K=I, concurrency=len(chunks))
                     # (the LayerNorm backward also writes the bf16 copy of its dx: the operand of the next dX GEMM, no separate cast pass)
                     ops.layernorm_bwd(R(bw["dh"]), R(Ls["x_mid"]), R(Ls["st2"]), P_[pre + "layer_norm2.weight"], R(bw["dx"]), R(bw["dxm"]), None, None,
                                       Mc, D, dx_bf16=R(bw["dxb"]))
-                    ops.gemm(ops.EPI_BIAS_BF16, R(bw["dxb"]), fz[f"{i}.woT"], R(bw["datt"]), M=Mc, N=D, K=D)
+                    ops.gemm(ops.EPI_BIAS_BF16, R(bw["dxb"]), fz[f"{i}.woT"], R(bw["datt"]), M=Mc, N=D, K=D, concurrency=len(chunks))
                     ops.attention_bwd(R(Ls["qkv"]), R(bw["datt"]), R(Ls["att"]), Ls["lse"][b0:b0 + nb], bw["dvec"][b0:b0 + nb], R(bw["dqkv"]),
                                       nb, H, T, Tp, scale)
-                    ops.gemm(ops.EPI_BIAS_BF16, R(bw["dqkv"]), fz[f"{i}.wqkvT"], R(bw["dh"]), M=Mc, N=D, K=3 * D)
+                    ops.gemm(ops.EPI_BIAS_BF16, R(bw["dqkv"]), fz[f"{i}.wqkvT"], R(bw["dh"]), M=Mc, N=D, K=3 * D, concurrency=len(chunks))
                     ops.layernorm_bwd(R(bw["dh"]), R(Ls["x_in"]), R(Ls["st1"]), P_[pre + "layer_norm1.weight"], R(bw["dxm"]), R(bw["dx"]), None, None,
                                       Mc, D, dx_bf16=R(bw["dxb"]))
         for c, s_ in enumerate(streams):
@@ -285,16 +285,17 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
     if cfg.trainable_layer() != cfg.layers - 1:     # (the last layer's fc2 bias gradient came out of merge_ln_bwd)
         ops.colsum_f32(bw["dx"], G(tl + "mlp.fc2.bias"), M, D, partials=bw["part"])
     on_side(0, lambda: dW(bw["dxb"], Lt["g"], G(tl + "mlp.fc2.weight"), D, I, M, Mp, part="part2"))
-    ops.gemm(ops.EPI_DQGELU_BF16, bw["dxb"], wT(tl + "mlp.fc2.weight", D, I), bw["du"], aux=Lt["u"], M=M, N=I, K=D)
+    dxc = 1 if side is main else 2          # (the weight-gradient GEMMs run beside the dX chain: ops.gemm's small-problem rule counts them)
+    ops.gemm(ops.EPI_DQGELU_BF16, bw["dxb"], wT(tl + "mlp.fc2.weight", D, I), bw["du"], aux=Lt["u"], M=M, N=I, K=D, concurrency=dxc)
     on_side(1, lambda: dW(bw["du"], Lt["h2"], G(tl + "mlp.fc1.weight"), I, D, M, Mp, G(tl + "mlp.fc1.bias"), part="part2"))
-    ops.gemm(ops.EPI_BIAS_BF16, bw["du"], wT(tl + "mlp.fc1.weight", I, D), bw["dh"], M=M, N=D, K=I)
+    ops.gemm(ops.EPI_BIAS_BF16, bw["du"], wT(tl + "mlp.fc1.weight", I, D), bw["dh"], M=M, N=D, K=I, concurrency=dxc)
     ops.layernorm_bwd(bw["dh"], Lt["x_mid"], Lt["st2"], P_[tl + "layer_norm2.weight"], bw["dx"], bw["dxm"],
                       G(tl + "layer_norm2.weight"), G(tl + "layer_norm2.bias"), M, D, dx_bf16=bw["dxb2"], partials=bw["part"],
                       dx_colsum=G(tl + "self_attn.out_proj.bias"))     # (dx here = d(x + out-proj output): its column sums are that bias's gradient)
     # attention
     on_side(2, lambda: dW(bw["dxb2"], Lt["att"], G(tl + "self_attn.out_proj.weight"), D, D, M, Mp, part="part2"))
     woT = wT(tl + "self_attn.out_proj.weight", D, D)
-    ops.gemm(ops.EPI_BIAS_BF16, bw["dxb2"], woT, bw["datt"], M=M, N=D, K=D)
+    ops.gemm(ops.EPI_BIAS_BF16, bw["dxb2"], woT, bw["datt"], M=M, N=D, K=D, concurrency=dxc)
     ops.attention_bwd(Lt["qkv"], bw["datt"], Lt["att"], Lt["lse"], bw["dvec"], bw["dqkv"], B, H, T, Tp,
                       cfg.head_dim ** -0.5)
     o = model.flat_offsets[tl + "self_attn.q_proj.weight"]
@@ -305,7 +306,7 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
     wqkv = model.flat_bf16[o: o + 3 * D * D].view(3 * D, D)
     wqkvT = bw["wT"][: 3 * D * D].view(D, 3 * D)
     ops.transpose_bf16(wqkv, wqkvT, 3 * D, D)
-    ops.gemm(ops.EPI_BIAS_BF16, bw["dqkv"], wqkvT, bw["dh"], M=M, N=D, K=3 * D)
+    ops.gemm(ops.EPI_BIAS_BF16, bw["dqkv"], wqkvT, bw["dh"], M=M, N=D, K=3 * D, concurrency=dxc)
     # everything below layer_norm1 is frozen: only its affine parameters need gradients
     ops.layernorm_bwd(bw["dh"], Lt["x_in"], Lt["st1"], P_[tl + "layer_norm1.weight"], None, None,
                       G(tl + "layer_norm1.weight"), G(tl + "layer_norm1.bias"), M, D, partials=bw["part"])

@@ -319,14 +319,15 @@ OWL_API int owl_gemm_nt_bf16(void* stream, int epi, const void* A, int64_t lda, 
                                 float alpha, int splits, int64_t Tp, int tile) {
     OWL_CHECK_ARG(A && W && out, "owl_gemm_nt_bf16: null pointer");
 #ifdef OWL_TUNING
-    OWL_CHECK_ARG(tile == 0 || tile == 128 || tile == 256 || tile == 8 || tile == 9 || tile == 4 || tile == 7 || tile == 5, "owl_gemm_nt_bf16: tile must be 0 (auto), 128, 256, 7 (or, tuning builds, 8, 9, 5, 4)");
+    OWL_CHECK_ARG(tile == 0 || tile == 128 || tile == 256 || tile == 8 || tile == 9 || tile == 4 || tile == 7 || tile == 5 || tile == 6, "owl_gemm_nt_bf16: tile must be 0 (auto), 6, 128, 256, 7 (or, tuning builds, 8, 9, 5, 4)");
 #else
-    OWL_CHECK_ARG(tile == 0 || tile == 128 || tile == 256 || tile == 7, "owl_gemm_nt_bf16: tile must be 0 (auto), 128, 256 or 7 (8, 9, 5, 4: the four-phase ping-pong, free-running and four-wave "
+    OWL_CHECK_ARG(tile == 0 || tile == 6 || tile == 128 || tile == 256 || tile == 7, "owl_gemm_nt_bf16: tile must be 0 (auto), 6, 128, 256 or 7 (8, 9, 5, 4: the four-phase ping-pong, free-running and four-wave "
                                                                       "experiments exist only in an OWL_TUNING build)");
     OWL_CHECK_ARG(epi != EPI_TRANS_BF16 && epi != EPI_ATOMIC_F32, "owl_gemm_nt_bf16: epilogues 5 (f32 atomics) and 6 (per-head transposed) exist only in an OWL_TUNING build "
                                                                     "(the train path uses split-K slabs and reads V row-major)");
 #endif
-    const int g_force_tile = tile;
+    const bool want_half = tile == 6;          // 6 = automatic + "half-height tiles if the whole problem is at most half a round" (see below)
+    const int g_force_tile = want_half ? 0 : tile;
     OWL_CHECK_ARG(K > 0 && K % BK == 0, "owl_gemm_nt_bf16: K=%lld must be a positive multiple of 64", (long long)K);
     OWL_CHECK_ARG(M > 0 && N > 0 && N % 8 == 0, "owl_gemm_nt_bf16: bad M=%lld N=%lld (N %% 8 == 0)", (long long)M, (long long)N);
     OWL_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0, "owl_gemm_nt_bf16: lda/ldw must be multiples of 8 elements");
@@ -386,9 +387,11 @@ OWL_API int owl_gemm_nt_bf16(void* stream, int epi, const void* A, int64_t lda, 
         // dense (GELU epilogue), +0.8 % out-proj (K = 768); nothing for wide outputs (QKV N = 2304: -0.1 %, fc1: does not fit one round), where
         // the half-height tiles -- latency-bound, ~0.85 of a full tile's time, not 0.56 -- only just pay for the second launch.  Hence the
         // automatic rule: narrow outputs only (N <= 1024); tile = 9 forces the split wherever it fits, tile = 8 never splits.
-        // Small problems (the reference's own batch size of 1: QKV = 90 tiles, fc1 = 120 on 256 CUs): no more 256 x 256 tiles than HALF the CUs -> every tile
-        // goes out as two half-height tiles (gemm_pph.hip), one partial round of ~0.85 tile times on twice the CUs.  Same K order and epilogue: bit-identical.
-        if (g_force_tile == 0 && a_rows >= M && 2 * ((M + 255) / 256) * ((N + 255) / 256) <= 256) {
+        // tile = 6 -- small problems (the reference's own batch size of 1: QKV = 90 tiles, fc1 = 120 on 256 CUs): no more 256 x 256 tiles than HALF the CUs ->
+        // every tile goes out as two half-height tiles (gemm_pph.hip), one partial round of ~0.85 tile times on twice the CUs.  Same K order and epilogue:
+        // bit-identical.  Asked for by the CALLER, who knows what else is in flight: with two sub-batch streams the other stream's tiles already fill the idle
+        // CUs and the half-height split loses (forward batch 8: -2.7 %; alone: +3.3 % / +4.5 % on the batch-1 train step / forward, profiles/r05_small_batch.md).
+        if (want_half && a_rows >= M && 2 * ((M + 255) / 256) * ((N + 255) / 256) <= 256) {
             const int rc = owl_gemm_pph_launch(s, epi, p);
             if (rc <= 0) return rc;      // 1 = epilogue not handled by the half-height kernel: the 256 x 256 kernel below
         }

@@ -401,10 +401,11 @@ class OwlViT(nn.Module):
         # (V^T; Q^T, K^T, dO^T) out of the row-major tiles with the LDS hardware transpose (ds_read_b64_tr_b16): no transposed
         # copy of anything exists in HBM.
         qkv_l = R(Ls["qkv"]) if sv else R(ws["qkv"])
-        ops.gemm(ops.EPI_BIAS_BF16, h, lw["wqkv"], qkv_l, bias=lw["bqkv"], M=M, N=3 * D, K=D, ldo=3 * D)
+        cc = st.get("conc", 1)          # sub-batch streams in flight: small problems running ALONE take half-height GEMM tiles (ops.gemm)
+        ops.gemm(ops.EPI_BIAS_BF16, h, lw["wqkv"], qkv_l, bias=lw["bqkv"], M=M, N=3 * D, K=D, ldo=3 * D, concurrency=cc)
         att_l = R(Ls["att"]) if sv else R(ws["att"])
         ops.attention_fwd_vrow(qkv_l, qkv_l[:, D:], qkv_l[:, 2 * D:], 3 * D, att_l, D, Ls["lse"][b0:b0 + nb] if sv else None, nb, H, T, Tp, scale)
-        ops.gemm(ops.EPI_BIAS_BF16, att_l, lw["wo"], d1, bias=lw["bo"], M=M, N=D, K=D)
+        ops.gemm(ops.EPI_BIAS_BF16, att_l, lw["wo"], d1, bias=lw["bo"], M=M, N=D, K=D, concurrency=cc)
         x_mid = R(Ls["x_mid"]) if sv else x_cur
         h2 = R(Ls["h2"]) if full else R(ws["h"])
         # A frozen layer's x + delta1 is read by nobody but the next LayerNorm: it is not stored (4 bytes per element), that
@@ -414,8 +415,8 @@ class OwlViT(nn.Module):
         ops.layernorm(x_cur, lw["g2"], lw["be2"], h2, M, D, R(Ls["st2"]) if sv else None, cfg.ln_eps, delta=d1, x_out=x_mid,
                       store_x=not defer)
         g_l = R(Ls["g"]) if full else R(ws["g"])
-        ops.gemm(ops.EPI_QGELU_BF16, h2, lw["w1"], g_l, bias=lw["b1"], aux=R(Ls["u"]) if sv else None, M=M, N=I, K=D)
-        ops.gemm(ops.EPI_BIAS_BF16, g_l, lw["w2"], d2, bias=lw["b2"], M=M, N=D, K=I)
+        ops.gemm(ops.EPI_QGELU_BF16, h2, lw["w1"], g_l, bias=lw["b1"], aux=R(Ls["u"]) if sv else None, M=M, N=I, K=D, concurrency=cc)
+        ops.gemm(ops.EPI_BIAS_BF16, g_l, lw["w2"], d2, bias=lw["b2"], M=M, N=D, K=I, concurrency=cc)
         st["pending"], st["xs"] = d2, x_mid
         st["pending1"] = d1 if defer else None
 
@@ -471,7 +472,7 @@ class OwlViT(nn.Module):
             self._fork_ev.record(main)
         states = []
         for c, (b0, nb) in enumerate(chunks):
-            st = dict(b0=b0, nb=nb, stream=main if c == 0 else self._side_stream(c), xs=x[b0 * Tp:(b0 + nb) * Tp], pending=None, pending1=None)
+            st = dict(b0=b0, nb=nb, stream=main if c == 0 else self._side_stream(c), xs=x[b0 * Tp:(b0 + nb) * Tp], pending=None, pending1=None, conc=len(chunks))
             if c > 0:
                 st["stream"].wait_event(self._fork_ev)
             states.append(st)

@@ -40,8 +40,10 @@ def _chk(t, dtype, name):
 
 
 def gemm(epi, A, W, out, bias=None, resid=None, aux=None, M=None, N=None, K=None, lda=None, ldw=None, ldo=None,
-         ld_aux=0, a_rows=None, w_rows=None, alpha=1.0, splits=1, Tp=0, tile=None):
-    """out = epilogue(A[M,K] @ W[N,K]^T).  A/W bf16; see include/owl_hip.h for epilogues."""
+         ld_aux=0, a_rows=None, w_rows=None, alpha=1.0, splits=1, Tp=0, tile=None, concurrency=None):
+    """out = epilogue(A[M,K] @ W[N,K]^T).  A/W bf16; see include/owl_hip.h for epilogues.
+    concurrency: how many launches like this one the caller has in flight at once (sub-batch streams).  If their 256 x 256 tiles together fill at most half
+    the chip's 256 CUs, the automatic kernel choice becomes tile 6 (half-height tiles; include/owl_hip.h): the library cannot know what else is running."""
     _chk(A, torch.bfloat16, "A"); _chk(W, torch.bfloat16, "W"); _chk(bias, torch.float32, "bias")
     K = K if K is not None else A.shape[-1]
     N = N if N is not None else W.shape[0]
@@ -53,8 +55,11 @@ def gemm(epi, A, W, out, bias=None, resid=None, aux=None, M=None, N=None, K=None
     w_rows = w_rows if w_rows is not None else W.shape[0]
     if aux is not None and ld_aux == 0:
         ld_aux = aux.shape[-1]
+    tile = int(GEMM_TILE if tile is None else tile)
+    if tile == 0 and concurrency is not None and 2 * int(concurrency) * ((M + 255) // 256) * ((N + 255) // 256) <= 256:
+        tile = 6
     _lib.call("owl_gemm_nt_bf16", stream(), epi, A, lda, a_rows, W, ldw, w_rows, bias, out, ldo, resid, aux, ld_aux,
-              M, N, K, float(alpha), int(splits), int(Tp), int(GEMM_TILE if tile is None else tile))
+              M, N, K, float(alpha), int(splits), int(Tp), tile)
     return out
 
 
@@ -83,9 +88,8 @@ def layernorm(x, gamma, beta, out, rows, D, stats=None, eps=1e-5, delta=None, x_
 
 
 def _tuning_only(what):
-    import os
-    if os.environ.get("OWL_TUNING", "0") != "1":
-        raise RuntimeError(f"{what} exists only in an OWL_TUNING build of libowlhip.so (OWL_TUNING=1 bash csrc/build.sh, run with OWL_TUNING=1)")
+    if not _lib.is_tuning_build():
+        raise RuntimeError(f"{what} exists only in an OWL_TUNING build of libowlhip.so (OWL_TUNING=1 bash csrc/build.sh); the loaded library is the shipped build")
 
 
 def attention_fwd(q, k, ld_qk, vt, vt_img_stride, out, ld_out, lse, B, H, T, Tp, scale):

@@ -8,6 +8,16 @@ import pytest
 from owl_vit_object_detection_amd import _lib
 
 
+def _TUNING_BUILD():
+    """Is the loaded libowlhip.so an OWL_TUNING build?  Asked of the library, not of the environment."""
+    from owl_vit_object_detection_amd import _lib as _L
+    try:
+        return _L.is_tuning_build()
+    except _L.OwlLibError:
+        return False
+
+
+
 @pytest.fixture(scope="module")
 def built():
     if not os.path.exists(_lib.LIB_PATH):
@@ -41,7 +51,7 @@ def test_no_process_global_setters_in_the_product_abi(built):
     for name in banned:
         assert name not in protos, name
     assert not any("_set_" in n or "_debug" in n for n in protos), [n for n in protos if "_set_" in n or "_debug" in n]
-    if os.environ.get("OWL_TUNING", "0") != "1":
+    if not _TUNING_BUILD():
         lib = ctypes.CDLL(_lib.LIB_PATH)
         for name in banned:
             assert not hasattr(lib, name), f"{name} exported by the default build"
@@ -103,7 +113,7 @@ def test_dynamic_symbol_table_holds_only_the_c_abi(built):
     declared = set(_lib.parse_header())
     stray = sorted(n for n in defined if not n.startswith("owl_"))
     assert stray == [], stray[:10]
-    if os.environ.get("OWL_TUNING", "0") != "1":
+    if not _TUNING_BUILD():
         assert defined == declared, (sorted(defined - declared), sorted(declared - defined))
 
 

@@ -8,6 +8,16 @@ pytestmark = pytest.mark.gpu
 
 from owl_vit_object_detection_amd import ops  # noqa: E402
 
+
+def _TUNING_BUILD():
+    """Is the loaded libowlhip.so an OWL_TUNING build?  Asked of the library, not of the environment."""
+    from owl_vit_object_detection_amd import _lib as _L
+    try:
+        return _L.is_tuning_build()
+    except _L.OwlLibError:
+        return False
+
+
 DEV = "cuda"
 
 
@@ -73,7 +83,7 @@ def test_gemm_pingpong_matches_tile256_bitwise(N, K, epi):
         return out
 
     import os
-    tuning = os.environ.get("OWL_TUNING", "0") == "1"
+    tuning = _TUNING_BUILD()
     ref = run(256)                                      # the single-phase reference kernel: every other kernel is held to its bits
     # the automatic rule: whole rounds on the two-phase 256 x 256 ping-pong kernel + (N <= 1024) the remainder rows on the half-height (128 x 256)
     # variant (N = 768: 867 tiles = 3 rounds + 99 tiles -> 198 half tiles), csrc/gemm_pp2.hip + csrc/gemm_pph.hip
@@ -91,6 +101,36 @@ def test_gemm_pingpong_matches_tile256_bitwise(N, K, epi):
     # ahead / B pieces two ahead on separate DMA cursors); every epilogue but the transposing one
     for _ in range(12):
         assert torch.equal(run(7), ref)
+
+
+@pytest.mark.parametrize("images", [1, 2, 4])
+@pytest.mark.parametrize("N,K,epi,with_aux", [(2304, 768, ops.EPI_BIAS_BF16, False), (3072, 768, ops.EPI_QGELU_BF16, True), (768, 3072, ops.EPI_BIAS_BF16, False),
+                                              (3072, 768, ops.EPI_DQGELU_BF16, True), (768, 768, ops.EPI_GELU_BF16, False)])
+def test_gemm_small_problem_half_height_tiles_match_tile256_bitwise(images, N, K, epi, with_aux):
+    """the reference's own batch size (1) and its neighbours leave most of the 256 CUs without a 256 x 256 tile (QKV: 90 tiles).  `tile = 6` --
+    what `ops.gemm(concurrency=...)` picks when the caller's launches in flight fill at most half the chip -- runs such a problem as half-height tiles
+    (csrc/gemm_pph.hip on the whole problem) and must give the bits of the single-phase reference kernel; where the rule does not apply (more than 128
+    tiles, an epilogue without a half-height kernel) tile 6 is tile 0."""
+    torch.manual_seed(11 + images)
+    M = images * 2312
+    A = torch.randn(ops.pad_rows(M), K, device=DEV).bfloat16()
+    W = (torch.randn(N, K, device=DEV) * 0.05).bfloat16()
+    bias = None if epi == ops.EPI_DQGELU_BF16 else torch.randn(N, device=DEV)
+    aux_in = torch.randn(ops.pad_rows(M), N, device=DEV).bfloat16() if epi == ops.EPI_DQGELU_BF16 else None
+
+    def run(tile, concurrency=None):
+        out = torch.zeros(ops.pad_rows(M), N, device=DEV, dtype=torch.bfloat16)
+        aux = aux_in if aux_in is not None else (torch.zeros(ops.pad_rows(M), N, device=DEV, dtype=torch.bfloat16) if with_aux else None)
+        ops.gemm(epi, A, W, out, bias=bias, aux=aux, M=M, tile=tile, concurrency=concurrency)
+        torch.cuda.synchronize()
+        return out, (aux if (with_aux and aux_in is None) else None)
+
+    ref, ref_aux = run(256)
+    for _ in range(4):
+        for got, got_aux in (run(6), run(None, concurrency=1), run(None, concurrency=2), run(0)):
+            assert torch.equal(got, ref)
+            assert ref_aux is None or torch.equal(got_aux, ref_aux)
+    assert float(ref[M:].abs().max()) == 0.0 if ref.shape[0] > M else True          # pad rows untouched
 
 
 def test_attention_bwd_bitwise_repeatable():

@@ -11,6 +11,16 @@ pytestmark = pytest.mark.gpu
 
 from owl_vit_object_detection_amd import ops  # noqa: E402
 
+
+def _TUNING_BUILD():
+    """Is the loaded libowlhip.so an OWL_TUNING build?  Asked of the library, not of the environment."""
+    from owl_vit_object_detection_amd import _lib as _L
+    try:
+        return _L.is_tuning_build()
+    except _L.OwlLibError:
+        return False
+
+
 DEV = "cuda"
 
 
@@ -35,7 +45,7 @@ def qgelu(x):
     return x * torch.sigmoid(1.702 * x)
 
 
-_TUNING = os.environ.get("OWL_TUNING", "0") == "1"
+_TUNING = _TUNING_BUILD()
 
 
 @pytest.fixture(params=[128, 256, 7, 0] + ([8, 5] if _TUNING else []), ids=["tile128", "tile256", "pingpong2", "auto"] + (["pingpong", "free-running"] if _TUNING else []))
@@ -91,7 +101,7 @@ def test_gemm_epilogues(gemm_tile):
     ops.gemm(ops.EPI_ACC_F32, A, W, o32, M=M)
     report("acc", o32[:M], 1.5 * acc, 1e-3, 1e-4)
     # split-K atomic (tuning builds only: the train path uses the deterministic slabs below)
-    if os.environ.get("OWL_TUNING", "0") == "1":
+    if _TUNING_BUILD():
         o32.zero_()
         ops.gemm(ops.EPI_ATOMIC_F32, A, W, o32, M=M, splits=3)
         report("atomic", o32[:M], acc, 1e-3, 1e-4)
@@ -116,7 +126,7 @@ def test_gemm_epilogues(gemm_tile):
     report("dgelu", out[:M], acc * g2, 2e-2, 1e-2)
 
 
-@pytest.mark.skipif(os.environ.get("OWL_TUNING", "0") != "1", reason="tuning-build experiment (OWL_TUNING=1 build of libowlhip.so): not in the shipped ABI")
+@pytest.mark.skipif(not _TUNING_BUILD(), reason="tuning-build experiment (OWL_TUNING=1 build of libowlhip.so): not in the shipped ABI")
 def test_gemm_transposed_epilogue(gemm_tile):
     B, Tp, T, K, N = 2, 152, 150, 128, 192          # 3 heads of 64
     M = B * Tp
@@ -454,7 +464,7 @@ def test_add2_layernorm_matches_two_separate_adds():
 def test_attention_fwd_vrow_matches_vt_variant_bitwise(B, H, T):
     """The library default (variant 0) is the plain tiling (variant 1) or the peeled one, selected by T alone.  Tuning builds also carry the round-1
     form that takes V^T per head: V read row-major through the LDS transpose-reads gives its very bits (same MFMAs, same order)."""
-    tuning = os.environ.get("OWL_TUNING", "0") == "1"
+    tuning = _TUNING_BUILD()
     torch.manual_seed(B * 100 + T)
     Tp = (T + 7) // 8 * 8; D = H * 64; M = B * Tp
     qkv = torch.zeros(ops.pad_rows(M), 3 * D, device=DEV, dtype=torch.bfloat16)
@@ -546,6 +556,37 @@ def test_attention_fwd_peeled_offset_paths(spike_key, spike_q, gain):
     report("peeled attn, spiked, vs plain tiling", out[:M].view(B, Tp, D)[:, 1:T], out1[:M].view(B, Tp, D)[:, 1:T], 1e-2, 1e-2)
 
 
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("above_log2,expect_slow", [(60.0, False), (80.0, False), (95.0, True), (120.0, True)])
+def test_attention_fwd_verdict_threshold_at_kernel_level(variant, above_log2, expect_slow):
+    """the stale-offset verdict sits at 2^88 (attention_fwd_common.h) since round 4 -- the spiked-score cases above were sized for the old 2^40 and
+    jump straight to scores of several hundred.  Here ONE key of a later tile scores `above_log2` (log2 domain) above the offset the wave holds, for every query of
+    head 0: 60 and 80 must ride the fast path (slow_tiles == 0: P up to 2^80 beside O accumulators with 2^48 of f32 headroom left) and still match the f32 softmax;
+    95 and 120 must take the slow path (slow_tiles > 0) and match too.  Plain tiling and the class-token-peeled one."""
+    B, H, T = 1, 2, 577
+    Tp = (T + 7) // 8 * 8; D = H * 64; M = B * Tp
+    x = rnd(B, T, 3 * D, seed=int(above_log2) + variant) * 0.05            # base scores ~ 1e-2: the held offset stays 0
+    q0 = 8.0
+    x[0, :, 0] = q0                                                        # head 0, feature 0 of every query
+    x[0, :, D] = 0.0                                                       # ... of every key: 0, but for the one spiking key (tile 4 of the sweep)
+    x[0, 250, D] = above_log2 / (q0 * 0.125 * 1.4426950408889634)
+    qkv = ops.zeros_rows(M, 3 * D, torch.bfloat16, DEV)
+    qkv[:M].view(B, Tp, 3 * D)[:, :T] = x.bfloat16()
+    want, lse_want = _vrow_reference(qkv, B, H, T, Tp)
+    s_spike = float(qkv[250, D].float()) * q0 * 0.125 * 1.4426950408889634
+    assert abs(s_spike - above_log2) < 0.5                                  # (after the bf16 rounding of the key)
+    out = ops.zeros_rows(M, D, torch.bfloat16, DEV); lse = torch.zeros(B, H, Tp, device=DEV)
+    counter = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.attention_fwd_vrow(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, out, D, lse, B, H, T, Tp, 0.125, variant=variant, slow_tiles=counter)
+    torch.cuda.synchronize()
+    slow = int(counter.item())
+    print(f"variant {variant}: spike {s_spike:.1f} (log2) above the held offset -> slow-path tiles {slow}")
+    assert bool(torch.isfinite(out[:M].float()).all()) and bool(torch.isfinite(lse[:, :, :T]).all())
+    report(f"attn, one key 2^{above_log2:.0f} above the offset", out[:M].view(B, Tp, D)[:, :T], want, 2e-2, 2e-2)
+    report("lse", lse[:, :, :T], lse_want, 5e-2, 2e-3)
+    assert (slow > 0) == expect_slow, (slow, above_log2)
+
+
 @pytest.mark.parametrize("B,H,T", [(2, 3, 333), (1, 2, 37), (1, 12, 577), (1, 12, 2305), (2, 4, 2305), (1, 16, 3601)])
 def test_attention_bwd_matches_torch_autograd(B, H, T):
     """dQ / dK / dV of the fused backward (every transposed operand read by the LDS transpose hardware) against f32 autograd of
@@ -609,7 +650,7 @@ def test_layernorm_bwd_matches_torch_autograd(rows, D, bf16_dy):
 
 
 # ---- attention forward, one wave per SIMD (variant 3; csrc/attention_fwd_w64.hip) -----------------------------------------------------------------
-@pytest.mark.skipif(os.environ.get("OWL_TUNING", "0") != "1", reason="tuning-build experiment (OWL_TUNING=1 build of libowlhip.so): not in the shipped ABI")
+@pytest.mark.skipif(not _TUNING_BUILD(), reason="tuning-build experiment (OWL_TUNING=1 build of libowlhip.so): not in the shipped ABI")
 @pytest.mark.parametrize("B,H,T", [(1, 1, 193), (1, 1, 257), (2, 3, 577), (3, 2, 1025), (2, 12, 2305), (1, 2, 449), (1, 1, 3585)])
 def test_attention_fwd_one_wave_per_simd(B, H, T):
     """64 queries per wave, softmax interleaved with the neighbouring tiles' MFMAs (peeled tiling, T - 1 = 3 .. 56 key tiles, odd and even, full and
@@ -639,7 +680,7 @@ def test_attention_fwd_one_wave_per_simd(B, H, T):
     assert torch.equal(v(o3), v(out))
 
 
-@pytest.mark.skipif(os.environ.get("OWL_TUNING", "0") != "1", reason="tuning-build experiment (OWL_TUNING=1 build of libowlhip.so): not in the shipped ABI")
+@pytest.mark.skipif(not _TUNING_BUILD(), reason="tuning-build experiment (OWL_TUNING=1 build of libowlhip.so): not in the shipped ABI")
 @pytest.mark.parametrize("spike_key,spike_q,gain", [(250, 10, 12.0), (0, 5, 12.0), (2304, 2000, 12.0), (70, 0, 12.0), (0, 700, -12.0), (1, 1, 12.0)])
 def test_attention_fwd_one_wave_per_simd_redo_path(spike_key, spike_q, gain):
     """Scores outside the range of the offset-free softmax: the block raises its flag and the classic kernel redoes exactly that block in the same
@@ -672,7 +713,7 @@ def test_attention_fwd_one_wave_per_simd_redo_path(spike_key, spike_q, gain):
                 assert torch.equal(lse[0, h, rows], l2[0, h, rows])
 
 
-@pytest.mark.skipif(os.environ.get("OWL_TUNING", "0") != "1", reason="tuning-build experiment (OWL_TUNING=1 build of libowlhip.so): not in the shipped ABI")
+@pytest.mark.skipif(not _TUNING_BUILD(), reason="tuning-build experiment (OWL_TUNING=1 build of libowlhip.so): not in the shipped ABI")
 def test_attention_fwd_one_wave_per_simd_rejects_other_lengths():
     B, H, T = 1, 1, 129
     Tp = 136; D = 64

@@ -371,17 +371,21 @@ def test_train_step_b16_matches_reference_fixture_f2(golden_dir):
 # ---------------------------------------------------------------------------------------------------
 MARGIN_FIXTURES = [("owlvit-base-patch16", "f2b_b16_margins", "init"), ("owlvit-large-patch14", "f4b_l14_margins", "init"),
                    ("owlvit-base-patch16", "f10b_b16_trained_margins", "trained_like"), ("owlvit-base-patch16", "f2c_b16_seed_search", "init")]
-# Bands (|norm ratio - 1|, min cosine on the 4096-element sample), ~2x what the round-5 build measures (profiles/r05_parity_bands.md; every run prints them):
-#   F2b / F4b: every tensor within 9.7e-3 / 0.99985 -> the default band with a cosine 8x tighter than F2 / F4 could hold; box_head.dense2.bias (FOUR numbers =
-#   sum over the 12 matched rows of d_box * sigmoid') 1.64e-2: the GIoU slope moves by eb / box size (2e-3 / 0.03) per row and a 4-element sum does not average it.
+# Bands (|norm ratio - 1|, min cosine on the 4096-element sample), ~2x what the round-5 build measures (profiles/r05_parity_bands.md; every run prints them).
+# The end-to-end deviation is ONE DRAW of the bf16 forward's rounding: the same build with another summation order in the patch embedding alone (L/14, the
+# im2row-free K order of this round) moved F4b's box-head tensors from <= 9.7e-3 to 1.5-1.8e-2 and dense2.bias from 1.64e-2 to 9e-3 -- the band has to hold the
+# spread of the draws, not one of them.
+#   F2b: every tensor within 1.41e-2 / cosine >= 0.99991.   F4b: 0.97e-2 ... 1.80e-2 / >= 0.99944 over the two draws; box_head.dense2.bias (FOUR numbers = sum over the
+#   12 matched rows of d_box * sigmoid': the GIoU slope moves by eb / box size = 2e-3 / 0.03 per row and a 4-element sum does not average it) up to 1.64e-2.
 #   F2c (seed search: |sim| margin only 1.2e-2, so the class term's -w / |sim| slope moves 8 % on one row): every backbone tensor 1.4-1.6e-2 in norm, cosine >= 0.99987.
 #   F10b (trained-like weights): worst 3.74e-2 (layer 11 k_proj.weight) / 0.99824; class-only tensors 1.5e-3 / 1.00000, box head 0.9-2.4e-2.  The backward-chain test on
 #   the same weights shows the q / k / LayerNorm-1 tensors AT their bf16-storage floor (5-9e-2 rel-L2): the data type's, not a kernel's.
+# For scale: F2 / F4 / F10 (a matched coordinate on a kink) needed (0.155, 0.88) on every box-fed tensor and skipped box_head.* altogether.
 GRAD_BANDS_TRAINED = (7.5e-2, 0.996)
 MARGIN_BANDS = {
-    "f2b_b16_margins": {"*": (1.5e-2, 0.9995), "box_head.dense2.bias": (3.5e-2, 0.9995)},
-    "f4b_l14_margins": {"*": (1.5e-2, 0.9995), "box_head.dense2.bias": (3.5e-2, 0.9995)},
-    "f2c_b16_seed_search": {"*": (3.2e-2, 0.9995)},
+    "f2b_b16_margins": {"*": (3e-2, 0.999)},
+    "f4b_l14_margins": {"*": (3.5e-2, 0.999)},
+    "f2c_b16_seed_search": {"*": (3.2e-2, 0.999)},
     "f10b_b16_trained_margins": {"*": GRAD_BANDS_TRAINED},
 }
 
