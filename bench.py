@@ -168,7 +168,7 @@ def _cpu_model_string():
 
 def cpu_baseline(cfg, steps, batch8=False):
     """Time the CPU oracle (restated reference path, fp32) on this box's host cores: full train steps (fwd + matcher + loss +
-    bwd; the 11 ms AdamW is left out as in BASELINE.md's breakdown) at batch 1 (the reference's own batch size; SURVEY.md 8(d)(ii) protocol:
+    bwd + AdamW on the 29 trainable tensors) at batch 1 (the reference's own batch size; SURVEY.md 8(d)(ii) protocol:
     median of >= 5 steps after 2 warm-ups).  Batch 8 costs ~20 s per step and the oracle gains nothing from batching (0.41 against 0.48 img/s,
     profiles/r03_cpu_threads.md): that leg runs only with --cpu-batch8, at the same protocol."""
     from oracle import owl_oracle as O
@@ -187,19 +187,29 @@ def cpu_baseline(cfg, steps, batch8=False):
         labels, boxes = synth.make_targets(cfg, B, max_boxes=16)
         lab = [torch.from_numpy(l) for l in labels]; tb = [torch.from_numpy(b) for b in boxes]
         scales = torch.from_numpy(synth.class_scales(cfg, labels))
-        for _ in range(n_warm):
-            O.train_step(cfg, w, img, lab, tb, scales)          # warm-ups
+        names = O.trainable_names(w)
+        state = {n: (torch.zeros_like(w[n]), torch.zeros_like(w[n])) for n in names}
+
+        def cpu_step(k):          # ref main.py:74-91: forward + matcher + loss + backward + AdamW (lr / wd of ref config.yaml)
+            _, _, grads = O.train_step(cfg, w, img, lab, tb, scales)
+            with torch.no_grad():
+                for n in names:
+                    m, v = state[n]
+                    w[n], m, v = O.adamw_step(w[n], grads[n], m, v, k + 1, lr=3e-6, wd=0.1)
+                    state[n] = (m, v)
+        for k in range(n_warm):
+            cpu_step(k)                                          # warm-ups
         ts = []
-        for _ in range(n_steps):
+        for k in range(n_steps):
             t0 = time.perf_counter()
-            O.train_step(cfg, w, img, lab, tb, scales)
+            cpu_step(n_warm + k)
             ts.append(time.perf_counter() - t0)
         res[B] = (float(np.median(ts)), len(ts), n_warm)
     m1, n1, w1 = res[1]
     out = {"value": round(1.0 / m1, 4), "unit": "images/sec", "cores": cores, "kind": "port",
            "batch1_images_per_sec": round(1.0 / m1, 4),
            "cpu": f"{_cpu_model_string()} ({total} logical cores, {cores} torch threads used)",
-           "sample": f"fp32 train steps (fwd+matcher+loss+bwd) of {cfg.name} on the CPU oracle at the reference's batch size of 1: median {m1:.2f} s/step "
+           "sample": f"fp32 train steps (fwd+matcher+loss+bwd+AdamW) of {cfg.name} on the CPU oracle at the reference's batch size of 1: median {m1:.2f} s/step "
                      f"over {n1} steps after {w1} warm-ups; {cores} of {total} threads = the fastest setting on this CPU (thread study: profiles/r03_cpu_threads.md); "
                      f"the reference itself: 0.32 img/s on 8 vCPUs (BASELINE.md section 2)"}
     if 8 in res:
