@@ -467,7 +467,7 @@ def test_loss_backward_at_the_operating_point(cname):
 
 
 def test_l14_train_step_matches_reference_fixture_f4(golden_dir):
-    """BASELINE configs[4] architecture (owlvit-large-patch14, 840x840) at batch 1: patch 14 (im2row fallback),
+    """BASELINE configs[4] architecture (owlvit-large-patch14, 840x840) at batch 1: patch 14 (gathered: rows padded to 16 positions in the K index),
     T = 3601, and the literal `layers.11` rule on 24 layers -> backward through 12 frozen layers."""
     path = os.path.join(golden_dir, "f4_l14.npz")
     if not os.path.exists(path):
