@@ -1,0 +1,10 @@
+#!/bin/bash
+# timing-only upper bound (round 5): attention backward without its four "constant" MFMAs per tile (-lse / -D broadcast through the matrix pipe)
+R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out; : > gpurun_out/r5_attn_bwd_ab.log
+for round in 1 2; do for v in shipped noconst; do
+  cp ab_libs/libowlhip_$v.so.bin owl-vit-object-detection_amd/libowlhip.so
+  echo "== $v (round $round)" >> gpurun_out/r5_attn_bwd_ab.log
+  python tools/attn_bwd_bench.py 2>&1 | grep "attention bwd" | tail -2 >> gpurun_out/r5_attn_bwd_ab.log
+done; done
+cp ab_libs/libowlhip_shipped.so.bin owl-vit-object-detection_amd/libowlhip.so
+cat gpurun_out/r5_attn_bwd_ab.log
