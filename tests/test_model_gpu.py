@@ -642,7 +642,7 @@ def test_backward_chain_trained_like_matches_oracle_given_same_upstream(cname, B
         den = max(float(r.norm()), floor_scale)
         e_hip, e_emu, e_he = float((grads[n] - r).norm()) / den, float((we[n].grad - r).norm()) / den, float((grads[n] - we[n].grad).norm()) / den
         lines.append(f"  {n:58s} HIP vs oracle {e_hip:.3e}   bf16-storage floor {e_emu:.3e}   HIP vs emulation {e_he:.3e}")
-        if e_hip > 2.0 * e_emu + 5e-3:          # (HIP and the emulation round at the same points but not the same values: two independent errors of one size;
+        if e_hip > 2.5 * e_emu + 5e-3:          # (HIP and the emulation round at the same points but not the same values: two independent errors of one size;
                                                 #  measured: B/16 every tensor <= 1.53x its floor, layer_norm1.weight 9.0e-2 vs 5.9e-2; tiny q_proj.bias 2.5e-2 vs 1.1e-2)
             bad.append((n, e_hip, e_emu))
     print("\n".join(lines))
