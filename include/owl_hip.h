@@ -32,9 +32,9 @@ extern "C" {
 
 /* ---- runtime ---------------------------------------------------------------------------------- */
 /* Bumped whenever a prototype, an argument's meaning or a caller-provided scratch layout changes (1 = round 1; 2 = round 2: per-call `tile` /
- * `variant` arguments, partial-sum scratch of the row reductions, 5D+4 box_final_bwd partials; 3 = round 3; 4 = round 4: `slow_tiles` statistic of the attention forward; 5 = round 5: owl_patch_embed_bf16's weight layout for patch sizes that are not 2^n (gathered, no im2row); the V^T attention form, attention variants 3-5, GEMM epilogues 5 / 6 and tiles 8 / 9 / 5 / 4 moved to OWL_TUNING builds).  owl_abi_version() returns the value
+ * `variant` arguments, partial-sum scratch of the row reductions, 5D+4 box_final_bwd partials; 3 = round 3; 4 = round 4: `slow_tiles` statistic of the attention forward; 5 = round 5: owl_patch_embed_bf16's weight layout for patch sizes that are not 2^n (gathered, no im2row); the V^T attention form, attention variants 3-5, GEMM epilogues 5 / 6 and tiles 8 / 9 / 5 / 4 moved to OWL_TUNING builds); 6 = round 6: + owl_patch_embed_scratch_bytes, owl_normalize_u8 (additions only; patch sizes must be even).  owl_abi_version() returns the value
  * the library was BUILT with: a binding compares it with the header it was generated from and refuses a mismatch (_lib.load() does). */
-#define OWL_ABI_VERSION 5
+#define OWL_ABI_VERSION 6
 const char* owl_last_error(void);
 int owl_abi_version(void);
 
@@ -60,7 +60,7 @@ int owl_gemm_slab_workspace_bytes(int64_t M, int64_t ldo, int64_t K, int splits,
 int owl_slab_reduce(void* stream, const float* slabs, float* out, int64_t n, int64_t slab_stride, int nsplit, int accumulate);
 
 /* ---- patch embedding (HF5:282-288 Conv2d k=s=patch, no bias; HF5:336-343 flatten + positions) ----
- * im2row-free for EVERY patch size 8 <= ps <= 64: the A-operand loader gathers 16-byte runs of each patch row straight from the
+ * im2row-free for EVERY even patch size 8 <= ps <= 64: the A-operand loader gathers 16-byte runs of each patch row straight from the
  * bf16 image [B,3,S,S] into LDS.  x_out[b*Tp + 1 + p, :] = W_pe . vec(patch) + pos[1+p, :].
  *   ps = 2^n      : w_pe = the conv weight [D, 3*ps*ps] as it lies.
  *   other ps (14) : the K index pads a patch row to psp = 2^n >= ps positions; position `pos` of a row holds pixel
@@ -69,7 +69,9 @@ int owl_slab_reduce(void* stream, const float* slabs, float* out, int64_t n, int
  *                   and zeros elsewhere (Python: weights.patch_weight_gather_layout).  (ABI 5; ABI <= 4 took an explicit im2row there.)
  * scratch: bf16 [rows128(B*P), Kg], needed only when a single-phase reference kernel (tile 256 / 128, or a problem too small for the
  *          ping-pong kernel) meets a patch size that is not 2^n (explicit im2row in the same K order: identical bits); else NULL.
+ *          owl_patch_embed_scratch_bytes answers "how many bytes, for this problem and tile" (0 = pass NULL): the dispatcher's rule lives there only (ABI 6).
  * tile: 0 = automatic (two-phase ping-pong kernel for big problems), 7 / 256 / 128 pin a kernel (tests); same bits.       */
+int owl_patch_embed_scratch_bytes(int64_t B, int64_t S, int64_t ps, int64_t D, int tile, int64_t* bytes);
 int owl_patch_embed_bf16(void* stream, const void* image_bf16, const void* w_pe, const float* pos, float* x_out, void* scratch, int64_t B, int64_t S, int64_t ps, int64_t D, int64_t Tp, int tile);
 /* class-token rows x[b*Tp, :] = class_embedding + pos[0, :]  (HF5:338-343)                        */
 int owl_cls_rows(void* stream, float* x, const float* cls, const float* pos, int64_t B, int64_t Tp, int64_t D);
@@ -155,6 +157,9 @@ int owl_bicubic_coeffs(int64_t in_size, int64_t out_size, int* bounds, int* kk, 
  * {src ptr, H, W, bounds_x ptr, kk_x ptr, ksize_x, bounds_y ptr, kk_y ptr, ksize_y, byte offset of its intermediate in tmp};
  * out [n_images,3,out_h,out_w]                                                                                        */
 int owl_preprocess_u8_batch(void* stream, const void* desc, int64_t n_images, int64_t max_h, unsigned char* tmp, const float* lut, void* out, int out_bf16, int64_t out_h, int64_t out_w);
+/* images that already have the model's size (ABI 6): src u8 [n,H,W,3] (src_chw = 0) or [n,3,H,W] (src_chw = 1) -> lut -> out [n,3,H,W] f32 | bf16.  Pillow's resize
+ * to the size an image already has is a copy, so this IS the reference pipeline for such images, bit for bit.  H*W % 4 == 0; src 4-byte, out 16-byte aligned.       */
+int owl_normalize_u8(void* stream, const unsigned char* src, int src_chw, const float* lut, void* out, int out_bf16, int64_t n_images, int64_t H, int64_t W);
 
 /* ---- query-bank initialisation: the CLIP-style text tower run once by ref src/models.py:155-169 (HF5:603-663, 945-970).
  * Linear / LayerNorm layers reuse owl_gemm_nt_bf16 / owl_layernorm_fwd; these are the text-only pieces:

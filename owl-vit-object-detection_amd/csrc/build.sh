@@ -13,13 +13,18 @@ if [ "${OWL_TUNING:-0}" = "1" ]; then FLAGS="$FLAGS -DOWL_TUNING"; BUILD=build_t
 mkdir -p $BUILD
 objs=""
 pids=""
-for f in *.hip; do
-  o=$BUILD/${f%.hip}.o
+# csrc/ holds the shipped kernels only; the whole-file experiments (free-running / four-phase / four-wave GEMMs, one-wave-per-SIMD attention forward)
+# live in tools/experiments/csrc/ and are compiled into a TUNING build alone (one command: tools/experiments/build.sh)
+SRCS=$(ls *.hip)
+if [ "${OWL_TUNING:-0}" = "1" ]; then SRCS="$SRCS $(ls ../../tools/experiments/csrc/*.hip)"; FLAGS="$FLAGS -I$(pwd)"; fi
+for f in $SRCS; do
+  b=$(basename "$f")
+  o=$BUILD/${b%.hip}.o
   stale=0
   for h in *.h; do [ "$h" -nt "$o" ] && stale=1; done
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ $stale = 1 ]; then
     extra=""
-    case "$f" in
+    case "$b" in
       loss.hip|postprocess.hip) extra="-ffp-contract=off";;
       # packed f32 VALU (v_pk_mul/add_f32) beside MFMAs costs more than the two scalar instructions it replaces
       # (MI355X_MICROARCH.md; measured -1.7 % on the backward pair): no SLP packing in the attention kernels

@@ -391,16 +391,16 @@ OWL_API int owl_gemm_nt_bf16(void* stream, int epi, const void* A, int64_t lda, 
         // every tile goes out as two half-height tiles (gemm_pph.hip), one partial round of ~0.85 tile times on twice the CUs.  Same K order and epilogue:
         // bit-identical.  Asked for by the CALLER, who knows what else is in flight: with two sub-batch streams the other stream's tiles already fill the idle
         // CUs and the half-height split loses (forward batch 8: -2.7 %; alone: +3.3 % / +4.5 % on the batch-1 train step / forward, profiles/r05_small_batch.md).
-        if (want_half && a_rows >= M && 2 * ((M + 255) / 256) * ((N + 255) / 256) <= 256) {
+        if (want_half && a_rows >= M && 2 * ((M + 255) / 256) * ((N + 255) / 256) <= NUM_CUS) {
             const int rc = owl_gemm_pph_launch(s, epi, p);
             if (rc <= 0) return rc;      // 1 = epilogue not handled by the half-height kernel: the 256 x 256 kernel below
         }
         if ((g_force_tile == 9 || (g_force_tile == 0 && N <= 1024)) && epi != EPI_TRANS_BF16 && epi != EPI_F32 && epi != EPI_ACC_F32 && a_rows >= M) {
             const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256, items = tm * tn;
-            const int64_t full_rounds = items / 256;
-            const int64_t tm_main = (full_rounds * 256) / tn;
+            const int64_t full_rounds = items / NUM_CUS;
+            const int64_t tm_main = (full_rounds * NUM_CUS) / tn;
             const int64_t rem_tiles = (tm - tm_main) * tn;
-            if (full_rounds >= 1 && tm_main >= 1 && rem_tiles > 0 && 2 * rem_tiles <= 256 && items - full_rounds * 256 > 0) {
+            if (full_rounds >= 1 && tm_main >= 1 && rem_tiles > 0 && 2 * rem_tiles <= NUM_CUS && items - full_rounds * NUM_CUS > 0) {
                 const int64_t M_main = tm_main * 256;
                 GemmP pm = p;
                 pm.M = M_main; pm.a_rows = M_main;
@@ -517,15 +517,33 @@ __global__ __launch_bounds__(256) void im2row_kernel(const bf16_t* __restrict__ 
 //                    at each pixel's FIRST position and zeros elsewhere (Python: weights.patch_weight_gather_layout).
 // `scratch` (bf16 [B*P (row-padded to 128), Kg]) is needed only when a single-phase reference kernel (tile = 256 / 128, or a problem too small for the ping-pong
 // kernel) meets a patch size that is not 2^n: it then receives an explicit im2row in the same K order (identical bits).
+static bool patch_embed_takes_pp2(int64_t M, int64_t D, int64_t Kg, int tile) {
+    return (tile == 7 || (tile == 0 && M >= 512 && D >= 256 && ((M + 255) / 256) * ((D + 255) / 256) >= 48)) && Kg >= 128;
+}
+
+// Bytes of the `scratch` argument of owl_patch_embed_bf16 for this problem and kernel choice: 0 when the chosen kernel gathers from the image itself (every 2^n
+// patch size; any patch size on the ping-pong kernel), else the im2row matrix bf16 [B*P rounded up to 128 rows, Kg].  The ONE place the rule lives (ADVICE r05:
+// the Python side used to restate the dispatcher's predicate).
+OWL_API int owl_patch_embed_scratch_bytes(int64_t B, int64_t S, int64_t ps, int64_t D, int tile, int64_t* bytes) {
+    OWL_CHECK_ARG(bytes && B > 0 && ps >= 8 && ps <= 64 && ps % 2 == 0 && S > 0 && S % ps == 0 && D > 0, "owl_patch_embed_scratch_bytes: bad arguments");
+    const int64_t G = S / ps, P = G * G;
+    int64_t psp = 8; while (psp < ps) psp *= 2;
+    const int64_t Kg = (3 * ps * psp + BK - 1) / BK * BK;
+    *bytes = (psp == ps || patch_embed_takes_pp2(B * P, D, Kg, tile)) ? 0 : ((B * P + 127) / 128 * 128) * Kg * 2;
+    return 0;
+}
+
 OWL_API int owl_patch_embed_bf16(void* stream, const void* image_bf16, const void* w_pe, const float* pos,
                                     float* x_out, void* scratch, int64_t B, int64_t S, int64_t ps, int64_t D, int64_t Tp, int tile) {
     OWL_CHECK_ARG(image_bf16 && w_pe && pos && x_out, "owl_patch_embed_bf16: null pointer");
-    OWL_CHECK_ARG(S % ps == 0 && ps >= 8 && ps <= 64, "owl_patch_embed_bf16: image side must be a multiple of the patch size, 8 <= patch size <= 64");
+    // (even patch sizes only: a 16-byte LDS-DMA piece starts at byte 2 * (row * S + px * ps + kx), which is 4-byte aligned -- what global_load_lds_dwordx4
+    //  needs -- only when ps, hence S, is even; tested: 14, 16, 24, 32)
+    OWL_CHECK_ARG(S % ps == 0 && ps >= 8 && ps <= 64 && ps % 2 == 0, "owl_patch_embed_bf16: image side must be a multiple of the patch size, patch size even and 8 <= patch size <= 64");
     const int64_t G = S / ps, P = G * G;
     int64_t psp = 8; while (psp < ps) psp *= 2;
     const int64_t K = 3 * ps * psp, Kg = (K + BK - 1) / BK * BK;
     OWL_CHECK_ARG(D % 8 == 0 && Tp >= P + 1, "owl_patch_embed_bf16: D %% 8, Tp");
-    OWL_CHECK_ARG(B * 3 * S * S * 2 < (1LL << 32) && B * P < (1LL << 31), "owl_patch_embed_bf16: image batch beyond 4 GiB (32-bit gather offsets)");
+    OWL_CHECK_ARG(B * 3 * S * S * 2 < (1LL << 32) && B * P < (1LL << 31), "owl_patch_embed_bf16: image batch beyond 4 GiB (unsigned 32-bit gather byte offsets)");
     OWL_CHECK_ARG(tile == 0 || tile == 7 || tile == 256 || tile == 128, "owl_patch_embed_bf16: tile must be 0 (auto), 7, 256 or 128");
     const bool pow2 = psp == ps;
     GemmP p{};
@@ -538,8 +556,7 @@ OWL_API int owl_patch_embed_bf16(void* stream, const void* image_bf16, const voi
     p.kt_per_split = (int)(Kg / BK);
     p.nsplit = 1;
     // big problems: the two-phase ping-pong kernel (same bits); tile = 256 / 128 pins the single-phase kernels, 7 the ping-pong one
-    const bool pp2 = tile == 7 || (tile == 0 && p.M >= 512 && D >= 256 && ((p.M + 255) / 256) * ((D + 255) / 256) >= 48);
-    if (pp2 && Kg >= 128) return owl_gemm_pp2_launch((hipStream_t)stream, EPI_PATCH_F32, p);
+    if (patch_embed_takes_pp2(p.M, D, Kg, tile)) return owl_gemm_pp2_launch((hipStream_t)stream, EPI_PATCH_F32, p);
     if (pow2) return launch<EPI_PATCH_F32>((hipStream_t)stream, p, 1, tile);           // (the single-phase kernels gather 2^n patch rows themselves)
     OWL_CHECK_ARG(scratch, "owl_patch_embed_bf16: patch size %lld on a single-phase kernel (tile %d, or a problem too small for the ping-pong kernel) needs the im2row scratch buffer",
                   (long long)ps, tile);

@@ -3,6 +3,10 @@
 #pragma once
 #include "common.h"
 
+// MI355X (gfx950) is the only target: 256 compute units in 8 XCDs.  The persistent grids, the remainder-round rule and the small-problem (tile 6) rule of
+// csrc/gemm.hip count on it; ops.CHIP_CUS is the Python side's copy (models.OwlViT warns if the device reports another count).
+constexpr int NUM_CUS = 256;
+
 enum {
     EPI_BIAS_BF16 = 0,   // out bf16 = acc + bias
     EPI_QGELU_BF16 = 1,  // u = acc + bias; out bf16 = u*sigmoid(1.702u); aux (optional) bf16 = u

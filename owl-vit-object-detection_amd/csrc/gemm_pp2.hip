@@ -101,7 +101,7 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
                     const int c = (lane & 7) ^ ((r >> 1) & 7);
                     int64_t am = m0 + r; if (am >= p.a_rows) am = p.a_rows - 1;
                     if constexpr (GATHER) {
-                        // (32-bit arithmetic: the 64-bit divisions here cost 14 spilled VGPRs inside the K loop; the host checks that the image fits 2^31 bytes)
+                        // (32-bit arithmetic: the 64-bit divisions here cost 14 spilled VGPRs inside the K loop; unsigned byte offsets: the host checks that the image batch stays below 2^32 bytes, csrc/gemm.hip)
                         const unsigned P32 = (unsigned)p.P, G32 = (unsigned)p.G, S32 = (unsigned)p.S, ps32 = (unsigned)p.ps;
                         const unsigned b = (unsigned)am / P32, pp = (unsigned)am - b * P32;
                         const unsigned py = pp / G32, px = pp - py * G32;

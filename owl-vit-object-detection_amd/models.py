@@ -20,7 +20,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import ops, weights as W
+from . import _lib, ops, weights as W
 from .config import OwlConfig, get_config
 from .postprocess import PostProcess  # noqa: F401  (the reference exports it from src/models.py:122)
 
@@ -70,6 +70,12 @@ class OwlViT(nn.Module):
         self.device_ = torch.device(device)
         if cfg.head_dim != 64:
             raise ValueError("attention kernels are built for head_dim = 64")
+        if self.device_.type == "cuda" and torch.cuda.is_available():
+            cus = torch.cuda.get_device_properties(self.device_).multi_processor_count
+            if cus != ops.CHIP_CUS:
+                import warnings
+                warnings.warn(f"OwlViT: {self.device_} reports {cus} compute units; the kernels' grids and tile rules are laid out for the {ops.CHIP_CUS} CUs of an "
+                              "unpartitioned MI355X (results stay correct, the schedule is not the measured one)")
         shapes = W.param_shapes(cfg)
         missing = set(shapes) - set(state)
         if missing:
@@ -218,15 +224,16 @@ class OwlViT(nn.Module):
                 del self._ws[k]
 
     def _patch_scratch(self, B):
-        """im2row scratch of owl_patch_embed_bf16: only a patch size that is not 2^n on a problem too small for the ping-pong kernel needs one
-        (csrc/gemm.hip; L/14 at any batch size does not)."""
+        """im2row scratch of owl_patch_embed_bf16, sized by the library's own query (the dispatcher's rule lives in csrc/gemm.hip only): a patch size that is
+        not 2^n on a problem too small for the ping-pong kernel needs one; L/14 at any batch size does not."""
         cfg = self.cfg
-        ps, Mh, D = cfg.patch_size, B * cfg.patches, cfg.hidden
-        if ps & (ps - 1) == 0 or (Mh >= 512 and D >= 256 and ((Mh + 255) // 256) * ((D + 255) // 256) >= 48):
+        nbytes = torch.zeros(1, dtype=torch.int64)
+        _lib.call("owl_patch_embed_scratch_bytes", B, cfg.image_size, cfg.patch_size, cfg.hidden, 0, nbytes)
+        if int(nbytes.item()) == 0:
             return None
         key = ("im2row", B)
         if key not in self._ws:
-            self._ws[key] = ops.zeros_rows(Mh, self._fz["w_pe"].shape[1], torch.bfloat16, self.device_)
+            self._ws[key] = torch.zeros(int(nbytes.item()) // 2, dtype=torch.bfloat16, device=self.device_)
         return self._ws[key]
 
     def _workspace(self, B: int, train: bool = True):

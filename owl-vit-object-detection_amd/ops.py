@@ -11,6 +11,8 @@ EPI_BIAS_BF16, EPI_QGELU_BF16, EPI_GELU_BF16, EPI_RESID_F32, EPI_F32, EPI_ATOMIC
 EPI_TRANS_BF16, EPI_PATCH_F32, EPI_DQGELU_BF16, EPI_DGELU_BF16, EPI_ACC_F32, EPI_SLAB_F32 = 6, 7, 8, 9, 10, 11
 
 ROW_PAD = 128
+CHIP_CUS = 256     # MI355X (gfx950), the only target: the kernels' persistent grids and the small-problem rule below count on it (csrc/gemm_common.h NUM_CUS);
+                   # models.OwlViT warns when the device reports another count (a partitioned GPU)
 ATTN_VARIANT = 0   # default `variant` of attention_fwd_vrow(): 0 = the library's choice; 1 plain tiling, 2 class token peeled (tests / tools)
 GEMM_TILE = 0      # default `tile` argument of gemm(): 0 = automatic kernel choice; tests / tools pin one kernel (128 | 256 | 7; tuning builds: 8 | 9 | 5 | 4)
 
@@ -43,7 +45,7 @@ def gemm(epi, A, W, out, bias=None, resid=None, aux=None, M=None, N=None, K=None
          ld_aux=0, a_rows=None, w_rows=None, alpha=1.0, splits=1, Tp=0, tile=None, concurrency=None):
     """out = epilogue(A[M,K] @ W[N,K]^T).  A/W bf16; see include/owl_hip.h for epilogues.
     concurrency: how many launches like this one the caller has in flight at once (sub-batch streams).  If their 256 x 256 tiles together fill at most half
-    the chip's 256 CUs, the automatic kernel choice becomes tile 6 (half-height tiles; include/owl_hip.h): the library cannot know what else is running."""
+    the chip's CHIP_CUS compute units, the automatic kernel choice becomes tile 6 (half-height tiles; include/owl_hip.h): the library cannot know what else is running."""
     _chk(A, torch.bfloat16, "A"); _chk(W, torch.bfloat16, "W"); _chk(bias, torch.float32, "bias")
     K = K if K is not None else A.shape[-1]
     N = N if N is not None else W.shape[0]
@@ -56,7 +58,7 @@ def gemm(epi, A, W, out, bias=None, resid=None, aux=None, M=None, N=None, K=None
     if aux is not None and ld_aux == 0:
         ld_aux = aux.shape[-1]
     tile = int(GEMM_TILE if tile is None else tile)
-    if tile == 0 and concurrency is not None and 2 * int(concurrency) * ((M + 255) // 256) * ((N + 255) // 256) <= 256:
+    if tile == 0 and concurrency is not None and 2 * int(concurrency) * ((M + 255) // 256) * ((N + 255) // 256) <= CHIP_CUS:
         tile = 6
     _lib.call("owl_gemm_nt_bf16", stream(), epi, A, lda, a_rows, W, ldw, w_rows, bias, out, ldo, resid, aux, ld_aux,
               M, N, K, float(alpha), int(splits), int(Tp), tile)

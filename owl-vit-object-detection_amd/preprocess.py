@@ -84,3 +84,289 @@ class DeviceImageProcessor:
                   1 if self.dtype == torch.bfloat16 else 0, self.size, self.size)
         self._keep = (imgs, desc_d)          # keep the sources alive until the stream has consumed them
         return {"pixel_values": out}
+
+    def normalize_sized(self, src_u8: torch.Tensor, chw: bool) -> torch.Tensor:
+        """Images that already have the model's size: u8 [B,S,S,3] (chw=False) or [B,3,S,S] (chw=True) ON THE DEVICE -> [B,3,S,S] self.dtype.  Pillow's resize to
+        the size an image already has is a copy, so only the table step of the reference pipeline is left (owl_normalize_u8)."""
+        if src_u8.dtype != torch.uint8 or src_u8.dim() != 4 or not src_u8.is_cuda:
+            raise ValueError(f"normalize_sized: expected a device uint8 [B,S,S,3] / [B,3,S,S] tensor, got {src_u8.dtype} {tuple(src_u8.shape)} on {src_u8.device}")
+        n = int(src_u8.shape[0])
+        H, W_ = (int(src_u8.shape[2]), int(src_u8.shape[3])) if chw else (int(src_u8.shape[1]), int(src_u8.shape[2]))
+        if (int(src_u8.shape[1]) if chw else int(src_u8.shape[3])) != 3 or (H, W_) != (self.size, self.size):
+            raise ValueError(f"normalize_sized: expected {self.size} x {self.size} RGB images, got {tuple(src_u8.shape)} (chw={chw})")
+        src_u8 = src_u8.contiguous()
+        out = torch.empty(n, 3, self.size, self.size, dtype=self.dtype, device=self.device)
+        _lib.call("owl_normalize_u8", ops.stream(), src_u8, 1 if chw else 0, self.lut, out, 1 if self.dtype == torch.bfloat16 else 0, n, H, W_)
+        return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# The reference's loop does `image = image.to(device)` in front of every step (ref main.py:77-79): 7.1 MB of f32 pixels per B/16 image over
+# PCIe, serialised with the step -- the HBM-resident kernels then wait for the bus (measured: 1003 against 1217 img/s at batch 32).  What
+# the hot path needs from its caller is the next batch already in HBM when the step starts, and as few bytes over the bus as the data has:
+# the u8 pixels (1.8 MB per 768^2 image; 0.9 MB for a COCO-size one that is resized on the device).
+# ---------------------------------------------------------------------------------------------------------------------------------------
+def _as_u8_tensor(img):
+    """torch u8 tensor view of one host image (torch / numpy / PIL), no copy where the source allows it."""
+    if torch.is_tensor(img):
+        return img
+    if isinstance(img, np.ndarray):
+        return torch.from_numpy(np.ascontiguousarray(img))
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(img.convert("RGB") if hasattr(img, "convert") else img)))
+
+
+def classify_images(images, size: int):
+    """What a host batch's image part is -> (kind, items).  kind: 'dense' (f32 / bf16 [B,3,S,S] pixel_values, the reference DataLoader's output: copied, cast to
+    the compute type on the device), 'u8_chw' / 'u8_hwc' (uint8 [B,3,S,S] / [B,S,S,3] already at the model's size: table step only), 'u8_ragged' (a list of -- or
+    a [B,H,W,3] tensor of -- uint8 HWC images of any sizes: Pillow-exact bicubic resize + table on the device).  Pure host logic (CPU-tested)."""
+    if isinstance(images, (list, tuple)):
+        items = [_as_u8_tensor(im) for im in images]
+        if not items:
+            raise ValueError("DevicePrefetcher: empty image list")
+        if all(t.dtype == torch.uint8 and t.dim() == 3 and t.shape[2] == 3 for t in items):
+            return "u8_ragged", items
+        if all(t.dtype in (torch.float32, torch.bfloat16) and tuple(t.shape) == (3, size, size) for t in items):
+            return "dense", [torch.stack(items)]
+        raise ValueError("DevicePrefetcher: a list of images must hold uint8 [H,W,3] images (or [3,S,S] pixel_values)")
+    t = images if torch.is_tensor(images) else _as_u8_tensor(images)
+    if t.dtype in (torch.float32, torch.bfloat16):
+        if t.dim() == 3:
+            t = t.unsqueeze(0)
+        if t.dim() != 4 or tuple(t.shape[1:]) != (3, size, size):
+            raise ValueError(f"DevicePrefetcher: pixel_values must be [B,3,{size},{size}], got {tuple(t.shape)}")
+        return "dense", [t]
+    if t.dtype != torch.uint8:
+        raise TypeError(f"DevicePrefetcher: images must be uint8 (raw pixels) or float32 / bfloat16 (pixel_values), got {t.dtype}")
+    if t.dim() == 3:
+        t = t.unsqueeze(0)
+    if t.dim() != 4:
+        raise ValueError(f"DevicePrefetcher: uint8 images must be [B,H,W,3] or [B,3,S,S], got {tuple(t.shape)}")
+    if tuple(t.shape[1:]) == (3, size, size):
+        return "u8_chw", [t]
+    if t.shape[3] == 3:
+        if tuple(t.shape[1:3]) == (size, size):
+            return "u8_hwc", [t]
+        return "u8_ragged", [t[i] for i in range(t.shape[0])]
+    raise ValueError(f"DevicePrefetcher: cannot interpret a uint8 tensor of shape {tuple(t.shape)}")
+
+
+def pack_plan(items, align: int = 256):
+    """Byte offsets of `items` (host tensors) in one staging slab, each aligned -> (offsets, total bytes)."""
+    offs, off = [], 0
+    for t in items:
+        offs.append(off)
+        off += (t.numel() * t.element_size() + align - 1) // align * align
+    return offs, off
+
+
+class _PinnedRing:
+    """`n` pinned host slabs (grown on demand), each with the event of the last H2D copy that read it: a slab is rewritten only after that copy has finished."""
+
+    def __init__(self, n):
+        self.slabs = [None] * n
+        self.events = [None] * n
+        self.k = 0
+
+    def next(self, nbytes):
+        i = self.k
+        self.k = (self.k + 1) % len(self.slabs)
+        if self.events[i] is not None:
+            self.events[i].synchronize()                    # (blocks the staging thread only)
+        if self.slabs[i] is None or self.slabs[i].numel() < nbytes:
+            self.slabs[i] = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, pin_memory=True)
+        return i, self.slabs[i]
+
+
+class DevicePrefetcher:
+    """Wraps any iterable of host batches `(images, *targets)` -- the reference's `train_dataloader` (ref main.py:70-73) -- and yields the same tuples with the
+    images ALREADY in HBM as the model's bf16 `[B,3,S,S]` input, one batch ahead of the step that consumes them:
+
+        host batch -> pinned ring slab -> copy stream (H2D) -> DeviceImageProcessor (resize / table / cast, same stream) -> event -> handed to the caller's stream
+
+    `images` may be uint8 raw pixels (a list of `[H,W,3]` images of any sizes, a `[B,H,W,3]` tensor, or `[B,S,S,3]` / `[B,3,S,S]` at the model's size) --
+    a quarter (or an eighth, for COCO-size images) of the PCIe bytes of f32 pixel_values, processed bit-exactly like the reference's HF processor (fixture F7) --
+    or the reference's own f32 `[B,3,S,S]` pixel_values (copied and cast only).  Targets: `target_transform(*targets)` runs on the HOST first (e.g. the
+    reference's `coco_to_model_input`, ref main.py:79), then tensors and lists of tensors are moved to the device on the copy stream (`move_targets`); dicts
+    (the reference's `metadata`) and everything else pass through untouched.  The reference loop's own `.to(device)` calls become no-ops.
+
+    Ordering: the consumer's stream waits for the batch's event and the tensors are `record_stream`-ed on it, so the caching allocator does not recycle them
+    while the step still reads them; a pinned slab is reused only after its own copy has completed.  `threaded=True` pulls from the loader, stages and
+    enqueues from a background thread (`depth` batches ahead); `threaded=False` does the same work inside `__next__`, one batch ahead.
+    No CPU fallback: images are processed by libowlhip.so on the device or not at all."""
+
+    _END = object()
+
+    def __init__(self, loader, device="cuda", size=768, dtype=torch.bfloat16, depth=2, processor=None, target_transform=None,
+                 move_targets=True, threaded=True):
+        self.loader = loader
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise ValueError("DevicePrefetcher: the device must be a GPU (there is no CPU path)")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.size = int(size)
+        self.dtype = dtype
+        self.depth = max(1, int(depth))
+        self.processor = processor if processor is not None else DeviceImageProcessor(size=size, device=self.device, dtype=dtype)
+        if self.processor.size != self.size or self.processor.dtype != dtype:
+            raise ValueError("DevicePrefetcher: the processor's size / dtype must match")
+        self.target_transform = target_transform
+        self.move_targets = bool(move_targets)
+        self.threaded = bool(threaded)
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self._ring = _PinnedRing(self.depth + 2)
+        from collections import deque
+        self._inflight = deque()
+        self._thread = None
+        self._stop = None
+        self._q = None
+        self.bytes_h2d = 0                 # image bytes sent over the bus so far (statistics: bench.py reports bytes per image)
+        self.batches = 0
+
+    def __len__(self):
+        return len(self.loader)
+
+    # -- staging (runs in the background thread when threaded) ------------------------------------------------------------------------------
+    def _h2d(self, items):
+        """Host tensors -> ONE device slab through a pinned ring slab (one copy per batch) -> device views.  An already pinned single tensor goes as it is."""
+        while self._inflight and self._inflight[0][0].query():          # caller-pinned sources whose copies have completed
+            self._inflight.popleft()
+        if len(items) == 1 and items[0].is_pinned() and items[0].is_contiguous():
+            src = items[0]                                               # (a DataLoader(pin_memory=True) batch: no second staging copy)
+            dst = torch.empty(src.shape, dtype=src.dtype, device=self.device)
+            dst.copy_(src, non_blocking=True)
+            ev = torch.cuda.Event(); ev.record(self.copy_stream)
+            self._inflight.append((ev, src))                             # keeps the pinned source alive until its copy has run
+            self.bytes_h2d += src.numel() * src.element_size()
+            return [dst]
+        offs, total = pack_plan(items)
+        i, slab = self._ring.next(total)
+        for t, o in zip(items, offs):
+            n = t.numel() * t.element_size()
+            slab[o:o + n].copy_(t.contiguous().view(-1).view(torch.uint8))   # host memcpy into pinned memory (releases the GIL)
+        dslab = torch.empty(total, dtype=torch.uint8, device=self.device)
+        dslab[:total].copy_(slab[:total], non_blocking=True)
+        ev = torch.cuda.Event(); ev.record(self.copy_stream)
+        self._ring.events[i] = ev
+        self.bytes_h2d += total
+        return [dslab[o:o + t.numel() * t.element_size()].view(t.dtype).view(t.shape) for t, o in zip(items, offs)]
+
+    def _stage_images(self, images):
+        kind, items = classify_images(images, self.size)
+        dev = self._h2d(items)
+        if kind == "dense":
+            x = dev[0]
+            if x.dtype == self.dtype:
+                return x
+            if x.dtype == torch.float32 and self.dtype == torch.bfloat16:
+                return ops.cast_bf16(x.contiguous())         # the model's own first step (same kernel, same rounding), off the critical path
+            return x.to(self.dtype)
+        if kind in ("u8_chw", "u8_hwc"):
+            return self.processor.normalize_sized(dev[0], chw=(kind == "u8_chw"))
+        return self.processor(dev)["pixel_values"]
+
+    def _move(self, obj):
+        if torch.is_tensor(obj):
+            return obj.to(self.device, non_blocking=True)
+        if isinstance(obj, (list, tuple)) and obj and all(torch.is_tensor(o) for o in obj):
+            return type(obj)(o.to(self.device, non_blocking=True) for o in obj)
+        return obj
+
+    def _stage(self, batch):
+        if not isinstance(batch, (list, tuple)) or len(batch) < 1:
+            raise TypeError("DevicePrefetcher: the loader must yield (images, *targets) tuples")
+        images, rest = batch[0], tuple(batch[1:])
+        if self.target_transform is not None:
+            rest = self.target_transform(*rest)
+            if not isinstance(rest, tuple):
+                rest = (rest,)
+        with torch.cuda.stream(self.copy_stream):
+            img = self._stage_images(images)
+            if self.move_targets:
+                rest = tuple(self._move(r) for r in rest)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+        self.batches += 1
+        return (img,) + rest, ev
+
+    # -- hand-over (the caller's thread and stream) ------------------------------------------------------------------------------------------------
+    def _hand_over(self, staged):
+        out, ev = staged
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(ev)
+        for o in out:
+            for t in (o if isinstance(o, (list, tuple)) else (o,)):
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(cur)
+        return out
+
+    def _worker(self, it, q, stop):
+        import queue
+        try:
+            torch.cuda.set_device(self.device)
+            for batch in it:
+                item = self._stage(batch)
+                while not stop.is_set():
+                    try:
+                        q.put(item, timeout=0.1)
+                        break
+                    except queue.Full:
+                        continue
+                if stop.is_set():
+                    return
+            item = self._END
+        except BaseException as e:          # re-raised in the consumer's thread
+            item = e
+        while not stop.is_set():
+            try:
+                q.put(item, timeout=0.1)
+                return
+            except queue.Full:
+                continue
+
+    def close(self):
+        """Stop the background thread (also called when the iterator is exhausted, abandoned by a new __iter__, or collected)."""
+        if self._stop is not None:
+            self._stop.set()
+        if self._thread is not None and self._thread.is_alive():
+            self._thread.join(timeout=5.0)
+        self._thread = self._stop = self._q = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __iter__(self):
+        self.close()
+        it = iter(self.loader)
+        if not self.threaded:
+            from collections import deque
+            pending = deque()
+            done = False
+            while True:
+                while not done and len(pending) < 1 + 1:          # the batch handed over now + one in flight behind it
+                    try:
+                        pending.append(self._stage(next(it)))
+                    except StopIteration:
+                        done = True
+                if not pending:
+                    return
+                yield self._hand_over(pending.popleft())
+        import queue
+        import threading
+        q, stop = queue.Queue(maxsize=self.depth), threading.Event()
+        th = threading.Thread(target=self._worker, args=(it, q, stop), daemon=True, name="owl-prefetch")
+        self._thread, self._stop, self._q = th, stop, q
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is self._END:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                yield self._hand_over(item)
+        finally:
+            stop.set()

@@ -22,6 +22,17 @@ def make_images(cfg: OwlConfig, batch: int, seed: int = 1234, first: int = 0) ->
     return out
 
 
+def make_images_u8(cfg: OwlConfig, batch: int, seed: int = 1234, first: int = 0, layout: str = "hwc") -> np.ndarray:
+    """The uint8 levels make_images() normalises (the same draws), as a camera / decoder hands them over: [B,S,S,3] (`hwc`) or [B,3,S,S] (`chw`).
+    What the u8 input stage (preprocess.DevicePrefetcher) is fed with; its table step gives make_images()'s values to within one f32 ulp (the HF
+    processor rounds x/255 to f32 before normalising, make_images() normalises in f64)."""
+    S = cfg.image_size
+    out = np.empty((batch, 3, S, S), dtype=np.uint8)
+    for b in range(batch):
+        out[b] = rng.randint(seed, f"image/{first + b}", 3 * S * S, 256).reshape(3, S, S).astype(np.uint8)
+    return out if layout == "chw" else np.ascontiguousarray(out.transpose(0, 2, 3, 1))
+
+
 def make_targets(cfg: OwlConfig, batch: int, seed: int = 1234, first: int = 0, max_boxes: int = 16):
     """Per image: n_i = 1 + h(seed, i) mod max_boxes; boxes valid, inside the image."""
     labels, boxes = [], []

@@ -91,15 +91,16 @@ def test_abi_version_mismatch_is_refused(built, monkeypatch, tmp_path):
 
 
 def test_product_package_never_imports_the_oracle():
-    """Only tests/, selftest.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/: NO file of the product package imports it (round 6: the
+    smoke check moved out of the package, so there is no exception to make)."""
     import os
     import re
     pkg = os.path.dirname(os.path.abspath(__import__("owl_vit_object_detection_amd").__file__))
     offenders = []
     for fn in sorted(os.listdir(pkg)):
-        if fn.endswith(".py") and fn != "selftest.py":
+        if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
-            if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
+            if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M) or "owl_oracle" in src:
                 offenders.append(fn)
     assert offenders == []
 
