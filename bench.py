@@ -678,6 +678,8 @@ def main():
             c["from_host_u8_product_windows"] = vals_u
             c["from_host_u8_product_bitwise_equals_resident_step"] = same
             c["from_host_u8_product_bytes_per_image"] = int(pf_u.bytes_h2d / max(1, pf_u.batches) / B)
+            c["from_host_u8_product_host_ms_per_batch"] = round(1e3 * pf_u.stage_seconds / max(1, pf_u.batches), 2)
+            c["from_host_u8_coco_size_host_ms_per_batch"] = round(1e3 * pf_c.stage_seconds / max(1, pf_c.batches), 2)
             c["images_per_sec_from_host_u8_coco_size_product"] = round(B * world * args.steps / dt_c, 2)
             c["from_host_u8_coco_size_bytes_per_image"] = int(pf_c.bytes_h2d / max(1, pf_c.batches) / B)
             c["images_per_sec_from_host_f32_product"] = round(B * world * args.steps / dt_f, 2)

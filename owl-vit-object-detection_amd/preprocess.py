@@ -220,40 +220,55 @@ class DevicePrefetcher:
         self._thread = None
         self._stop = None
         self._q = None
-        self.bytes_h2d = 0                 # image bytes sent over the bus so far (statistics: bench.py reports bytes per image)
+        self.bytes_h2d = 0                 # bytes sent over the bus so far (statistics: bench.py reports bytes per image)
         self.batches = 0
+        self.stage_seconds = 0.0           # host time spent staging (pull from the loader excluded): must stay below the step time for the stage to hide
 
     def __len__(self):
         return len(self.loader)
 
     # -- staging (runs in the background thread when threaded) ------------------------------------------------------------------------------
     def _h2d(self, items):
-        """Host tensors -> ONE device slab through a pinned ring slab (one copy per batch) -> device views.  An already pinned single tensor goes as it is."""
+        """Host tensors (the batch's images AND its target tensors) -> ONE pinned ring slab -> ONE H2D copy -> device views (never one small copy per tensor: a
+        pageable source makes every `.to(device)` a blocking round trip).  A large tensor the caller already pinned (DataLoader(pin_memory=True)) goes as it is.
+        The host-side copy into the slab is a plain memmove (ctypes: releases the GIL): torch's own CPU copy fans out over the intra-op thread pool, which --
+        called from a second thread on a many-core host -- costs several times the copy itself (measured: 40 ms per 57 MB batch on the 256-thread GPU box)."""
+        import ctypes
         while self._inflight and self._inflight[0][0].query():          # caller-pinned sources whose copies have completed
             self._inflight.popleft()
-        if len(items) == 1 and items[0].is_pinned() and items[0].is_contiguous():
-            src = items[0]                                               # (a DataLoader(pin_memory=True) batch: no second staging copy)
-            dst = torch.empty(src.shape, dtype=src.dtype, device=self.device)
-            dst.copy_(src, non_blocking=True)
+        out = [None] * len(items)
+        packed = []
+        for k, t in enumerate(items):
+            if t.is_cuda:
+                out[k] = t if t.device == self.device else t.to(self.device, non_blocking=True)
+            elif t.is_pinned() and t.is_contiguous() and t.numel() * t.element_size() >= (1 << 20):
+                dst = torch.empty(t.shape, dtype=t.dtype, device=self.device)
+                dst.copy_(t, non_blocking=True)
+                ev = torch.cuda.Event(); ev.record(self.copy_stream)
+                self._inflight.append((ev, t))                           # keeps the pinned source alive until its copy has run
+                self.bytes_h2d += t.numel() * t.element_size()
+                out[k] = dst
+            else:
+                packed.append(k)
+        if packed:
+            src = [items[k].contiguous() for k in packed]
+            offs, total = pack_plan(src)
+            i, slab = self._ring.next(total)
+            base = slab.data_ptr()
+            for t, o in zip(src, offs):
+                n = t.numel() * t.element_size()
+                if n:
+                    ctypes.memmove(base + o, t.data_ptr(), n)
+            dslab = torch.empty(total, dtype=torch.uint8, device=self.device)
+            dslab.copy_(slab[:total], non_blocking=True)
             ev = torch.cuda.Event(); ev.record(self.copy_stream)
-            self._inflight.append((ev, src))                             # keeps the pinned source alive until its copy has run
-            self.bytes_h2d += src.numel() * src.element_size()
-            return [dst]
-        offs, total = pack_plan(items)
-        i, slab = self._ring.next(total)
-        for t, o in zip(items, offs):
-            n = t.numel() * t.element_size()
-            slab[o:o + n].copy_(t.contiguous().view(-1).view(torch.uint8))   # host memcpy into pinned memory (releases the GIL)
-        dslab = torch.empty(total, dtype=torch.uint8, device=self.device)
-        dslab[:total].copy_(slab[:total], non_blocking=True)
-        ev = torch.cuda.Event(); ev.record(self.copy_stream)
-        self._ring.events[i] = ev
-        self.bytes_h2d += total
-        return [dslab[o:o + t.numel() * t.element_size()].view(t.dtype).view(t.shape) for t, o in zip(items, offs)]
+            self._ring.events[i] = ev
+            self.bytes_h2d += total
+            for k, t, o in zip(packed, src, offs):
+                out[k] = dslab[o:o + t.numel() * t.element_size()].view(t.dtype).view(t.shape)
+        return out
 
-    def _stage_images(self, images):
-        kind, items = classify_images(images, self.size)
-        dev = self._h2d(items)
+    def _images_on_device(self, kind, dev):
         if kind == "dense":
             x = dev[0]
             if x.dtype == self.dtype:
@@ -265,13 +280,6 @@ class DevicePrefetcher:
             return self.processor.normalize_sized(dev[0], chw=(kind == "u8_chw"))
         return self.processor(dev)["pixel_values"]
 
-    def _move(self, obj):
-        if torch.is_tensor(obj):
-            return obj.to(self.device, non_blocking=True)
-        if isinstance(obj, (list, tuple)) and obj and all(torch.is_tensor(o) for o in obj):
-            return type(obj)(o.to(self.device, non_blocking=True) for o in obj)
-        return obj
-
     def _stage(self, batch):
         if not isinstance(batch, (list, tuple)) or len(batch) < 1:
             raise TypeError("DevicePrefetcher: the loader must yield (images, *targets) tuples")
@@ -280,14 +288,35 @@ class DevicePrefetcher:
             rest = self.target_transform(*rest)
             if not isinstance(rest, tuple):
                 rest = (rest,)
+        import time
+        t0 = time.perf_counter()
+        kind, items = classify_images(images, self.size)
+        # target tensors ride in the same slab: (position in `rest`, index inside a list or None)
+        where, tensors = [], []
+        if self.move_targets:
+            for r, obj in enumerate(rest):
+                if torch.is_tensor(obj):
+                    where.append((r, None)); tensors.append(obj)
+                elif isinstance(obj, (list, tuple)) and obj and all(torch.is_tensor(o) for o in obj):
+                    for j, o in enumerate(obj):
+                        where.append((r, j)); tensors.append(o)
         with torch.cuda.stream(self.copy_stream):
-            img = self._stage_images(images)
-            if self.move_targets:
-                rest = tuple(self._move(r) for r in rest)
+            dev = self._h2d(list(items) + tensors)
+            img = self._images_on_device(kind, dev[:len(items)])
+            if tensors:
+                seq = {r: type(rest[r]) for r, j in where if j is not None}       # lists / tuples of tensors keep their type
+                rest = [list(o) if r in seq else o for r, o in enumerate(rest)]
+                for (r, j), d in zip(where, dev[len(items):]):
+                    if j is None:
+                        rest[r] = d
+                    else:
+                        rest[r][j] = d
+                rest = tuple(seq[r](o) if r in seq else o for r, o in enumerate(rest))
             ev = torch.cuda.Event()
             ev.record(self.copy_stream)
         self.batches += 1
-        return (img,) + rest, ev
+        self.stage_seconds += time.perf_counter() - t0
+        return (img,) + tuple(rest), ev
 
     # -- hand-over (the caller's thread and stream) ------------------------------------------------------------------------------------------------
     def _hand_over(self, staged):

@@ -10,7 +10,8 @@ import torch.nn.functional as F
 from oracle import owl_oracle as O
 
 
-SKIP = set()       # rounding points switched OFF (study only: which storage matters) -- names: w h q k qs v p o d1 g d2 feats box
+ROUND_LAYERS = None   # study only: encoder layers whose rounding points are ON (None = all)
+SKIP = set()       # rounding points switched OFF (study only: which storage matters) -- names: w h q k qs v p o d1 g d2 feats box img
 
 
 def bf(x, name=None):
@@ -19,9 +20,13 @@ def bf(x, name=None):
     return x.to(torch.bfloat16).to(torch.float32)
 
 
-def _layer(x, w, pre, heads, eps):
+def _layer(x, w, pre, heads, eps, index=None):
     B, T, D = x.shape
     dh = D // heads
+    if ROUND_LAYERS is not None and index is not None and index not in ROUND_LAYERS:
+        bf = lambda t, name=None: t                    # this layer computes in f32 throughout (study)
+    else:
+        bf = globals()["bf"]
     lin = lambda t, n: F.linear(t, bf(w[pre + n + ".weight"], "w"), w[pre + n + ".bias"])
     h = bf(F.layer_norm(x, (D,), w[pre + "layer_norm1.weight"], w[pre + "layer_norm1.bias"], eps), "h")
     q = bf(lin(h, "self_attn.q_proj"), "q").view(B, T, heads, dh).transpose(1, 2)
@@ -41,12 +46,12 @@ def _layer(x, w, pre, heads, eps):
 def model_forward_bf16_storage(cfg, w, image, taps=None):
     D, eps, g = cfg.hidden, cfg.ln_eps, cfg.grid
     B = image.shape[0]
-    pe = F.conv2d(bf(image), bf(w["backbone.embeddings.patch_embedding.weight"], "w"), stride=cfg.patch_size).flatten(2).transpose(1, 2)
+    pe = F.conv2d(bf(image, "img"), bf(w["backbone.embeddings.patch_embedding.weight"], "w"), stride=cfg.patch_size).flatten(2).transpose(1, 2)
     cls = w["backbone.embeddings.class_embedding"].expand(B, 1, -1)
     x = torch.cat([cls, pe], dim=1) + w["backbone.embeddings.position_embedding.weight"].unsqueeze(0)
     x = F.layer_norm(x, (D,), w["backbone.pre_layernorm.weight"], w["backbone.pre_layernorm.bias"], eps)
     for i in range(cfg.layers):
-        x = _layer(x, w, f"backbone.encoder.layers.{i}.", cfg.heads, eps)
+        x = _layer(x, w, f"backbone.encoder.layers.{i}.", cfg.heads, eps, index=i)
         if taps is not None:
             taps[f"backbone.encoder.layers.{i}.out"] = x
     x = F.layer_norm(x, (D,), w["backbone.post_layernorm.weight"], w["backbone.post_layernorm.bias"], eps)
