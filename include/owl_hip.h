@@ -32,7 +32,7 @@ extern "C" {
 
 /* ---- runtime ---------------------------------------------------------------------------------- */
 /* Bumped whenever a prototype, an argument's meaning or a caller-provided scratch layout changes (1 = round 1; 2 = round 2: per-call `tile` /
- * `variant` arguments, partial-sum scratch of the row reductions, 5D+4 box_final_bwd partials; 3 = round 3; 4 = round 4: `slow_tiles` statistic of the attention forward; 5 = round 5: owl_patch_embed_bf16's weight layout for patch sizes that are not 2^n (gathered, no im2row); the V^T attention form, attention variants 3-5, GEMM epilogues 5 / 6 and tiles 8 / 9 / 5 / 4 moved to OWL_TUNING builds); 6 = round 6: + owl_patch_embed_scratch_bytes, owl_normalize_u8 (additions only; patch sizes must be even).  owl_abi_version() returns the value
+ * `variant` arguments, partial-sum scratch of the row reductions, 5D+4 box_final_bwd partials; 3 = round 3; 4 = round 4: `slow_tiles` statistic of the attention forward; 5 = round 5: owl_patch_embed_bf16's weight layout for patch sizes that are not 2^n (gathered, no im2row); the V^T attention form, attention variants 3-5, GEMM epilogues 5 / 6 and tiles 8 / 9 / 5 / 4 moved to OWL_TUNING builds); 6 = round 6: + owl_patch_embed_scratch_bytes, owl_normalize_u8, `phases` of owl_attention_bwd_bf16; GEMM epilogue 1 saves quick_gelu'(u) and epilogue 8 multiplies by it; patch sizes must be even.  owl_abi_version() returns the value
  * the library was BUILT with: a binding compares it with the header it was generated from and refuses a mismatch (_lib.load() does). */
 #define OWL_ABI_VERSION 6
 const char* owl_last_error(void);
@@ -41,8 +41,9 @@ int owl_abi_version(void);
 /* ---- GEMM  C[M,N] = A[M,K] . W[N,K]^T with fused epilogue ---------------------------------------
  * replaces aten::addmm/mm under HF5:437-439,457 (q/k/v/out proj), HF5:472,474 (fc1/fc2),
  * HF5:994-997 (box head dense0/1), ref src/models.py:25 (class dense0) and their autograd forms.
- * epi: 0 bias->bf16 | 1 bias+quick_gelu->bf16 (aux = pre-activation) | 2 bias+erf-gelu->bf16 |
- *      3 resid+acc+bias->f32 | 4 alpha*acc(+bias)->f32 | 8 acc*quick_gelu'(aux)->bf16 |
+ * epi: 0 bias->bf16 | 1 bias+quick_gelu->bf16 (aux, optional = bf16 quick_gelu'(pre-activation): ABI 6; ABI <= 5 saved the pre-activation) |
+ *      2 bias+erf-gelu->bf16 (aux, optional = pre-activation) |
+ *      3 resid+acc+bias->f32 | 4 alpha*acc(+bias)->f32 | 8 acc*aux->bf16 (aux = what epi 1 saved: the dX GEMM through quick-GELU is one multiply, ABI 6) |
  *      9 acc*gelu'(aux)->bf16 | 10 out f32 += acc | 11 split-K slab
  *      (5 atomicAdd f32 and 6 per-head transposed bf16: OWL_TUNING builds only -- the train path uses neither).
  * a_rows / w_rows clamp the tile loads; M, N guard the stores; K % 64 == 0.
@@ -100,7 +101,7 @@ int owl_attention_fwd_vrow_bf16(void* stream, const void* q, const void* k, cons
  * [B*Tp,D], lse from the forward; writes dqkv [B*Tp,3D] (dq|dk|dv, bf16).  Every transposed operand of the dK/dV/dQ MFMAs is read
  * out of the row-major tiles by the LDS hardware (ds_read_b64_tr_b16): no Q^T / K^T / dO^T copies exist.  dvec_ws: f32 [B,H,Tp]. */
 int owl_attention_bwd_workspace_bytes(int64_t B, int64_t H, int64_t Tp, int64_t* bytes);   /* dvec_ws; `bytes` is a HOST pointer */
-int owl_attention_bwd_bf16(void* stream, const void* qkv, const void* dO, const void* O, const float* lse, float* dvec_ws, void* dqkv, int64_t B, int64_t H, int64_t T, int64_t Tp, float scale);
+int owl_attention_bwd_bf16(void* stream, const void* qkv, const void* dO, const void* O, const float* lse, float* dvec_ws, void* dqkv, int64_t B, int64_t H, int64_t T, int64_t Tp, float scale, int phases);   /* phases (ABI 6): 0 = all three kernels; else a mask 1 dvec | 2 dK, dV | 4 dQ -- the last two only share inputs and may go to two streams behind the first */
 
 /* ---- post_layernorm on all tokens + class-token merge + post_post_layernorm (ref src/models.py:80-86);
  * optional fused final residual add (delta_bf16 -> x_out = x + delta, may alias x)                      */

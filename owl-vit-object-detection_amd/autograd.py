@@ -246,7 +246,7 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
                 r0, Mc = b0 * Tp, nb * Tp
                 R = lambda t: t[r0:r0 + Mc]
                 with torch.cuda.stream(s_):
-                    ops.gemm(ops.EPI_DQGELU_BF16, R(bw["dxb"]), fz[f"{i}.w2T"], R(bw["du"]), aux=R(Ls["u"]), M=Mc, N=I, K=D, concurrency=len(chunks))
+                    ops.gemm(ops.EPI_DQGELU_BF16, R(bw["dxb"]), fz[f"{i}.w2T"], R(bw["du"]), aux=R(Ls["gp"]), M=Mc, N=I, K=D, concurrency=len(chunks))
                     ops.gemm(ops.EPI_BIAS_BF16, R(bw["du"]), fz[f"{i}.w1T"], R(bw["dh"]), M=Mc, N=D, K=I, concurrency=len(chunks))
                     # (the LayerNorm backward also writes the bf16 copy of its dx: the operand of the next dX GEMM, no separate cast pass)
                     ops.layernorm_bwd(R(bw["dh"]), R(Ls["x_mid"]), R(Ls["st2"]), P_[pre + "layer_norm2.weight"], R(bw["dx"]), R(bw["dxm"]), None, None,
@@ -286,7 +286,7 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
         ops.colsum_f32(bw["dx"], G(tl + "mlp.fc2.bias"), M, D, partials=bw["part"])
     on_side(0, lambda: dW(bw["dxb"], Lt["g"], G(tl + "mlp.fc2.weight"), D, I, M, Mp, part="part2"))
     dxc = 1 if side is main else 2          # (the weight-gradient GEMMs run beside the dX chain: ops.gemm's small-problem rule counts them)
-    ops.gemm(ops.EPI_DQGELU_BF16, bw["dxb"], wT(tl + "mlp.fc2.weight", D, I), bw["du"], aux=Lt["u"], M=M, N=I, K=D, concurrency=dxc)
+    ops.gemm(ops.EPI_DQGELU_BF16, bw["dxb"], wT(tl + "mlp.fc2.weight", D, I), bw["du"], aux=Lt["gp"], M=M, N=I, K=D, concurrency=dxc)
     on_side(1, lambda: dW(bw["du"], Lt["h2"], G(tl + "mlp.fc1.weight"), I, D, M, Mp, G(tl + "mlp.fc1.bias"), part="part2"))
     ops.gemm(ops.EPI_BIAS_BF16, bw["du"], wT(tl + "mlp.fc1.weight", I, D), bw["dh"], M=M, N=D, K=I, concurrency=dxc)
     ops.layernorm_bwd(bw["dh"], Lt["x_mid"], Lt["st2"], P_[tl + "layer_norm2.weight"], bw["dx"], bw["dxm"],

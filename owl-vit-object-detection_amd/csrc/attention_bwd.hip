@@ -437,8 +437,10 @@ OWL_API int owl_attention_bwd_workspace_bytes(int64_t B, int64_t H, int64_t Tp, 
 
 OWL_API int owl_attention_bwd_bf16(void* stream, const void* qkv, const void* dO, const void* O,
                                       const float* lse, float* dvec_ws, void* dqkv, int64_t B, int64_t H, int64_t T, int64_t Tp,
-                                      float scale) {
+                                      float scale, int phases) {
     OWL_CHECK_ARG(qkv && dO && O && lse && dvec_ws && dqkv, "owl_attention_bwd_bf16: null pointer");
+    OWL_CHECK_ARG(phases >= 0 && phases <= 7, "owl_attention_bwd_bf16: phases is a mask of 1 (dvec) | 2 (dK, dV) | 4 (dQ); 0 = all");
+    if (phases == 0) phases = 7;
     OWL_CHECK_ARG(Tp % 8 == 0 && T > 0 && T <= Tp, "owl_attention_bwd_bf16: Tp %% 8, T <= Tp");
     AttnBwdP p{};
     p.D = (int)(H * 64);
@@ -454,13 +456,20 @@ OWL_API int owl_attention_bwd_bf16(void* stream, const void* qkv, const void* dO
         (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BWD2_STAGE);
     });
     const int64_t nd = B * Tp * (H * 8);                       // one thread per 16-byte chunk
-    hipLaunchKernelGGL(attn_dvec_kernel, dim3((unsigned)((nd + 255) / 256), 1, 1), dim3(256), 0, s, p);
-    OWL_LAUNCH_CHECK();
+    if (phases & 1) {
+        hipLaunchKernelGGL(attn_dvec_kernel, dim3((unsigned)((nd + 255) / 256), 1, 1), dim3(256), 0, s, p);
+        OWL_LAUNCH_CHECK();
+    }
     const int64_t npairs8 = (B * H + 7) / 8;                  // (image, head) pairs per XCD, rounded up
     dim3 grid((unsigned)(npairs8 * ((T + 127) / 128) * 8));
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(256), 2 * BWD1_STAGE, s, p);
-    OWL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 2 * BWD2_STAGE, s, p);
-    OWL_LAUNCH_CHECK();
+    // dK / dV and dQ only share their inputs (and write disjoint column thirds of dqkv): a caller may give them to two streams behind the dvec pass (`phases`)
+    if (phases & 2) {
+        hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(256), 2 * BWD1_STAGE, s, p);
+        OWL_LAUNCH_CHECK();
+    }
+    if (phases & 4) {
+        hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 2 * BWD2_STAGE, s, p);
+        OWL_LAUNCH_CHECK();
+    }
     return 0;
 }

@@ -9,14 +9,14 @@ constexpr int NUM_CUS = 256;
 
 enum {
     EPI_BIAS_BF16 = 0,   // out bf16 = acc + bias
-    EPI_QGELU_BF16 = 1,  // u = acc + bias; out bf16 = u*sigmoid(1.702u); aux (optional) bf16 = u
+    EPI_QGELU_BF16 = 1,  // u = acc + bias; out bf16 = u*sigmoid(1.702u); aux (optional) bf16 = quick_gelu'(u) (round 6; before: u) -- what EPI_DQGELU_BF16 multiplies by
     EPI_GELU_BF16 = 2,   // erf GELU, aux (optional) bf16 = u
     EPI_RESID_F32 = 3,   // out f32 = resid + acc + bias
     EPI_F32 = 4,         // out f32 = alpha*acc (+ bias)
     EPI_ATOMIC_F32 = 5,  // atomicAdd(out f32, alpha*acc)            (split-K)
     EPI_TRANS_BF16 = 6,  // out_t[b][n][t] bf16 = acc + bias, m = b*Tp + t   (per-head transposed)
     EPI_PATCH_F32 = 7,   // A gathered from image patches (any patch size >= 8: rows padded to 2^n in the K index only); out f32 [b*Tp + 1 + p][n] = acc + pos[1+p][n]
-    EPI_DQGELU_BF16 = 8, // out bf16 = acc * quick_gelu'(aux u)
+    EPI_DQGELU_BF16 = 8, // out bf16 = acc * aux   (aux = the quick_gelu' the forward epilogue saved: one multiply, no transcendental)
     EPI_DGELU_BF16 = 9,  // out bf16 = acc * gelu_erf'(aux u)
     EPI_ACC_F32 = 10,    // out f32 += acc   (resid == out)
     EPI_SLAB_F32 = 11,   // split-K partial: out f32 [split][M][N] = alpha*acc   (reduced by owl_slab_reduce)
@@ -46,10 +46,14 @@ __device__ __forceinline__ float sigmoid1702_f(float u) {   // 1 / (1 + exp(-1.7
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * u));
 }
 __device__ __forceinline__ float qgelu_f(float u) { return u * sigmoid1702_f(u); }
-__device__ __forceinline__ float dqgelu_f(float u) {
-    const float s = sigmoid1702_f(u);
-    return s * (1.0f + 1.702f * u * (1.0f - s));
+// quick_gelu'(u) = s (1 + 1.702 u (1 - s)) from the sigmoid s the forward epilogue has in hand anyway.  Round 6: the quick-GELU epilogue SAVES THIS (bf16) instead
+// of the pre-activation, and the backward epilogue (EPI_DQGELU_BF16) is one multiply: no v_exp / v_rcp in the dX GEMM, same bytes.  Explicit operation order
+// (mul, sub, fma, mul): every kernel of the family gives the same bits.
+__device__ __forceinline__ float dqgelu_from_s(float u, float s) {
+    const float t = 1.702f * u, om = 1.0f - s;
+    return s * fmaf(t, om, 1.0f);
 }
+__device__ __forceinline__ float dqgelu_f(float u) { return dqgelu_from_s(u, sigmoid1702_f(u)); }
 __device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752f)); }
 __device__ __forceinline__ float dgelu_f(float u) { return dgelu_erf_f(u); }   // (common.h)
 
@@ -73,20 +77,27 @@ __device__ __forceinline__ void epi_quad(const GemmP& p, int64_t orow, const flo
         uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
         *(uint2*)((bf16_t*)p.out + orow * p.ldo + n) = o;
     } else if constexpr (EPI == EPI_QGELU_BF16 || EPI == EPI_GELU_BF16) {
+        float g[4], sv[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            if constexpr (EPI == EPI_QGELU_BF16) {
+                const float sg = sigmoid1702_f(v[e]);
+                g[e] = v[e] * sg; sv[e] = dqgelu_from_s(v[e], sg);          // saved: the derivative
+            } else {
+                g[e] = gelu_f(v[e]); sv[e] = v[e];                           // saved: the pre-activation
+            }
+        }
         if (p.aux) {
-            uint2 a; a.x = pack_bf2(v[0], v[1]); a.y = pack_bf2(v[2], v[3]);
+            uint2 a; a.x = pack_bf2(sv[0], sv[1]); a.y = pack_bf2(sv[2], sv[3]);
             *(uint2*)((bf16_t*)p.aux + orow * p.ld_aux + n) = a;
         }
-        float g[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) g[e] = (EPI == EPI_QGELU_BF16) ? qgelu_f(v[e]) : gelu_f(v[e]);
         uint2 o; o.x = pack_bf2(g[0], g[1]); o.y = pack_bf2(g[2], g[3]);
         *(uint2*)((bf16_t*)p.out + orow * p.ldo + n) = o;
     } else if constexpr (EPI == EPI_DQGELU_BF16 || EPI == EPI_DGELU_BF16) {
         const uint2 a = *(const uint2*)((const bf16_t*)p.aux + orow * p.ld_aux + n);
         const float u[4] = {bf2f(a.x & 0xffff), bf2f(a.x >> 16), bf2f(a.y & 0xffff), bf2f(a.y >> 16)};
 #pragma unroll
-        for (int e = 0; e < 4; e++) v[e] *= (EPI == EPI_DQGELU_BF16) ? dqgelu_f(u[e]) : dgelu_f(u[e]);
+        for (int e = 0; e < 4; e++) v[e] *= (EPI == EPI_DQGELU_BF16) ? u[e] : dgelu_f(u[e]);
         uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
         *(uint2*)((bf16_t*)p.out + orow * p.ldo + n) = o;
     } else if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_ACC_F32) {
@@ -247,10 +258,7 @@ __device__ __forceinline__ void epi_tile_bf16(const GemmP& p, const f32x16& acc,
             const f32x2_t v23 = __builtin_elementwise_fma((f32x2_t){acc[qd * 4 + 2], acc[qd * 4 + 3]}, al, b23);
             v[0] = v01.x; v[1] = v01.y; v[2] = v23.x; v[3] = v23.y;
             if constexpr (EPI == EPI_QGELU_BF16 || EPI == EPI_GELU_BF16) {
-                if (p.aux) {                               // wave-uniform; pre-activation save (trainable layer only)
-                    uint2 a; a.x = pack_bf2(v[0], v[1]); a.y = pack_bf2(v[2], v[3]);
-                    if (ok) *(uint2*)((bf16_t*)aux_row + 8 * qd) = a;
-                }
+                float sv[4] = {v[0], v[1], v[2], v[3]};    // what is saved for the backward: erf-GELU the pre-activation, quick-GELU its derivative (below)
                 if constexpr (EPI == EPI_QGELU_BF16) {
                     // u * 1/(1 + exp2(-2.4555 u)), two elements per VALU instruction where the ISA has a packed form
                     // (v_pk_mul_f32 / v_pk_add_f32); v_exp / v_rcp stay scalar.  Same operations as qgelu_f, same rounding.
@@ -259,12 +267,18 @@ __device__ __forceinline__ void epi_tile_bf16(const GemmP& p, const f32x16& acc,
                         const f32x2_t u = {v[e], v[e + 1]};
                         const f32x2_t t = u * -2.4554669595930156f;
                         const f32x2_t d = (f32x2_t){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + 1.0f;
-                        const f32x2_t o = u * (f32x2_t){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+                        const f32x2_t r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+                        const f32x2_t o = u * r;
+                        if (p.aux) { sv[e] = dqgelu_from_s(u.x, r.x); sv[e + 1] = dqgelu_from_s(u.y, r.y); }     // (wave-uniform branch)
                         v[e] = o.x; v[e + 1] = o.y;
                     }
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; e++) v[e] = gelu_f(v[e]);
+                }
+                if (p.aux) {                               // wave-uniform; saved for the backward (layers the backward passes through only)
+                    uint2 a; a.x = pack_bf2(sv[0], sv[1]); a.y = pack_bf2(sv[2], sv[3]);
+                    if (ok) *(uint2*)((bf16_t*)aux_row + 8 * qd) = a;
                 }
             } else if constexpr (EPI == EPI_DQGELU_BF16 || EPI == EPI_DGELU_BF16) {
                 uint2 a = make_uint2(0u, 0u);
@@ -272,7 +286,7 @@ __device__ __forceinline__ void epi_tile_bf16(const GemmP& p, const f32x16& acc,
                 else if (ok) a = *(const uint2*)(aux_row + 8 * qd);
                 const float u[4] = {bf2f(a.x & 0xffff), bf2f(a.x >> 16), bf2f(a.y & 0xffff), bf2f(a.y >> 16)};
 #pragma unroll
-                for (int e = 0; e < 4; e++) v[e] *= (EPI == EPI_DQGELU_BF16) ? dqgelu_f(u[e]) : dgelu_f(u[e]);
+                for (int e = 0; e < 4; e++) v[e] *= (EPI == EPI_DQGELU_BF16) ? u[e] : dgelu_f(u[e]);       // (quick-GELU: the saved derivative itself)
             }
             w[2 * qd] = pack_bf2(v[0], v[1]);
             w[2 * qd + 1] = pack_bf2(v[2], v[3]);
@@ -335,20 +349,23 @@ __device__ __forceinline__ void epi_lines_bf16(const GemmP& p, const f32x16& acc
             const f32x2_t v23 = __builtin_elementwise_fma((f32x2_t){acc[qd * 4 + 2], acc[qd * 4 + 3]}, al, b23);
             v[0] = v01.x; v[1] = v01.y; v[2] = v23.x; v[3] = v23.y;
             if constexpr (EPI == EPI_QGELU_BF16 || EPI == EPI_GELU_BF16) {
-                if (p.aux) { a[8 * j + 2 * qd] = pack_bf2(v[0], v[1]); a[8 * j + 2 * qd + 1] = pack_bf2(v[2], v[3]); }
+                float sv[4] = {v[0], v[1], v[2], v[3]};
                 if constexpr (EPI == EPI_QGELU_BF16) {
 #pragma unroll
                     for (int e = 0; e < 4; e += 2) {
                         const f32x2_t u = {v[e], v[e + 1]};
                         const f32x2_t t = u * -2.4554669595930156f;
                         const f32x2_t dd = (f32x2_t){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + 1.0f;
-                        const f32x2_t o = u * (f32x2_t){__builtin_amdgcn_rcpf(dd.x), __builtin_amdgcn_rcpf(dd.y)};
+                        const f32x2_t r = {__builtin_amdgcn_rcpf(dd.x), __builtin_amdgcn_rcpf(dd.y)};
+                        const f32x2_t o = u * r;
+                        if (p.aux) { sv[e] = dqgelu_from_s(u.x, r.x); sv[e + 1] = dqgelu_from_s(u.y, r.y); }
                         v[e] = o.x; v[e + 1] = o.y;
                     }
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; e++) v[e] = gelu_f(v[e]);
                 }
+                if (p.aux) { a[8 * j + 2 * qd] = pack_bf2(sv[0], sv[1]); a[8 * j + 2 * qd + 1] = pack_bf2(sv[2], sv[3]); }
             }
             d[8 * j + 2 * qd] = pack_bf2(v[0], v[1]);
             d[8 * j + 2 * qd + 1] = pack_bf2(v[2], v[3]);

@@ -276,7 +276,8 @@ class OwlViT(nn.Module):
         z = ops.zeros_rows
         L = dict(x_in=z(M, D, f32, dev), x_mid=z(M, D, f32, dev), st1=torch.zeros(M, 2, device=dev), st2=torch.zeros(M, 2, device=dev),
                  qkv=z(M, 3 * D, bf, dev), att=z(M, D, bf, dev),
-                 lse=torch.zeros(B, cfg.heads, Tp, device=dev), u=z(M, I, bf, dev))
+                 lse=torch.zeros(B, cfg.heads, Tp, device=dev),
+                 gp=z(M, I, bf, dev))          # quick_gelu'(u), saved by fc1's epilogue: what the dX GEMM through the activation multiplies by
         if i == cfg.trainable_layer():   # dW operands
             L.update(h1=z(M, D, bf, dev), h2=z(M, D, bf, dev), g=z(M, I, bf, dev))
         self._ws[key] = L
@@ -422,7 +423,7 @@ class OwlViT(nn.Module):
         ops.layernorm(x_cur, lw["g2"], lw["be2"], h2, M, D, R(Ls["st2"]) if sv else None, cfg.ln_eps, delta=d1, x_out=x_mid,
                       store_x=not defer)
         g_l = R(Ls["g"]) if full else R(ws["g"])
-        ops.gemm(ops.EPI_QGELU_BF16, h2, lw["w1"], g_l, bias=lw["b1"], aux=R(Ls["u"]) if sv else None, M=M, N=I, K=D, concurrency=cc)
+        ops.gemm(ops.EPI_QGELU_BF16, h2, lw["w1"], g_l, bias=lw["b1"], aux=R(Ls["gp"]) if sv else None, M=M, N=I, K=D, concurrency=cc)
         ops.gemm(ops.EPI_BIAS_BF16, g_l, lw["w2"], d2, bias=lw["b2"], M=M, N=D, K=I, concurrency=cc)
         st["pending"], st["xs"] = d2, x_mid
         st["pending1"] = d1 if defer else None

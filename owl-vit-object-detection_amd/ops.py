@@ -232,8 +232,9 @@ def colsum_f32(src, colsum, R, C, partials=None):
     _lib.call("owl_colsum_f32", stream(), src, colsum, R, C, part, part.numel())
 
 
-def attention_bwd(qkv, dO, O, lse, dvec, dqkv, B, H, T, Tp, scale):
-    _lib.call("owl_attention_bwd_bf16", stream(), qkv, dO, O, lse, dvec, dqkv, B, H, T, Tp, float(scale))
+def attention_bwd(qkv, dO, O, lse, dvec, dqkv, B, H, T, Tp, scale, phases=0):
+    """phases: 0 = dvec + dK / dV + dQ on this stream; a mask (1 | 2 | 4) launches a subset (dK / dV and dQ only share inputs: tools/attn_bwd_overlap_ab.py)."""
+    _lib.call("owl_attention_bwd_bf16", stream(), qkv, dO, O, lse, dvec, dqkv, B, H, T, Tp, float(scale), int(phases))
 
 
 _pp_ws = {}

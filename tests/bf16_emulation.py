@@ -79,7 +79,8 @@ def model_forward_bf16_storage(cfg, w, image, taps=None):
 #   * every stored activation's GRADIENT is stored in bf16 too (dxb / dxb2 = d(branch outputs), datt = d(attention output), dqkv, dh = d(LN outputs), du)
 #     -> `rb`: round forward and backward;   feats: bf16 forward, f32 gradient (EPI_F32 / EPI_ACC_F32) -> `rf`;   e: f32 forward, bf16 gradient (de) -> `rg`;
 #   * weights: bf16 compute copy, f32 gradient (split-K slabs) -> `rf` (straight-through);
-#   * d(pre-activation) = bf16(acc * act'(bf16 pre-activation)): ONE rounding after the product, the derivative taken at the STORED pre-activation;
+#   * d(pre-activation) = bf16(acc * act'): ONE rounding after the product; erf-GELU (box head): the derivative taken at the STORED (bf16) pre-activation;
+#     quick-GELU (round 6): the STORED derivative bf16(act'(f32 pre-activation)), saved by the forward epilogue;
 #   * attention backward: P and dS recomputed per kernel from the forward's log-sum-exp -- dK / dV kernel: S = Q . bf16(c K)^T, dQ kernel: S = bf16(c Q) . K^T --,
 #     P and dS = P (dP - D) rounded to bf16 as MFMA operands, D = rowsum(dO . O) on the stored (bf16) O, dK / dQ scaled in f32.
 # A HIP gradient that sits as far from the oracle as this emulation does (and closer to the emulation) carries the data type's error, not a kernel's.
@@ -102,21 +103,26 @@ def _r(x): return x.to(torch.bfloat16).to(torch.float32)
 
 
 class _ActStore(torch.autograd.Function):
-    """y = act(u); backward d(u) = bf16(dy * act'(bf16(u))) (gemm_common.h EPI_DQGELU / EPI_DGELU: aux = the bf16 pre-activation)."""
+    """y = act(u).  erf-GELU (box head): backward d(u) = bf16(dy * act'(bf16(u))) -- gemm_common.h EPI_DGELU, aux = the bf16 pre-activation.
+    quick-GELU (encoder MLP, round 6): the forward epilogue saves bf16(act'(u)) taken at the f32 pre-activation and the backward epilogue is one multiply:
+    d(u) = bf16(dy * bf16(act'(u))) -- EPI_QGELU's aux / EPI_DQGELU."""
     @staticmethod
     def forward(ctx, u, kind):
         ctx.kind = kind
-        ctx.save_for_backward(_r(u))
+        if kind == "quick":
+            s = torch.sigmoid(1.702 * u)
+            ctx.save_for_backward(_r(s * (1.0 + 1.702 * u * (1.0 - s))))
+        else:
+            ctx.save_for_backward(_r(u))
         return O.quick_gelu(u) if kind == "quick" else F.gelu(u)
 
     @staticmethod
     def backward(ctx, dy):
-        (ub,) = ctx.saved_tensors
+        (sb,) = ctx.saved_tensors
         if ctx.kind == "quick":
-            s = torch.sigmoid(1.702 * ub)
-            d = s * (1.0 + 1.702 * ub * (1.0 - s))
+            d = sb
         else:
-            d = 0.5 * (1.0 + torch.erf(ub * 0.7071067811865476)) + ub * torch.exp(-0.5 * ub * ub) * 0.3989422804014327
+            d = 0.5 * (1.0 + torch.erf(sb * 0.7071067811865476)) + sb * torch.exp(-0.5 * sb * sb) * 0.3989422804014327
         return _r(dy * d), None
 
 

@@ -80,10 +80,14 @@ def test_gemm_epilogues(gemm_tile):
     bias = rnd(N, seed=2)
     acc = A[:M].float() @ W.float().t()
     u = acc + bias
-    # quick-gelu with pre-activation
+    # quick-gelu; saved for the backward: its derivative at the f32 pre-activation (round 6; before: the pre-activation itself)
     out = ops.zeros_rows(M, N, torch.bfloat16, DEV); aux = ops.zeros_rows(M, N, torch.bfloat16, DEV)
     ops.gemm(ops.EPI_QGELU_BF16, A, W, out, bias=bias, aux=aux, M=M)
-    report("qgelu", out[:M], qgelu(u), 2e-2, 1e-2); report("qgelu aux", aux[:M], u, 2e-2, 1e-2)
+    sg = torch.sigmoid(1.702 * u)
+    report("qgelu", out[:M], qgelu(u), 2e-2, 1e-2); report("qgelu aux = quick_gelu'(u)", aux[:M], sg * (1.0 + 1.702 * u * (1.0 - sg)), 5e-3, 5e-3)
+    out2 = ops.zeros_rows(M, N, torch.bfloat16, DEV)
+    ops.gemm(ops.EPI_QGELU_BF16, A, W, out2, bias=bias, M=M)
+    assert torch.equal(out, out2)                       # saving the derivative does not touch the output's bits
     # erf gelu
     out.zero_()
     ops.gemm(ops.EPI_GELU_BF16, A, W, out, bias=bias, M=M)
@@ -117,11 +121,15 @@ def test_gemm_epilogues(gemm_tile):
     upre = ops.zeros_rows(M, N, torch.bfloat16, DEV); upre[:M] = rnd(M, N, seed=9).bfloat16()
     uf = upre[:M].float()
     uf.requires_grad_(True)
-    (g1,) = torch.autograd.grad(qgelu(uf).sum(), uf)
     (g2,) = torch.autograd.grad(F.gelu(uf).sum(), uf)
     out.zero_()
-    ops.gemm(ops.EPI_DQGELU_BF16, A, W, out, aux=upre, M=M)
-    report("dqgelu", out[:M], acc * g1, 2e-2, 1e-2)
+    ops.gemm(ops.EPI_DQGELU_BF16, A, W, out, aux=upre, M=M)       # out = acc * aux: aux IS the derivative the forward epilogue saved
+    report("dqgelu (multiply by the saved derivative)", out[:M], acc * upre[:M].float(), 2e-2, 1e-2)
+    # ... and the pair end to end: forward saves quick_gelu'(u), backward multiplies -> d(u) of the autograd reference
+    uu = (A[:M].float() @ W.float().t() + bias).detach().requires_grad_(True)
+    (g1,) = torch.autograd.grad(qgelu(uu).sum(), uu)
+    ops.gemm(ops.EPI_DQGELU_BF16, A, W, out, aux=aux, M=M)
+    report("dqgelu, forward-saved derivative", out[:M], acc * g1, 2e-2, 1e-2)
     ops.gemm(ops.EPI_DGELU_BF16, A, W, out, aux=upre, M=M)
     report("dgelu", out[:M], acc * g2, 2e-2, 1e-2)
 
