@@ -50,8 +50,8 @@ PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md "Peak BF16/FP
 # (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE in separate passes, FETCH x2 per MI355X_MICROARCH.md "HBM"); None elsewhere
 # The JSON carries the digest of the kernel sources it was measured on (tools/pmc_traffic.py); a figure taken on other sources is
 # refused (traffic = null) rather than quoted: a kernel edit must not silently keep an old number.
-TRAFFIC_FILE = "profiles/r05_traffic.json"
-TRAFFIC_SOURCE = "profiles/r05_hbm_traffic.md"
+TRAFFIC_FILE = "profiles/r06_traffic.json"
+TRAFFIC_SOURCE = "profiles/r06_hbm_traffic.md"
 LABEL_BIAS = "gemm op <bias> (gemm_pp2_kernel + gemm_pph_kernel remainder)"
 LABEL_QGELU = "gemm_pp2_kernel<qgelu>"
 LABEL_ATTN = "attn_fwd_kernel<VROW>"

@@ -22,7 +22,8 @@ int owl_gemm_pp2_slots(int n);
 /* ... 1: skip every epilogue store of that kernel (tools/gemm_nostore_ab.py) */
 int owl_gemm_pp2_nostore(int on);
 int owl_gemm_pp2_block_width(int epi, int bw);   /* tile order of the two-phase GEMM: epi 0 bias / 1 quick-GELU; bw 0 = the launcher's rule, else column blocks of the largest divisor of tiles_n up to bw */
-int owl_gemm_pp2_lines(int on);              /* quad-contiguous epilogue stores: 0 off, 1 bias epilogue (default, = the product), 2 quick-GELU epilogue too */
+int owl_gemm_pp2_lines(int on);              /* quad-contiguous epilogue stores: 0 off, 1 bias epilogue (default, = the product), 2 quick-GELU epilogue too, 3 + dX through quick-GELU' (its saved tile is loaded that way too) */
+int owl_gemm_pp2_stagger(int n);             /* round 6 experiment: every second workgroup of an XCD starts n x ~8 k cycles late (epilogue bursts of the two halves interleave) */
 int owl_gemm_pp2_ablate(int a);              /* timing-only ablations of the shipped two-phase GEMM: bit 0 no LDS-DMA requests after the prologue, bit 1 fragments read once per tile, bit 2 no epilogue */
 int owl_gemm_pp2_trace(void* buf);
 /* ... which of workgroup 0's tiles is stamped (0 = its first; later tiles see the sustained clock and warm queues) */

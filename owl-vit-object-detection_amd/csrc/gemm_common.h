@@ -39,6 +39,7 @@ struct GemmP {
     int ps_magic;          // 65536 / ps + 1: R / ps == (R * ps_magic) >> 16 for the gather's row index R < 3 ps + 8 (patch sizes that are not 2^n)
     const float* pos;      // [T, N]
     int64_t slab_stride;   // EPI_SLAB: elements per split slab
+    int stagger;           // gemm_pp2: start delay of every second workgroup of an XCD, in units of s_sleep 127 (0 = none)
     int dbg;               // read by the kernels of an OWL_TUNING build only: bit 1 = stores wrapped into a cache-resident window, bit 2 = non-temporal bf16 stores
 };
 
@@ -325,14 +326,63 @@ __device__ __forceinline__ void epi_lines_bias_preload(const float* lds_bias, in
                  : "v"(a) : "memory");
 }
 
+// 4 x 4 transposition of a lane's four 16-byte pieces d[4t .. 4t+3] against the four lanes of its quad: two butterfly stages; lanes l and l ^ X exchange so
+// that the lane with bit X clear ends with (x, partner's x) and the other with (partner's y, y).  hipcc makes a select + v_mov_b32_dpp + two selects of each
+// pair and stage.  Its own inverse: "piece t of my row" <-> "piece (lane & 3) of row (lane & 28) + t".
+// (Hand-written v_cndmask_b32_dpp pairs -- x' = bit ? partner.y : x, y' = bit ? y : partner.x, half the instructions, VCC set by
+// hand -- measured SLOWER in the model, 1209 against 1212.5 img/s on one box: the asm blocks pin the order hipcc otherwise interleaves with the
+// conversion of the next row block and the stores.)
+__device__ __forceinline__ void quad_transpose16(unsigned (&d)[16], int lane) {
+    const bool o1 = lane & 1, o2 = lane & 2;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            unsigned& x = d[8 * g + c]; unsigned& y = d[8 * g + 4 + c];
+            const unsigned u = (unsigned)__builtin_amdgcn_mov_dpp((int)(o1 ? x : y), 0xB1, 0xF, 0xF, true);
+            if (o1) x = u; else y = u;
+        }
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            unsigned& x = d[4 * g + c]; unsigned& y = d[4 * g + 8 + c];
+            const unsigned u = (unsigned)__builtin_amdgcn_mov_dpp((int)(o2 ? x : y), 0x4E, 0xF, 0xF, true);
+            if (o2) x = u; else y = u;
+        }
+    }
+}
+
+// The saved tile of EPI_DQGELU_BF16 (p.aux) for one row block of the quad-contiguous epilogue, LOADED the way that epilogue stores (round 6): instruction t
+// reads row (lane & 28) + t, the quad's four lanes 64 contiguous bytes of it -- one step of the CU's load path where epi_aux_load's accumulator-layout pattern
+// (a row's two 16-byte pieces in lanes r and r + 32) takes four (tools/probe/store_pattern.hip: 1.5 against 4.3 us per 128-KiB tile and CU).  x[4t .. 4t+3] is
+// what instruction t returned; quad_transpose16 turns it into the lane's own 64 bytes (word 8 j + 2 qd + s = columns 16 j + 4 qd + 2 s, + 1 of its half).
+template <bool GUARD>
+__device__ __forceinline__ void epi_lines_aux_load(const GemmP& p, int64_t m_tile, int64_t n_wave, int lane, unsigned (&x)[16]) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+    const int hi = lane >> 5;
+    // wave-uniform base (SGPR pair) + one 32-bit lane offset per load: 64-bit per-lane addresses cost the registers the two row blocks in flight need
+    const bf16_t* base = (const bf16_t*)p.aux + m_tile * p.ld_aux + n_wave;
+    const unsigned ld = (unsigned)p.ld_aux, col = 32u * hi + 8u * (lane & 3), r0 = (unsigned)(lane & 28);
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        u32x4_t v = {0u, 0u, 0u, 0u};
+        if (!GUARD || (m_tile + r0 + t < p.M && n_wave + col < p.N)) v = *(const u32x4_t*)(base + ((r0 + t) * ld + col));
+        x[4 * t] = v[0]; x[4 * t + 1] = v[1]; x[4 * t + 2] = v[2]; x[4 * t + 3] = v[3];
+    }
+}
+
 template <int EPI, bool GUARD>
 __device__ __forceinline__ void epi_lines_bf16(const GemmP& p, const f32x16& acc0, const f32x16& acc1, int64_t m_tile, int64_t n_wave, int lane,
-                                               const float* lds_bias, const f32x4* bias_pre = nullptr) {   // bias_pre[4 j + qd]: epi_lines_bias_preload
-    static_assert(EPI == EPI_BIAS_BF16 || EPI == EPI_QGELU_BF16 || EPI == EPI_GELU_BF16, "quad-contiguous epilogue: forward bf16 epilogues only");
+                                               const float* lds_bias, const f32x4* bias_pre = nullptr,   // bias_pre[4 j + qd]: epi_lines_bias_preload
+                                               unsigned* aux_words = nullptr) {                         // EPI_DQGELU: the lane's own 64 bytes of p.aux (epi_lines_aux_load + quad_transpose16); overwritten
+    static_assert(EPI == EPI_BIAS_BF16 || EPI == EPI_QGELU_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_DQGELU_BF16,
+                  "quad-contiguous epilogue: forward bf16 epilogues and the multiply-by-saved-derivative one");
     const int hi = lane >> 5;
     const int64_t m = m_tile + (lane & 31);
     const float* bias_p = lds_bias + 32 * hi;
-    unsigned d[16], a[16];
+    unsigned d_own[16], a[16];
+    // EPI_DQGELU: the packed products replace the aux words they were formed from (word k of d and of aux_words hold the same two elements): 16 registers
+    // less while two row blocks of aux are in flight
+    unsigned (&d)[16] = (EPI == EPI_DQGELU_BF16) ? *reinterpret_cast<unsigned (*)[16]>(aux_words) : d_own;
 #pragma unroll
     for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -366,6 +416,9 @@ __device__ __forceinline__ void epi_lines_bf16(const GemmP& p, const f32x16& acc
                     for (int e = 0; e < 4; e++) v[e] = gelu_f(v[e]);
                 }
                 if (p.aux) { a[8 * j + 2 * qd] = pack_bf2(sv[0], sv[1]); a[8 * j + 2 * qd + 1] = pack_bf2(sv[2], sv[3]); }
+            } else if constexpr (EPI == EPI_DQGELU_BF16) {
+                const unsigned a0 = aux_words[8 * j + 2 * qd], a1 = aux_words[8 * j + 2 * qd + 1];
+                v[0] *= bf2f(a0 & 0xffff); v[1] *= bf2f(a0 >> 16); v[2] *= bf2f(a1 & 0xffff); v[3] *= bf2f(a1 >> 16);      // same product as epi_tile_bf16 / epi_quad
             }
             d[8 * j + 2 * qd] = pack_bf2(v[0], v[1]);
             d[8 * j + 2 * qd + 1] = pack_bf2(v[2], v[3]);
@@ -380,29 +433,7 @@ __device__ __forceinline__ void epi_lines_bf16(const GemmP& p, const f32x16& acc
                     *(u32x4_t*)(aux_row + 8 * t) = (u32x4_t){a[4 * t], a[4 * t + 1], a[4 * t + 2], a[4 * t + 3]};
         }
     }
-    // 4 x 4 transposition of the 16-byte pieces d[4t .. 4t+3] against the quad's lanes: two butterfly stages; lanes l and l ^ X exchange so that the
-    // lane with bit X clear ends with (x, partner's x) and the other with (partner's y, y).  hipcc makes a select + v_mov_b32_dpp + two selects of each
-    // pair and stage.  (Hand-written v_cndmask_b32_dpp pairs -- x' = bit ? partner.y : x, y' = bit ? y : partner.x, half the instructions, VCC set by
-    // hand -- measured SLOWER in the model, 1209 against 1212.5 img/s on one box: the asm blocks pin the order hipcc otherwise interleaves with the
-    // conversion of the next row block and the stores.)
-    {
-        const bool o1 = lane & 1, o2 = lane & 2;
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-#pragma unroll
-            for (int g = 0; g < 2; g++) {
-                unsigned& x = d[8 * g + c]; unsigned& y = d[8 * g + 4 + c];
-                const unsigned u = (unsigned)__builtin_amdgcn_mov_dpp((int)(o1 ? x : y), 0xB1, 0xF, 0xF, true);
-                if (o1) x = u; else y = u;
-            }
-#pragma unroll
-            for (int g = 0; g < 2; g++) {
-                unsigned& x = d[4 * g + c]; unsigned& y = d[4 * g + 8 + c];
-                const unsigned u = (unsigned)__builtin_amdgcn_mov_dpp((int)(o2 ? x : y), 0x4E, 0xF, 0xF, true);
-                if (o2) x = u; else y = u;
-            }
-        }
-    }
+    quad_transpose16(d, lane);          // piece i of rows 4k .. 4k + 3 into lane 4k + i: store instruction t writes row 4k + t with the quad's 64 bytes contiguous
     const int64_t row0 = m_tile + (lane & 28), n = n_wave + 32 * hi + 8 * (lane & 3);
 #pragma unroll
     for (int t = 0; t < 4; t++) {

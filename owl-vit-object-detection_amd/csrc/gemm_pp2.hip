@@ -60,6 +60,10 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
         item = xcd_remap(blockIdx.x, nitems); item_end = item + 1; item_step = 1;
     }
     if (item >= item_end) return;
+    // Start stagger (round 6 experiment, p.stagger > 0): every second workgroup of an XCD sleeps p.stagger x ~8 k cycles before its first tile, so that half of the
+    // chip's epilogues (HBM store / load bursts of 128 KiB per CU) fall into the other half's K-loops instead of all 256 CUs bursting at once.
+    if (p.stagger > 0 && ((blockIdx.x >> 3) & 1))
+        for (int i = 0; i < p.stagger; i++) __builtin_amdgcn_s_sleep(127);
     // (OWL_TUNING builds, timing only -- results are wrong: p.dbg bit 16 = no LDS-DMA requests after the prologue, bit 17 = fragments read in a tile's first
     //  K-tile only, bit 18 = no epilogue; tools/gemm_pp2_ablate.py, profiles/r04_gemm_fr.md section 5)
 #ifdef OWL_TUNING
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
             // tiles requested up front (64 registers beside the 128 accumulators) spilled 8 VGPRs into scratch.
             constexpr bool AUX_IN = (EPI == EPI_DQGELU_BF16);
             uint4 auxr[AUX_IN ? 2 : 1][2][2];
-            if constexpr (AUX_IN) {
+            if constexpr (AUX_IN && !LINES) {
 #pragma unroll
                 for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -349,7 +353,21 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
             constexpr bool BIAS_PRE = (EPI == EPI_BIAS_BF16 || EPI == EPI_QGELU_BF16 || EPI == EPI_F32 || EPI == EPI_ACC_F32);
             f32x4 bq[2][4];
             if constexpr (BIAS_PRE && !LINES) { if (has_bias) epi_bias_preload(lbias, hi, bq); }
-            if constexpr (LINES) {
+            if constexpr (LINES && AUX_IN) {
+                // dX through quick-GELU' (round 6): the saved derivative tile comes in through the SAME quad-contiguous pattern the stores leave by, two row
+                // blocks in flight (block i + 2 requested into the slot block i just left), then one multiply per element
+                unsigned ax[2][16];
+                epi_lines_aux_load<G>(p, cm0 + grp * 128, cn0 + wc * 64, lane, ax[0]);
+                epi_lines_aux_load<G>(p, cm0 + grp * 128 + 32, cn0 + wc * 64, lane, ax[1]);
+                estamp(1);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    quad_transpose16(ax[i & 1], lane);
+                    epi_lines_bf16<EPI, G>(p, acc[i][0], acc[i][1], cm0 + grp * 128 + i * 32, cn0 + wc * 64, lane, lbias, nullptr, ax[i & 1]);
+                    if (i + 2 < 4) epi_lines_aux_load<G>(p, cm0 + grp * 128 + (i + 2) * 32, cn0 + wc * 64, lane, ax[i & 1]);
+                    estamp(2 + i);
+                }
+            } else if constexpr (LINES) {
                 f32x4 bl[8];
                 if (has_bias) epi_lines_bias_preload(lbias, hi, bl);
                 estamp(1);
@@ -433,8 +451,10 @@ static int g_pp2_bw[2] = {0, 0};         // column-block width of the tile order
 OWL_API int owl_gemm_pp2_block_width(int epi, int bw) { if (epi < 0 || epi > 1) return -1; g_pp2_bw[epi] = bw; return 0; }
 static int g_pp2_abl = 0;                // timing-only ablations: bit 0 no LDS-DMA requests after the prologue, bit 1 fragments read once per tile, bit 2 no epilogue
 OWL_API int owl_gemm_pp2_ablate(int a) { g_pp2_abl = a; return 0; }
-static int g_pp2_lines = 1;              // quad-contiguous stores: 0 off, 1 bias epilogue (the product's choice), 2 quick-GELU epilogue too
+static int g_pp2_lines = 1;              // quad-contiguous stores: 0 off, 1 bias epilogue (the product's choice), 2 quick-GELU epilogue too, 3 + dX through quick-GELU' (loads too)
 OWL_API int owl_gemm_pp2_lines(int on) { g_pp2_lines = on; return 0; }
+static int g_pp2_stagger = 0;            // start stagger of every second workgroup, in units of s_sleep 127 (~8 k cycles)
+OWL_API int owl_gemm_pp2_stagger(int n) { g_pp2_stagger = n; return 0; }
 #else
 static constexpr int g_pp2_slots = 256;
 #endif
@@ -447,8 +467,10 @@ static int launch_pp2(hipStream_t s, GemmP p) {
     });
     p.tiles_m = (int)((p.M + QBM - 1) / QBM); p.tiles_n = (int)((p.N + QBN - 1) / QBN);
     p.dbg = 0;
+    p.stagger = 0;
 #ifdef OWL_TUNING
     p.dbg = g_pp2_abl << 16;
+    p.stagger = g_pp2_stagger;
 #endif
     // column-block width of the tile order (see `decode`): the largest divisor of tiles_n up to 4 for the forward epilogues (same-process A/B at
     // M = 73 984: QKV -3 %, half-batch fc1 -4 %, others +-0); the plain row-major order (one block) elsewhere -- dX through quick-GELU' measured
@@ -479,9 +501,12 @@ static int launch_pp2(hipStream_t s, GemmP p) {
     // K = 768.  The quick-GELU epilogue is VALU-bound and loses 2-4 % with the transposition on top (tuning builds can still switch it on:
     // owl_gemm_pp2_lines(2)); the erf-GELU one does not fit the register file with it (76 spilled registers).
 #ifdef OWL_TUNING
-    constexpr bool LINES_OK = (EPI == EPI_BIAS_BF16 || EPI == EPI_QGELU_BF16);
-    const bool lines_on = EPI == EPI_BIAS_BF16 ? g_pp2_lines >= 1 : g_pp2_lines >= 2;
+    constexpr bool LINES_OK = (EPI == EPI_BIAS_BF16 || EPI == EPI_QGELU_BF16 || EPI == EPI_DQGELU_BF16);
+    const bool lines_on = EPI == EPI_BIAS_BF16 ? g_pp2_lines >= 1 : (EPI == EPI_DQGELU_BF16 ? g_pp2_lines >= 3 : g_pp2_lines >= 2);
 #else
+    // (EPI_DQGELU_BF16 through this epilogue -- saved tile loaded AND result stored quad-contiguous -- needs two row blocks of aux in flight beside the 128
+    //  accumulators: 25 spilled VGPRs, and measured +1.3 % (B/16) / +3.8 % (L/14) SLOWER than the accumulator-layout form, bit-identical: tuning builds only,
+    //  tools/experiments/dqgelu_lines_ab.py, profiles/r06_dqgelu.md)
     constexpr bool LINES_OK = (EPI == EPI_BIAS_BF16);
     const bool lines_on = true;
 #endif

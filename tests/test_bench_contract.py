@@ -22,11 +22,11 @@ def bench_mod():
 
 
 def test_traffic_file_is_bound_to_the_shipped_kernel_sources(bench_mod):
-    """`roofline.traffic` is a PMC figure taken in separate rocprofv3 passes (tools/run_traffic_r05.sh) and read from profiles/: bench.py refuses it (traffic =
+    """`roofline.traffic` is a PMC figure taken in separate rocprofv3 passes (tools/run_profiles_r06.sh) and read from profiles/: bench.py refuses it (traffic =
     null) when the kernel sources changed since.  This test makes that refusal visible BEFORE a round ends: edit a kernel -> re-run the traffic passes."""
     t = json.load(open(os.path.join(ROOT, bench_mod.TRAFFIC_FILE)))
     assert t["kernel_source_digest"] == bench_mod.kernel_source_digest(), (
-        f"{bench_mod.TRAFFIC_FILE} was measured on other kernel sources: re-run tools/run_traffic_r05.sh on a GPU box and copy gpurun_out/r5_traffic.json over it")
+        f"{bench_mod.TRAFFIC_FILE} was measured on other kernel sources: re-run tools/run_profiles_r06.sh on a GPU box and copy gpurun_out/r6_traffic.json over it")
     assert bench_mod.TRAFFIC_NOTE is None
     for wl in ("owlvit-base-patch16/32", "owlvit-large-patch14/16"):
         assert set(t["workloads"][wl]) == {bench_mod.LABEL_BIAS, bench_mod.LABEL_QGELU, bench_mod.LABEL_ATTN}

@@ -552,6 +552,10 @@ def test_trained_like_train_step_matches_reference_fixture_f10(golden_dir, cname
         print(f"   bf16-storage floor (emulation vs reference): boxes max {fb:.3e} rms {frb:.3e}; HIP vs emulation max {_maxerr(pb, emb):.3e}")
         assert es < TOL_TRAINED and fb > TOL_TRAINED, (es, fb)
         assert eb < 1.5 * fb and rb < 1.5 * frb, (eb, fb, rb, frb)
+        # ... and ABSOLUTE bands (round 6), ~1.4x the measured 3.49e-2 / 4.75e-3: the floor-relative assertion above cannot move with a
+        # regression of the emulation itself.  Why no compensated path brings this weight set under 1e-2 at < 10 % cost: profiles/r06_hard_localise.md
+        # (every one of the 14 bf16 storage points alone moves the boxes 9e-4 ... 1.6e-2 -- the input cast alone 1.5e-2).
+        assert eb < 5e-2 and rb < 7e-3, (eb, rb)
     # the attention forward's stale-offset verdict: exercised where the reference's own logits say it must be (and only there)
     pred = int(g["attn/slow_tiles"].sum())
     if pred == 0:
