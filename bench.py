@@ -120,6 +120,9 @@ def parse():
     ap.add_argument("--windows", type=int, default=5,
                     help="timed windows of --steps steps each, back to back after ONE warm-up (each bracketed by barrier + synchronize, max over ranks); "
                          "`value` / `ms_per_step` are the MEDIAN window's, config.window_values lists them all (VERDICT r05 #4: one 0.5 s window cannot resolve 2 %%)")
+    ap.add_argument("--pretranspose", type=int, choices=(0, 1), default=1,
+                    help="1 (default, = the product): the backward's weight transposes are launched by the forward on their own stream (models.OwlViT.pretranspose); "
+                         "0: made inside the backward (A/B, profiles/r06_tail.md)")
     ap.add_argument("--encoder-streams", type=int, default=2,
                     help="sub-batches of the encoder forward / dX-only backward, one HIP stream each (OwlViT(encoder_streams=...)); 1 = one stream "
                          "(what the rocprofv3 profiles are taken with: kernel durations are then exclusive)")
@@ -294,6 +297,7 @@ def main():
     B = args.batch
 
     model = OwlViT(cfg, weights.make_weights(cfg, profile=args.weights), dev, encoder_streams=args.encoder_streams)    # identical weights on every rank (seeded)
+    model.pretranspose = bool(args.pretranspose)
     slow_tiles = torch.zeros(1, dtype=torch.int32, device=dev)      # attention forward: (wave, key tile) pairs that left the fast path (csrc/attention_fwd.hip)
     ops.ATTN_SLOW_TILES = slow_tiles
     batches = synth_batches(cfg, B, dev, rank)
@@ -533,6 +537,8 @@ def main():
         main_r, others = None, []
         for label in (LABEL_BIAS, LABEL_QGELU, LABEL_ATTN, LABEL_DQGELU, LABEL_ATTN_BWD):     # (the last two: the kernels furthest below their roofline)
             r = kt.summary(label)
+            if r is None:                                   # batch 1-2: the event steps' GEMMs take the small-problem rule and carry its suffix (classify_gemm)
+                r = next((kt.summary(l) for l in kt.rec if l.startswith(label + " [")), None)
             if r is None:
                 continue
             r["ms_total_per_step"] = round(r["ms_per_launch"] * r["launches_timed"] / (len(range(0, args.steps, EVENT_EVERY)) * kt.windows_recorded), 3)

@@ -158,6 +158,11 @@ class OwlViT(nn.Module):
         # forward's GEMMs instead of alone.  Same kernels, same operands, same order per buffer: bitwise the in-line schedule.
         self.overlap_tail = False
         self._tail_stream_ = None
+        # Round 6: the backward's seven weight transposes (bf16 W^T of the trainable weights: the "W" operand of the dX GEMMs) do not depend on the loss -- a
+        # gradient-recording forward launches them on a stream of their own where it first reads the trainable weights, into buffers of their own, and they run
+        # beside the trainable layer / heads / loss chain instead of on the backward's critical path (74 us of 26.8 ms; same kernels, same operands: same bits).
+        self.pretranspose = True
+        self._wt, self._wt_stream_, self._wt_event = None, None, None
         self._trainable = frozenset(order)
         # checkpointing while a deferred optimizer step (ddp.DataParallel(overlap=True)) is still running on its side stream: order the
         # current stream behind it before any parameter is read
@@ -282,6 +287,36 @@ class OwlViT(nn.Module):
             L.update(h1=z(M, D, bf, dev), h2=z(M, D, bf, dev), g=z(M, I, bf, dev))
         self._ws[key] = L
         return L
+
+    def _wt_specs(self):
+        """(name, rows, cols) of every trainable weight the backward needs transposed (autograd.backward_impl)."""
+        cfg = self.cfg
+        D, I, Dt = cfg.hidden, cfg.mlp, cfg.text_dim
+        tl = f"backbone.encoder.layers.{cfg.trainable_layer()}."
+        return [("class_predictor.dense0.weight", Dt, D), ("box_head.dense1.weight", D, D), ("box_head.dense0.weight", D, D), (tl + "mlp.fc2.weight", D, I),
+                (tl + "mlp.fc1.weight", I, D), (tl + "self_attn.out_proj.weight", D, D), ("qkv", 3 * D, D)]
+
+    def _pretranspose_weights(self):
+        """Launch the backward's weight transposes now, on their own stream (called by a gradient-recording forward on the stream that has just ordered itself
+        behind any deferred optimizer step, right before the trainable layer).  The backward waits for `_wt_event` and reads `_wt[name]`."""
+        if self._wt is None:
+            self._wt = {n: torch.empty(c, r, dtype=torch.bfloat16, device=self.device_) for n, r, c in self._wt_specs()}
+            self._wt_stream_ = torch.cuda.Stream(device=self.device_)
+        cur = torch.cuda.current_stream()
+        s_ = self._wt_stream_
+        s_.wait_stream(cur)                       # (the bf16 compute copies are current on `cur`; a previous backward's reads of these buffers precede this point on it too)
+        with torch.cuda.stream(s_):
+            D = self.cfg.hidden
+            for n, r, c in self._wt_specs():
+                if n == "qkv":
+                    o = self.flat_offsets[f"backbone.encoder.layers.{self.cfg.trainable_layer()}.self_attn.q_proj.weight"]
+                    src = self.flat_bf16[o: o + 3 * D * D].view(3 * D, D)
+                else:
+                    src = self._tview(n)
+                ops.transpose_bf16(src, self._wt[n], r, c)
+            ev = torch.cuda.Event()
+            ev.record(s_)
+        self._wt_event = ev
 
     def refresh_compute_weights(self, force: bool = True):
         """bf16 copies of the trainable tensors: one cast over the flat bucket.  Every forward calls it, except the first forward after a
@@ -489,6 +524,8 @@ class OwlViT(nn.Module):
                 with torch.cuda.stream(st["stream"]):
                     if i == tl and param_event is not None:
                         st["stream"].wait_event(param_event)    # everything above ran on frozen weights only (ddp overlap schedule)
+                    if i == tl and save and self.pretranspose and st is states[0]:
+                        self._pretranspose_weights()            # the backward's W^T copies, beside the rest of this forward and the loss chain
                     self._encoder_layer(i, ws, B, save, st)
         for c, st in enumerate(states):
             if c > 0:

@@ -297,3 +297,38 @@ def test_patch_embed_pingpong_matches_single_phase_bitwise(arch, B):
     for _ in range(6):
         assert torch.equal(run(7), ref)
     assert torch.equal(run(0), ref)
+
+
+@pytest.mark.parametrize("arch,B,overlap", [("owlvit-base-patch16", 4, False), ("tiny-l14", 3, False), ("tiny", 5, True)])
+def test_pretransposed_weights_give_the_in_backward_transposes_bits(arch, B, overlap):
+    """Round 6: the backward's seven weight transposes are launched by the forward on a stream of their own (models.OwlViT.pretranspose) and run beside the
+    trainable layer / heads / loss chain.  Same kernels, same operands: parameters after three AdamW steps (weights change between steps, so a stale
+    transposed copy would show) are the bits of the in-backward transposes -- also with the deferred tail (backward + AdamW on the tail stream)."""
+    from owl_vit_object_detection_amd import synth, weights
+    from owl_vit_object_detection_amd.config import get_config
+    from owl_vit_object_detection_amd.losses import PushPullLoss
+    from owl_vit_object_detection_amd.models import OwlViT
+    from owl_vit_object_detection_amd.optim import FusedAdamW
+    cfg = get_config(arch)
+    Wnp = weights.make_weights(cfg)
+    imgs = torch.from_numpy(synth.make_images(cfg, B)).to(DEV)
+    labels, boxes = synth.make_targets(cfg, B, max_boxes=6)
+    lab = [torch.from_numpy(l).to(DEV) for l in labels]; box = [torch.from_numpy(b).to(DEV) for b in boxes]
+    crit = PushPullLoss(cfg.n_classes, synth.class_scales(cfg, labels))
+    out = []
+    for pre in (False, True):
+        model = OwlViT(cfg, Wnp, DEV)
+        model.pretranspose = pre
+        opt = FusedAdamW(model, lr=1e-3, weight_decay=0.1, overlap=overlap)
+        ls = []
+        for it in range(3):
+            opt.zero_grad()
+            pb, _, ps, _ = model(imgs)
+            losses = crit(ps, lab, pb, box)
+            (losses["loss_ce"] + losses["loss_bg"] + losses["loss_bbox"] + losses["loss_giou"]).backward()
+            opt.step()
+            ls.append(torch.stack([losses[k].detach() for k in ("loss_ce", "loss_bg", "loss_bbox", "loss_giou")]))
+        model.finish(); torch.cuda.synchronize()
+        assert (model._wt is not None) == pre
+        out.append((torch.stack(ls).cpu(), model.flat_param.clone().cpu()))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])

@@ -1,0 +1,21 @@
+#!/bin/bash
+# round 6, GPU call 6: pre-transposed weights -- bit-equality tests, then same-box A/B of the train step (two processes alternated, 9 windows of 20 steps each)
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_determinism_gpu.py tests/test_training_gpu.py tests/test_autograd_contract_gpu.py tests/test_ddp_rccl_gpu.py -x -q -m gpu > gpurun_out/r6_c6_tests.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/r6_c6_tests.log
+: > gpurun_out/r6_pretranspose_ab.log
+for round in 1 2 3; do
+  for v in 0 1; do
+    python bench.py --no-cpu-baseline --no-compare --steps 20 --warmup 3 --windows 9 --pretranspose $v 2>/dev/null | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); c = d['config']
+print('round $round pretranspose $v:', d['value'], 'img/s', d['ms_per_step'], 'ms; windows', c['window_values'], 'spread', c['window_spread_pct'])" >> gpurun_out/r6_pretranspose_ab.log
+  done
+done
+for v in 0 1; do
+  python bench.py --no-cpu-baseline --no-compare --steps 20 --warmup 3 --windows 5 --encoder-streams 1 --pretranspose $v 2>/dev/null | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); c = d['config']
+print('one-stream schedule, pretranspose $v:', d['value'], 'img/s', d['ms_per_step'], 'ms; windows', c['window_values'])" >> gpurun_out/r6_pretranspose_ab.log
+done
+cat gpurun_out/r6_pretranspose_ab.log
