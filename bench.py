@@ -120,9 +120,9 @@ def parse():
     ap.add_argument("--windows", type=int, default=5,
                     help="timed windows of --steps steps each, back to back after ONE warm-up (each bracketed by barrier + synchronize, max over ranks); "
                          "`value` / `ms_per_step` are the MEDIAN window's, config.window_values lists them all (VERDICT r05 #4: one 0.5 s window cannot resolve 2 %%)")
-    ap.add_argument("--pretranspose", type=int, choices=(0, 1), default=1,
-                    help="1 (default, = the product): the backward's weight transposes are launched by the forward on their own stream (models.OwlViT.pretranspose); "
-                         "0: made inside the backward (A/B, profiles/r06_tail.md)")
+    ap.add_argument("--pretranspose", type=int, choices=(0, 1), default=0,
+                    help="0 (default, = the product): the backward makes its weight transposes itself; 1: the forward launches them on their own stream "
+                         "(models.OwlViT.pretranspose; measured no faster: A/B, profiles/r06_tail.md)")
     ap.add_argument("--encoder-streams", type=int, default=2,
                     help="sub-batches of the encoder forward / dX-only backward, one HIP stream each (OwlViT(encoder_streams=...)); 1 = one stream "
                          "(what the rocprofv3 profiles are taken with: kernel durations are then exclusive)")

@@ -156,14 +156,14 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
     d_sims = d_sims.contiguous().float()
 
     # the forward launched the transposes on their own stream (models.OwlViT._pretranspose_weights): order this stream behind them once
-    pre = model._wt if (getattr(model, "pretranspose", False) and model._wt_event is not None) else None
-    if pre is not None:
+    pre_wt = model._wt if (getattr(model, "pretranspose", False) and model._wt_event is not None) else None
+    if pre_wt is not None:
         torch.cuda.current_stream().wait_event(model._wt_event)
 
     def wT(name, rows, cols, buf="wT"):
         """bf16 transpose of a trainable weight [rows, cols] -> [cols, rows]: the forward's pre-transposed copy, or (pretranspose off) made here in scratch."""
-        if pre is not None:
-            return pre[name]
+        if pre_wt is not None:
+            return pre_wt[name]
         out = bw[buf][: rows * cols].view(cols, rows)
         ops.transpose_bf16(tv(name), out, rows, cols)
         return out
@@ -311,8 +311,8 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
     g_bqkv = model.flat_grad[ob: ob + 3 * D]
     on_side(3, lambda: dW(bw["dqkv"], Lt["h1"], g_wqkv, 3 * D, D, M, Mp, g_bqkv, part="part2"))
     wqkv = model.flat_bf16[o: o + 3 * D * D].view(3 * D, D)
-    if pre is not None:
-        wqkvT = pre["qkv"]
+    if pre_wt is not None:
+        wqkvT = pre_wt["qkv"]
     else:
         wqkvT = bw["wT"][: 3 * D * D].view(D, 3 * D)
         ops.transpose_bf16(wqkv, wqkvT, 3 * D, D)

@@ -158,10 +158,12 @@ class OwlViT(nn.Module):
         # forward's GEMMs instead of alone.  Same kernels, same operands, same order per buffer: bitwise the in-line schedule.
         self.overlap_tail = False
         self._tail_stream_ = None
-        # Round 6: the backward's seven weight transposes (bf16 W^T of the trainable weights: the "W" operand of the dX GEMMs) do not depend on the loss -- a
-        # gradient-recording forward launches them on a stream of their own where it first reads the trainable weights, into buffers of their own, and they run
-        # beside the trainable layer / heads / loss chain instead of on the backward's critical path (74 us of 26.8 ms; same kernels, same operands: same bits).
-        self.pretranspose = True
+        # Round 6 experiment, OFF by default: with `pretranspose` the backward's seven weight transposes (bf16 W^T of the trainable weights, the "W" operand of the
+        # dX GEMMs; they do not depend on the loss) are launched by a gradient-recording forward on a stream of their own where it first reads the trainable
+        # weights, and run beside the trainable layer / heads / loss chain instead of inside the backward.  Same kernels, same operands: same bits
+        # (tests/test_determinism_gpu.py).  Measured (profiles/r06_tail.md): 74 us of transposes leave the backward's stream and the step does not get
+        # faster (three alternated rounds: +0.17 / -0.38 / -0.23 %): the in-backward form stays the default.
+        self.pretranspose = False
         self._wt, self._wt_stream_, self._wt_event = None, None, None
         self._trainable = frozenset(order)
         # checkpointing while a deferred optimizer step (ddp.DataParallel(overlap=True)) is still running on its side stream: order the
