@@ -196,3 +196,50 @@ def test_prefetcher_surfaces_loader_errors_and_stops():
     assert th is None or not th.is_alive()
     with pytest.raises(ValueError):
         DevicePrefetcher([], "cpu")
+
+
+@pytest.mark.gpu
+def test_prefetcher_around_a_torch_dataloader_with_workers():
+    """The reference's own shape of the input side (ref src/dataset.py:60-106: a Dataset returning (image, labels, boxes, metadata), DataLoader with worker
+    processes) with the HF processor taken OUT of the dataset: workers hand over raw uint8 images of different sizes, the prefetcher resizes + normalises on the
+    device -- pixel_values equal to DeviceImageProcessor's own (which F7 pins to PIL + HF), targets converted on the host by the reference's coco_to_model_input."""
+    from torch.utils.data import DataLoader, Dataset
+    from owl_vit_object_detection_amd.preprocess import DeviceImageProcessor, DevicePrefetcher
+    from owl_vit_object_detection_amd.train_util import coco_to_model_input
+    S = 96
+
+    class Raw(Dataset):
+        def __len__(self):
+            return 6
+
+        def __getitem__(self, i):
+            g = torch.Generator().manual_seed(100 + i)
+            H, W = 60 + 7 * i, 90 - 5 * i
+            img = torch.randint(0, 256, (H, W, 3), generator=g, dtype=torch.uint8)
+            n = 1 + i % 3
+            boxes = torch.rand(n, 4, generator=g) * 20.0 + 1.0                       # xywh pixels
+            return img, torch.arange(n), boxes, {"width": W, "height": H, "impath": f"img{i}"}
+
+    def collate(items):                                                                # batch of 2, ragged: lists (the reference's loader is batch 1)
+        imgs, labels, boxes, meta = zip(*items)
+        return list(imgs), list(labels), list(boxes), list(meta)
+
+    def tt(labels, boxes, meta):
+        return labels, [coco_to_model_input(b[None], m)[0] for b, m in zip(boxes, meta)], meta
+
+    ds = Raw()
+    loader = DataLoader(ds, batch_size=2, shuffle=False, num_workers=2, collate_fn=collate)
+    ip = DeviceImageProcessor(size=S, dtype=torch.bfloat16)
+    k = 0
+    for img, labels, boxes, meta in DevicePrefetcher(loader, "cuda", size=S, target_transform=tt):
+        assert img.dtype == torch.bfloat16 and tuple(img.shape) == (2, 3, S, S)
+        exp = ip(images=[ds[2 * k + j][0] for j in range(2)])["pixel_values"]
+        assert torch.equal(img, exp)
+        for j in range(2):
+            raw = ds[2 * k + j]
+            assert labels[j].is_cuda and torch.equal(labels[j].cpu(), raw[1])
+            want = coco_to_model_input(raw[2][None], raw[3])[0]
+            assert boxes[j].is_cuda and torch.equal(boxes[j].cpu(), want)
+            assert meta[j]["impath"] == f"img{2 * k + j}"
+        k += 1
+    assert k == 3
