@@ -7,6 +7,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.utils.data
 
 from owl_vit_object_detection_amd.preprocess import classify_images, pack_plan
 
@@ -198,37 +199,42 @@ def test_prefetcher_surfaces_loader_errors_and_stops():
         DevicePrefetcher([], "cpu")
 
 
+class _RawImages(torch.utils.data.Dataset):
+    """Module level (picklable): the DataLoader workers of the test below are SPAWNED -- a forked child of a process that has initialised the HIP runtime
+    (and, under pytest, a few hundred tests' worth of streams and threads) is not safe to run in; first attempt: worker killed by SIGSEGV."""
+
+    def __len__(self):
+        return 6
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(100 + i)
+        H, W = 60 + 7 * i, 90 - 5 * i
+        img = torch.randint(0, 256, (H, W, 3), generator=g, dtype=torch.uint8)
+        n = 1 + i % 3
+        boxes = torch.rand(n, 4, generator=g) * 20.0 + 1.0                       # xywh pixels
+        return img, torch.arange(n), boxes, {"width": W, "height": H, "impath": f"img{i}"}
+
+
+def _collate_lists(items):                                                        # batch of 2, ragged: lists (the reference's loader is batch 1)
+    imgs, labels, boxes, meta = zip(*items)
+    return list(imgs), list(labels), list(boxes), list(meta)
+
+
 @pytest.mark.gpu
 def test_prefetcher_around_a_torch_dataloader_with_workers():
     """The reference's own shape of the input side (ref src/dataset.py:60-106: a Dataset returning (image, labels, boxes, metadata), DataLoader with worker
     processes) with the HF processor taken OUT of the dataset: workers hand over raw uint8 images of different sizes, the prefetcher resizes + normalises on the
     device -- pixel_values equal to DeviceImageProcessor's own (which F7 pins to PIL + HF), targets converted on the host by the reference's coco_to_model_input."""
-    from torch.utils.data import DataLoader, Dataset
+    from torch.utils.data import DataLoader
     from owl_vit_object_detection_amd.preprocess import DeviceImageProcessor, DevicePrefetcher
     from owl_vit_object_detection_amd.train_util import coco_to_model_input
     S = 96
 
-    class Raw(Dataset):
-        def __len__(self):
-            return 6
-
-        def __getitem__(self, i):
-            g = torch.Generator().manual_seed(100 + i)
-            H, W = 60 + 7 * i, 90 - 5 * i
-            img = torch.randint(0, 256, (H, W, 3), generator=g, dtype=torch.uint8)
-            n = 1 + i % 3
-            boxes = torch.rand(n, 4, generator=g) * 20.0 + 1.0                       # xywh pixels
-            return img, torch.arange(n), boxes, {"width": W, "height": H, "impath": f"img{i}"}
-
-    def collate(items):                                                                # batch of 2, ragged: lists (the reference's loader is batch 1)
-        imgs, labels, boxes, meta = zip(*items)
-        return list(imgs), list(labels), list(boxes), list(meta)
-
     def tt(labels, boxes, meta):
         return labels, [coco_to_model_input(b[None], m)[0] for b, m in zip(boxes, meta)], meta
 
-    ds = Raw()
-    loader = DataLoader(ds, batch_size=2, shuffle=False, num_workers=2, collate_fn=collate)
+    ds = _RawImages()
+    loader = DataLoader(ds, batch_size=2, shuffle=False, num_workers=2, collate_fn=_collate_lists, multiprocessing_context="spawn")
     ip = DeviceImageProcessor(size=S, dtype=torch.bfloat16)
     k = 0
     for img, labels, boxes, meta in DevicePrefetcher(loader, "cuda", size=S, target_transform=tt):
