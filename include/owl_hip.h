@@ -32,7 +32,7 @@ extern "C" {
 
 /* ---- runtime ---------------------------------------------------------------------------------- */
 /* Bumped whenever a prototype, an argument's meaning or a caller-provided scratch layout changes (1 = round 1; 2 = round 2: per-call `tile` /
- * `variant` arguments, partial-sum scratch of the row reductions, 5D+4 box_final_bwd partials; 3 = round 3; 4 = round 4: `slow_tiles` statistic of the attention forward; 5 = round 5: owl_patch_embed_bf16's weight layout for patch sizes that are not 2^n (gathered, no im2row); the V^T attention form, attention variants 3-5, GEMM epilogues 5 / 6 and tiles 8 / 9 / 5 / 4 moved to OWL_TUNING builds); 6 = round 6: + owl_patch_embed_scratch_bytes, owl_normalize_u8, `phases` of owl_attention_bwd_bf16; GEMM epilogue 1 saves quick_gelu'(u) and epilogue 8 multiplies by it; patch sizes must be even.  owl_abi_version() returns the value
+ * `variant` arguments, partial-sum scratch of the row reductions, 5D+4 box_final_bwd partials; 3 = round 3; 4 = round 4: `slow_tiles` statistic of the attention forward; 5 = round 5: owl_patch_embed_bf16's weight layout for patch sizes that are not 2^n (gathered, no im2row); the V^T attention form, attention variants 3-5, GEMM epilogues 5 / 6 and tiles 8 / 9 / 5 / 4 moved to OWL_TUNING builds); 6 = round 6: + owl_patch_embed_scratch_bytes, owl_normalize_u8, owl_allreduce_sum_f32, `phases` of owl_attention_bwd_bf16; GEMM epilogue 1 saves quick_gelu'(u) and epilogue 8 multiplies by it; patch sizes must be even.  owl_abi_version() returns the value
  * the library was BUILT with: a binding compares it with the header it was generated from and refuses a mismatch (_lib.load() does). */
 #define OWL_ABI_VERSION 6
 const char* owl_last_error(void);
@@ -147,6 +147,12 @@ int owl_push_pull_loss_bwd(void* stream, const float* g4, const int64_t* target_
  * workspace: device scratch of owl_postprocess_workspace() bytes (16-byte aligned); `bytes` is a HOST pointer.     */
 int owl_postprocess_workspace(int64_t B, int64_t P, int64_t* bytes);
 int owl_postprocess(void* stream, const float* boxes, const float* sims, void* workspace, int64_t ws_bytes, float* out_boxes, float* out_scores, int64_t* out_classes, int64_t* out_patch, int* out_count, int64_t B, int64_t P, int64_t C, int64_t max_out, float conf_thr, float iou_thr, int route);
+
+/* ---- the one collective of the path: in-place SUM of the flat f32 gradient bucket over the data-parallel ranks on `stream`, through the
+ * CALLER's RCCL communicator (`rccl_comm` = an `ncclComm_t`).  For hosts without PyTorch; this repo's Python host issues the same collective through
+ * torch.distributed (torch owns its communicator).  librccl.so is bound lazily at the first call: no load-time dependency.  Scale by 1 / world in
+ * owl_adamw_step (`grad_scale`).  ABI 6.                                                                                                                          */
+int owl_allreduce_sum_f32(void* stream, void* rccl_comm, float* buf, int64_t n);
 
 /* ---- device input pipeline (ref src/dataset.py:69-71: HF OwlViTImageProcessor = PIL bicubic resize -> x(1/255) ->
  * (x-mean)/std).  owl_bicubic_coeffs is HOST-side (all pointers host): Pillow's Resample.c tap tables for one axis,

@@ -40,5 +40,5 @@ fail=0
 for pid in $pids; do wait $pid || fail=1; done
 if [ $fail = 1 ]; then echo "build.sh: a HIP source failed to compile" >&2; exit 1; fi
 g++ -O2 -fPIC -fvisibility=hidden -std=c++17 -ffp-contract=off -c runtime.cpp -o $BUILD/runtime.o
-hipcc --offload-arch=${ARCH} -shared -fPIC -Wl,--version-script=libowlhip.map -o ../libowlhip.so $objs $BUILD/runtime.o
+hipcc --offload-arch=${ARCH} -shared -fPIC -Wl,--version-script=libowlhip.map -o ../libowlhip.so $objs $BUILD/runtime.o -ldl
 echo "built $(cd .. && pwd)/libowlhip.so"

@@ -77,3 +77,41 @@ OWL_API int owl_bicubic_coeffs(int64_t in_size, int64_t out_size, int* bounds, i
     }
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The path's ONE collective: SUM of the flat f32 gradient bucket over the data-parallel ranks, in place, on the caller's
+// stream, through the caller's RCCL communicator.  For hosts WITHOUT PyTorch: the Python host of this repo issues the same collective through
+// torch.distributed (backend "nccl" = RCCL; ddp.py) because torch owns its communicator and does not hand it out.  librccl is bound lazily
+// (dlopen at the first call), so libowlhip.so has no load-time dependency on it: single-GPU users never touch it.
+// ---------------------------------------------------------------------------------------------------------------------
+#include <dlfcn.h>
+#include <stddef.h>
+
+typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, void*);    // ncclAllReduce(send, recv, count, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t)
+typedef const char* (*nccl_errstr_fn)(int);
+
+OWL_API int owl_allreduce_sum_f32(void* stream, void* rccl_comm, float* buf, int64_t n) {
+    if (!rccl_comm || !buf || n <= 0) {
+        owl_set_error("owl_allreduce_sum_f32: null communicator / buffer or n = %lld", (long long)n);
+        return -1;
+    }
+    static nccl_allreduce_fn allreduce = nullptr;          // (resolved once; a benign race resolves the same symbol twice)
+    static nccl_errstr_fn errstr = nullptr;
+    if (!allreduce) {
+        // the RCCL instance the process ALREADY has (the one the caller built `rccl_comm` with: e.g. PyTorch's bundled copy) before loading another one
+        void* h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) { owl_set_error("owl_allreduce_sum_f32: cannot load librccl.so (%s)", dlerror()); return -2; }
+        allreduce = (nccl_allreduce_fn)dlsym(h, "ncclAllReduce");
+        errstr = (nccl_errstr_fn)dlsym(h, "ncclGetErrorString");
+        if (!allreduce) { owl_set_error("owl_allreduce_sum_f32: librccl.so has no ncclAllReduce"); return -2; }
+    }
+    const int rc = allreduce(buf, buf, (size_t)n, /* ncclFloat32 */ 7, /* ncclSum */ 0, rccl_comm, stream);
+    if (rc != 0) {
+        owl_set_error("owl_allreduce_sum_f32: ncclAllReduce failed: %s", errstr ? errstr(rc) : "unknown RCCL error");
+        return -3;
+    }
+    return 0;
+}

@@ -230,3 +230,40 @@ def test_two_rank_rccl_step(tmp_path, overlap):
     glob = model.flat_grad.cpu().numpy()
     mean = 0.5 * (r0["local"] + r1["local"])
     np.testing.assert_allclose(mean, glob, rtol=1e-3, atol=1e-5 * float(np.abs(glob).max()))
+
+
+def test_c_abi_allreduce_entry_single_rank():
+    """the C ABI's own collective entry (for hosts without PyTorch): `owl_allreduce_sum_f32` over a communicator the CALLER built with RCCL's C API
+    (here through ctypes: ncclGetUniqueId + ncclCommInitRank with one rank -- all a 1-GPU box allows).  One rank's sum is the bucket itself, bit for bit; the
+    call is enqueued on the given stream; a null communicator is refused with a message."""
+    import ctypes
+    from owl_vit_object_detection_amd import _lib, ops
+    try:
+        rccl = ctypes.CDLL("librccl.so")          # the instance torch already mapped (its bundled copy): the library binds the same one (RTLD_NOLOAD first)
+    except OSError:
+        pytest.skip("librccl.so not loadable")
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+
+    uid = UniqueId()
+    rccl.ncclGetUniqueId.argtypes = [ctypes.POINTER(UniqueId)]
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    torch.cuda.set_device(0)
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    try:
+        g = torch.randn(8_684_292, device="cuda")
+        ref = g.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            _lib.call("owl_allreduce_sum_f32", ops.stream(), comm.value, g, g.numel())
+        side.synchronize()
+        assert torch.equal(g, ref)
+        with pytest.raises(_lib.OwlLibError, match="null communicator"):
+            _lib.call("owl_allreduce_sum_f32", ops.stream(), None, g, g.numel())
+    finally:
+        rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        rccl.ncclCommDestroy(comm)
