@@ -175,3 +175,23 @@ def test_hot_kernels_do_not_spill(built):
             assert hits, (obj, pat)
             for k, v in hits.items():
                 assert v["spill"] <= cap, (k, v)
+
+
+def test_patch_embed_scratch_query_is_the_dispatchers_rule(built):
+    """the Python side sizes the im2row scratch of owl_patch_embed_bf16 from the library's own query (host function, no GPU): 0 where the chosen
+    kernel gathers from the image itself -- every 2^n patch size, any patch size on the ping-pong kernel --, the im2row matrix otherwise; odd patch sizes refused."""
+    import torch
+
+    def q(B, S, ps, D, tile=0):
+        n = torch.zeros(1, dtype=torch.int64)
+        _lib.call("owl_patch_embed_scratch_bytes", B, S, ps, D, tile, n)
+        return int(n.item())
+
+    assert q(32, 768, 16, 768) == 0 and q(1, 768, 16, 768) == 0 and q(1, 96, 16, 64) == 0          # 2^n patch sizes: never
+    assert q(16, 840, 14, 1024) == 0 and q(1, 840, 14, 1024) == 0                                   # L/14: the ping-pong kernel at every batch size
+    small = q(3, 84, 14, 128)                                                                       # tiny-l14: a problem too small for the ping-pong kernel
+    rows = (3 * 36 + 127) // 128 * 128
+    assert small == rows * 704 * 2                                                                  # [rows128(B*P), Kg = 3*14*16 -> 704] bf16
+    assert q(3, 84, 14, 128, tile=7) == 0 and q(16, 840, 14, 1024, tile=256) > 0                    # a pinned kernel follows the same rule
+    with pytest.raises(_lib.OwlLibError):
+        q(1, 90, 15, 128)

@@ -332,3 +332,42 @@ def test_pretransposed_weights_give_the_in_backward_transposes_bits(arch, B, ove
         assert (model._wt is not None) == pre
         out.append((torch.stack(ls).cpu(), model.flat_param.clone().cpu()))
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+
+
+def test_attention_bwd_phases_mask_gives_the_one_call_bits():
+    """ABI 6: `phases` of owl_attention_bwd_bf16 launches dvec / dK,dV / dQ separately (dK/dV and dQ only share inputs and write disjoint thirds of dqkv): any order
+    of the last two behind the first, on one stream or two, gives the bits of the single call; a bad mask is refused."""
+    from owl_vit_object_detection_amd import _lib
+    torch.manual_seed(4)
+    H, T, B = 3, 449, 2
+    Tp = (T + 7) // 8 * 8; D = H * 64; M = B * Tp
+    qkv = torch.zeros(ops.pad_rows(M), 3 * D, device=DEV, dtype=torch.bfloat16); qkv[:M] = torch.randn(M, 3 * D, device=DEV).bfloat16()
+    O = torch.zeros(ops.pad_rows(M), D, device=DEV, dtype=torch.bfloat16); lse = torch.zeros(B, H, Tp, device=DEV)
+    ops.attention_fwd_vrow(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, O, D, lse, B, H, T, Tp, 0.125)
+    dO = torch.zeros(ops.pad_rows(M), D, device=DEV, dtype=torch.bfloat16); dO[:M] = (0.1 * torch.randn(M, D, device=DEV)).bfloat16()
+
+    def run(order, two_streams=False):
+        dqkv = torch.zeros(ops.pad_rows(M), 3 * D, device=DEV, dtype=torch.bfloat16); dvec = torch.zeros(B, H, Tp, device=DEV)
+        if order == (0,):
+            ops.attention_bwd(qkv, dO, O, lse, dvec, dqkv, B, H, T, Tp, 0.125)
+        else:
+            ops.attention_bwd(qkv, dO, O, lse, dvec, dqkv, B, H, T, Tp, 0.125, phases=1)
+            if two_streams:
+                side, ev, ev2 = torch.cuda.Stream(), torch.cuda.Event(), torch.cuda.Event()
+                ev.record(); side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    ops.attention_bwd(qkv, dO, O, lse, dvec, dqkv, B, H, T, Tp, 0.125, phases=order[0]); ev2.record(side)
+                ops.attention_bwd(qkv, dO, O, lse, dvec, dqkv, B, H, T, Tp, 0.125, phases=order[1])
+                torch.cuda.current_stream().wait_event(ev2)
+            else:
+                for ph in order:
+                    ops.attention_bwd(qkv, dO, O, lse, dvec, dqkv, B, H, T, Tp, 0.125, phases=ph)
+        torch.cuda.synchronize()
+        return dqkv
+
+    ref = run((0,))
+    assert float(ref[:M].float().abs().max()) > 0
+    for order, two in (((2, 4), False), ((4, 2), False), ((4, 2), True), ((6,), False)):
+        assert torch.equal(run(order, two), ref), (order, two)
+    with pytest.raises(_lib.OwlLibError, match="phases"):
+        ops.attention_bwd(qkv, dO, O, lse, torch.zeros(B, H, Tp, device=DEV), torch.zeros_like(qkv), B, H, T, Tp, 0.125, phases=9)
