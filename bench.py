@@ -123,6 +123,8 @@ def parse():
     ap.add_argument("--pretranspose", type=int, choices=(0, 1), default=0,
                     help="0 (default, = the product): the backward makes its weight transposes itself; 1: the forward launches them on their own stream "
                          "(models.OwlViT.pretranspose; measured no faster: A/B, profiles/r06_tail.md)")
+    ap.add_argument("--ablate", default="", help="TIMING ONLY (results are wrong, the line says so): comma list of launches to skip -- colsum (the bias-gradient column sums of "
+                                                "the dW chain), slab_reduce (the split-K reductions): an upper bound on what folding them into the dW GEMM could buy (profiles/r06_tail.md)")
     ap.add_argument("--encoder-streams", type=int, default=2,
                     help="sub-batches of the encoder forward / dX-only backward, one HIP stream each (OwlViT(encoder_streams=...)); 1 = one stream "
                          "(what the rocprofv3 profiles are taken with: kernel durations are then exclusive)")
@@ -298,6 +300,15 @@ def main():
 
     model = OwlViT(cfg, weights.make_weights(cfg, profile=args.weights), dev, encoder_streams=args.encoder_streams)    # identical weights on every rank (seeded)
     model.pretranspose = bool(args.pretranspose)
+    ablate = [a for a in args.ablate.split(",") if a]
+    if ablate:
+        from owl_vit_object_detection_amd import _lib as _L, autograd as _AG
+        if "colsum" in ablate:
+            ops.colsum_bf16 = lambda *a, **k: None
+        if "slab_reduce" in ablate:
+            _orig_call = _L.call
+            _AG._lib = type("LibNoSlabReduce", (), {"call": staticmethod(lambda name, *a: None if name == "owl_slab_reduce" else _orig_call(name, *a)),
+                                                    "load": staticmethod(_L.load)})
     slow_tiles = torch.zeros(1, dtype=torch.int32, device=dev)      # attention forward: (wave, key tile) pairs that left the fast path (csrc/attention_fwd.hip)
     ops.ATTN_SLOW_TILES = slow_tiles
     batches = synth_batches(cfg, B, dev, rank)
@@ -500,6 +511,7 @@ def main():
                        "weights": args.weights,
                        "attention_slow_tiles_per_step": round(slow / max(1, args.steps), 1),
                        "optimizer_schedule": schedule,
+                       **({"ABLATION_timing_only_results_wrong": args.ablate} if args.ablate else {}),
                        "gflop_per_image": round(flops_img / 1e9, 1),
                        "step_mfma_frac": round(flops_img * value / world / 1e12 / PEAK_BF16_TFLOPS, 4),
                        # `value` / `ms_per_step` = the MEDIAN of `windows` back-to-back windows of exactly `steps` steps (one warm-up in front of the first)

@@ -479,7 +479,47 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     *(float4*)(out + i) = a;
 }
 
+// The same reduction for TALL problems -- many partial rows, few columns (box_final_bwd: 1152 workgroup partials x 3844 columns at batch 32): slab_reduce_kernel
+// gives every column quad ONE thread that walks all partials (4 workgroups on the chip, 54 us for 17 MB -- latency, not bandwidth; profiles/r06_tail.md).  Here a
+// workgroup takes 32 column quads x 8 lanes per quad: lane g sums partials g, g + 8, g + 16, ... (fixed order), the eight sums meet in LDS and are added in order
+// g = 0 .. 7 (fixed): deterministic, 8x the loads in flight per column and 8x the workgroups.  (Another summation order than slab_reduce_kernel's: the two are
+// never mixed for one output -- the choice depends on the shape alone.)
+__global__ __launch_bounds__(256) void tall_reduce_kernel(const float* __restrict__ slabs, float* out, int64_t n, int64_t stride, int nsplit, int accumulate) {
+    __shared__ float4 part[8][32];
+    const int q = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int64_t i = ((int64_t)blockIdx.x * 32 + q) * 4;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n) {
+        const float* src = slabs + i;
+        int sidx = g;
+        for (; sidx + 24 < nsplit; sidx += 32) {           // 4 independent 16-byte loads in flight per thread
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = *(const float4*)(src + (int64_t)(sidx + 8 * u) * stride);
+#pragma unroll
+            for (int u = 0; u < 4; u++) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+        }
+        for (; sidx < nsplit; sidx += 8) {
+            const float4 v = *(const float4*)(src + (int64_t)sidx * stride);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+    }
+    part[g][q] = a;
+    __syncthreads();
+    if (g == 0 && i < n) {
+        float4 r = accumulate ? *(const float4*)(out + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const float4 v = part[k][q]; r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
+        *(float4*)(out + i) = r;
+    }
+}
+
 int owl_slab_reduce_impl(hipStream_t s, const float* slabs, float* out, int64_t n, int64_t slab_stride, int nsplit, int accumulate) {
+    if (nsplit >= 128 && n / 4 <= 8192) {                    // tall: see tall_reduce_kernel
+        hipLaunchKernelGGL(tall_reduce_kernel, dim3((unsigned)((n / 4 + 31) / 32)), dim3(256), 0, s, slabs, out, n, slab_stride, nsplit, accumulate);
+        OWL_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, slabs, out, n, slab_stride, nsplit, accumulate);
     OWL_LAUNCH_CHECK();
     return 0;

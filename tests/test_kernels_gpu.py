@@ -665,3 +665,24 @@ def test_shipped_library_refuses_the_tuning_only_kernels():
     lib = _lib.load()
     for sym in ("owl_attention_fwd_bf16", "owl_attention_fwd_w64_bf16", "owl_attention_fwd_workspace_bytes", "owl_gemm_fr_ablate", "owl_gemm_set_persistent"):
         assert not hasattr(lib, sym), sym
+
+
+@pytest.mark.parametrize("ns,n,stride", [(1152, 3076, 3844), (1152, 768, 3844), (130, 32, 64), (127, 3076, 3844), (36, 2359296, 2359296)])
+def test_slab_reduce_tall_and_wide(ns, n, stride):
+    """owl_slab_reduce: out (+)= sum over `ns` partial rows.  Many partials x few columns (box_final_bwd's 1152 workgroup partials) take the tall kernel (round 6:
+    8 lanes per column quad, fixed-order combination), everything else the one-thread-per-quad kernel; both against an f64 sum, with and without accumulation,
+    repeatable bits, columns beyond n untouched."""
+    from owl_vit_object_detection_amd import _lib
+    g = torch.Generator(device="cpu").manual_seed(ns + n)
+    slabs = torch.randn(ns, stride, generator=g).to(DEV)
+    ref = slabs[:, :n].double().sum(0)
+    out = torch.full((stride,), 7.0, device=DEV)
+    _lib.call("owl_slab_reduce", ops.stream(), slabs, out, n, stride, ns, 0)
+    assert float((out[:n].double() - ref).abs().max()) < 2e-4 * max(1.0, ns ** 0.5 / 8)
+    assert bool((out[n:] == 7.0).all())
+    out2 = torch.full((stride,), 7.0, device=DEV)
+    _lib.call("owl_slab_reduce", ops.stream(), slabs, out2, n, stride, ns, 0)
+    assert torch.equal(out, out2)
+    acc = torch.ones(stride, device=DEV)
+    _lib.call("owl_slab_reduce", ops.stream(), slabs, acc, n, stride, ns, 1)
+    assert float((acc[:n].double() - 1.0 - ref).abs().max()) < 2e-4 * max(1.0, ns ** 0.5 / 8)
