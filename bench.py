@@ -123,6 +123,8 @@ def parse():
     ap.add_argument("--pretranspose", type=int, choices=(0, 1), default=0,
                     help="0 (default, = the product): the backward makes its weight transposes itself; 1: the forward launches them on their own stream "
                          "(models.OwlViT.pretranspose; measured no faster: A/B, profiles/r06_tail.md)")
+    ap.add_argument("--fold-bias", type=int, choices=(0, 1), default=1,
+                    help="1 (default, = the product): bias gradients out of the dW GEMM's own pass (autograd.FOLD_BIAS_COLSUM); 0: the separate column-sum kernel (A/B)")
     ap.add_argument("--ablate", default="", help="TIMING ONLY (results are wrong, the line says so): comma list of launches to skip -- colsum (the bias-gradient column sums of "
                                                 "the dW chain), slab_reduce (the split-K reductions): an upper bound on what folding them into the dW GEMM could buy (profiles/r06_tail.md)")
     ap.add_argument("--encoder-streams", type=int, default=2,
@@ -300,6 +302,8 @@ def main():
 
     model = OwlViT(cfg, weights.make_weights(cfg, profile=args.weights), dev, encoder_streams=args.encoder_streams)    # identical weights on every rank (seeded)
     model.pretranspose = bool(args.pretranspose)
+    from owl_vit_object_detection_amd import autograd as _autograd
+    _autograd.FOLD_BIAS_COLSUM = bool(args.fold_bias)
     ablate = [a for a in args.ablate.split(",") if a]
     if ablate:
         from owl_vit_object_detection_amd import _lib as _L, autograd as _AG

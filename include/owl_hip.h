@@ -182,7 +182,7 @@ int owl_text_pool_project(void* stream, const float* x, const int64_t* ids, cons
  * zero_row: >= 512 B of device zeros (source of rows m >= M); slabs [splits_used][N][K] f32 are reduced by owl_slab_reduce;
  * splits_used is a HOST pointer.  variant: 0 = the library's choice (the ping-pong schedule), 1 = single-phase kernel, 2 = ping-pong; same bits.
  * owl_colsum_bf16: colsum[c] += sum_r in[r][c] (bias gradients).                                                                   */
-int owl_gemm_tn_slab_bf16(void* stream, const void* dY, int64_t ldy, const void* X, int64_t ldx, const void* zero_row, float* slab, int64_t M, int64_t N, int64_t K, int splits, int* splits_used, int variant);
+int owl_gemm_tn_slab_bf16(void* stream, const void* dY, int64_t ldy, const void* X, int64_t ldx, const void* zero_row, float* slab, int64_t M, int64_t N, int64_t K, int splits, int* splits_used, int variant, float* bias_slab);   /* bias_slab (ABI 6, optional): f32 [splits_used][N] receives the column sums of dY over each split's token range from the same pass (variant 0 / 2) -- the bias gradient's partial sums; add them with owl_slab_reduce(bias_slab, db, N, N, splits_used, 1) */
 int owl_colsum_bf16(void* stream, const void* in_bf16, int64_t ld, float* colsum, int64_t R, int64_t C, float* partials, int64_t partials_floats);
 /* f32 slab scratch of the call above for (M, N, K, splits): bytes = splits_used * N * K * 4 (`bytes` is a HOST pointer) */
 int owl_gemm_tn_slab_workspace_bytes(int64_t M, int64_t N, int64_t K, int splits, int64_t* bytes);

@@ -14,6 +14,9 @@ import torch
 from . import _lib, ops
 
 
+FOLD_BIAS_COLSUM = True    # round 6: bias gradients of the TN-kernel Linears come out of the dW GEMM's own pass (csrc/gemm_tn.hip); False = the separate colsum_bf16 pass (A/B: bench.py --fold-bias 0)
+
+
 def _grads_attached(model) -> bool:
     """Every trainable parameter's .grad is its view of model.flat_grad."""
     for n, off in model.flat_offsets.items():
@@ -97,6 +100,8 @@ def _bws(model, B):
         g32=z(Mh, 32, bf, dev), e_bf=z(Mh, Dt, bf, dev),
         box_part=torch.zeros(_lib.load().owl_box_final_bwd_blocks(Mh), 5 * D + 4, device=dev),
         slab=torch.zeros(_slab_elems(cfg), device=dev),
+        # per-split partial sums of the bias gradients (one row of n_out floats per split of the dW GEMM; at most 256 splits); the class head's chain has its own
+        bslab=torch.zeros(256 * max(3 * D, I, Dt), device=dev), bslab2=torch.zeros(256 * max(D, Dt), device=dev),
         dfeats=z(Mh, D, f32, dev), dcls=torch.zeros(B, D, device=dev),
         dx=z(M, D, f32, dev), dxb=z(M, D, bf, dev), du=z(M, I, bf, dev), dh=z(M, D, bf, dev), dxm=z(M, D, f32, dev),
         datt=z(M, D, bf, dev), dqkv=z(M, 3 * D, bf, dev),
@@ -173,12 +178,16 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
         Token-major operand copies (transposes) -> split-K GEMM into f32 slabs -> deterministic slab reduction.
         Pad columns [rows, rows_pad) of the scratch stay zero: never written, buffers start zeroed."""
         if n_out % 256 == 0 and n_in % 256 == 0:
-            # TN kernel: reads dy / x where they lie (LDS transpose-reads), no token-major copies
-            if grad_b is not None:
-                ops.colsum_bf16(dy, grad_b, rows, n_out, partials=bw[part])
+            # TN kernel: reads dy / x where they lie (LDS transpose-reads), no token-major copies.  The bias gradient (column sums of dy) comes out of the
+            # same pass as per-split partial sums (round 6: it was a second read of dy by a kernel of its own) and is added up like the weight slabs
             tiles = (n_out // 256) * (n_in // 256)
-            ns = ops.gemm_tn_slab(dy, x, bw[slab], rows, n_out, n_in, max(1, 256 // tiles))
+            bs = bw["bslab2" if slab == "slab2" else "bslab"] if (grad_b is not None and FOLD_BIAS_COLSUM) else None
+            if grad_b is not None and bs is None:          # (A/B switch off: the column-sum kernel of rounds 2-5)
+                ops.colsum_bf16(dy, grad_b, rows, n_out, partials=bw[part])
+            ns = ops.gemm_tn_slab(dy, x, bw[slab], rows, n_out, n_in, max(1, 256 // tiles), bias_slab=bs)
             _lib.call("owl_slab_reduce", ops.stream(), bw[slab], grad_w, n_out * n_in, n_out * n_in, ns, accumulate)
+            if bs is not None:
+                _lib.call("owl_slab_reduce", ops.stream(), bs, grad_b, n_out, n_out, ns, 1)
             return
         tA, tB = (bw["tAh"], bw["tBh"]) if rows == Mh else (bw["tA"], bw["tB"])
         ld = tA.shape[1]

@@ -30,6 +30,7 @@ struct TnP {
     const bf16_t* X; int64_t ldx;      // [M, ldx], features k in [0, K)
     const bf16_t* zero_row;            // >= 512 bytes of zeros
     float* slab; int64_t slab_stride;  // [nsplit][N][K]
+    float* bias_slab;                  // optional [nsplit][N]: column sums of dY over the split's token range (the bias gradient's partial sums), see gemm_tn_pp_kernel
     int64_t M, N, K;
     int tiles_n, tiles_k, kt_per_split, nsplit, persistent;
 };
@@ -209,6 +210,13 @@ __global__ __launch_bounds__(512) void gemm_tn_pp_kernel(TnP p) {
     const int64_t n0 = (int64_t)tn * 256, k0 = (int64_t)tk * 256;
     const int kt0 = split * p.kt_per_split, kt1 = min(nk_all, kt0 + p.kt_per_split);
     const int nkt = kt1 - kt0;                                 // >= 1
+    // Round 6: the bias gradient rides along.  db[n] = sum_m dY[m][n] used to be a kernel of its own (colsum_bf16: dY read a second time out of the HBM, 38 ... 83 us
+    // per Linear, and +1.0 % on the train step when all four are skipped -- profiles/r06_colsum_ablate.log).  The dY^T fragments of the MFMAs already hold exactly
+    // these values: lane l of a fragment owns feature n = 32 i + (l & 31) and 8 consecutive tokens, so ONE wave per row group (wc == 0) of the workgroups of the
+    // first k-tile column (tk == 0) adds its fragments up with v_dot2c_f32_bf16 against (1, 1) -- 64 instructions per K-tile in the shadow of 32 MFMAs -- and
+    // writes one partial per (split, feature); owl_slab_reduce adds the splits in fixed order like the weight slabs.
+    const bool do_cs = p.bias_slab != nullptr && tk == 0 && wc == 0;      // (wave-uniform)
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
 
     // ---- staging (as above): wave w fills token rows [w*8, w*8+8) of both operand tiles, 4 pieces (2 rows each) per operand --------------
     int s_kt = kt0, s_buf = 0;                                 // next K-tile to request, and its buffer
@@ -307,10 +315,31 @@ __global__ __launch_bounds__(512) void gemm_tn_pp_kernel(TnP p) {
                     acc[2 * ih + t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][kc], fa[t][kc], acc[2 * ih + t][j], 0, 0, 0);   // D rows = k, cols = n
             __builtin_amdgcn_s_setprio(0);
         };
+        auto colsum = [&](int ih) {                              // fa[t][kc]: 4 dwords = 8 tokens of the lane's feature
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
+            typedef __attribute__((ext_vector_type(2))) short s2_t;
+            const bf2_t ones = __builtin_bit_cast(bf2_t, 0x3f803f80u);
+            // (the four token pairs of a fragment by CONSTANT shuffles of the fragment itself: subscripting a bit-cast copy of the asm-produced tuple made hipcc 7.2
+            //  read its first dword four times -- caught by tools/debug_bias_fold.py with dY[m][n] = m / 64)
+#define TN_CS_PAIR(F, A, B) __builtin_bit_cast(bf2_t, (s2_t)__builtin_shufflevector(F, F, A, B))
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int kc = 0; kc < 4; kc++) {
+                    float c = cs[2 * ih + t];
+                    c = __builtin_amdgcn_fdot2_f32_bf16(TN_CS_PAIR(fa[t][kc], 0, 1), ones, c, false);
+                    c = __builtin_amdgcn_fdot2_f32_bf16(TN_CS_PAIR(fa[t][kc], 2, 3), ones, c, false);
+                    c = __builtin_amdgcn_fdot2_f32_bf16(TN_CS_PAIR(fa[t][kc], 4, 5), ones, c, false);
+                    c = __builtin_amdgcn_fdot2_f32_bf16(TN_CS_PAIR(fa[t][kc], 6, 7), ones, c, false);
+                    cs[2 * ih + t] = c;
+                }
+#undef TN_CS_PAIR
+        };
         // ---- q0 ----
         ld_b(0); ld_a(0);
         wait_frags(); tnp_bar();
         mma(0, 0);
+        if (do_cs) colsum(0);
         tnp_bar();
         // ---- q1 ----
         ld_b(1);
@@ -323,6 +352,7 @@ __global__ __launch_bounds__(512) void gemm_tn_pp_kernel(TnP p) {
         if (live) stage_one(true);
         wait_frags(); tnp_bar();
         mma(1, 1);
+        if (do_cs) colsum(1);
         tnp_bar();
         // ---- q3: the dY tile is free; retire K-tile kt+1, leave kt+2 in flight ----
         if (live) { stage_one(false); stage_advance(); tnp_wait<8>(); } else { tnp_wait<0>(); }
@@ -330,6 +360,14 @@ __global__ __launch_bounds__(512) void gemm_tn_pp_kernel(TnP p) {
         mma(1, 0);
         tnp_bar();
         cur ^= 1;
+    }
+    if (do_cs) {                                               // token halves (lanes l, l + 32) -> one partial per feature and split
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            cs[i] += __shfl_xor(cs[i], 32, 64);
+            const int64_t n = n0 + grp * 128 + i * 32 + (lane & 31);
+            if (lane < 32 && n < p.N) p.bias_slab[(int64_t)split * p.N + n] = cs[i];
+        }
     }
     if (grp == 0) tnp_bar();                                   // group 1's last MFMA half
     {
@@ -355,13 +393,14 @@ OWL_API int owl_gemm_tn_slab_workspace_bytes(int64_t M, int64_t N, int64_t K, in
 }
 
 OWL_API int owl_gemm_tn_slab_bf16(void* stream, const void* dY, int64_t ldy, const void* X, int64_t ldx, const void* zero_row,
-                                     float* slab, int64_t M, int64_t N, int64_t K, int splits, int* splits_used, int variant) {
+                                     float* slab, int64_t M, int64_t N, int64_t K, int splits, int* splits_used, int variant, float* bias_slab) {
     OWL_CHECK_ARG(dY && X && zero_row && slab && splits_used, "owl_gemm_tn_slab_bf16: null pointer");
+    OWL_CHECK_ARG(!bias_slab || variant != 1, "owl_gemm_tn_slab_bf16: bias_slab (column sums of dY from the same pass) exists in the ping-pong kernel only (variant 0 / 2)");
     OWL_CHECK_ARG(M > 0 && N >= 8 && K >= 8 && N % 8 == 0 && K % 8 == 0, "owl_gemm_tn_slab_bf16: bad M=%lld N=%lld K=%lld (N, K %% 8 == 0)", (long long)M, (long long)N, (long long)K);
     OWL_CHECK_ARG(ldy % 8 == 0 && ldx % 8 == 0 && splits >= 1, "owl_gemm_tn_slab_bf16: ldy/ldx must be multiples of 8, splits >= 1");
     TnP p{};
     p.dY = (const bf16_t*)dY; p.ldy = ldy; p.X = (const bf16_t*)X; p.ldx = ldx; p.zero_row = (const bf16_t*)zero_row;
-    p.slab = slab; p.slab_stride = N * K; p.M = M; p.N = N; p.K = K;
+    p.slab = slab; p.slab_stride = N * K; p.M = M; p.N = N; p.K = K; p.bias_slab = bias_slab;
     p.tiles_n = (int)((N + 255) / 256); p.tiles_k = (int)((K + 255) / 256);
     const int nk = (int)((M + TBK - 1) / TBK);
     if (splits > nk) splits = nk;

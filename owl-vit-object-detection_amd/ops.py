@@ -267,15 +267,16 @@ def postprocess(boxes, sims, max_out, conf_thr, iou_thr, route="torchvision_gpu"
 _zero_row = {}
 
 
-def gemm_tn_slab(dy, x, slab, rows, n_out, n_in, splits, variant=0):
-    """slab[s][n][k] = sum_{m in split s} dy[m][n] * x[m][k] (weight gradient, no transposed copies) -> splits used."""
-    _chk(dy, torch.bfloat16, "dy"); _chk(x, torch.bfloat16, "x"); _chk(slab, torch.float32, "slab")
+def gemm_tn_slab(dy, x, slab, rows, n_out, n_in, splits, variant=0, bias_slab=None):
+    """slab[s][n][k] = sum_{m in split s} dy[m][n] * x[m][k] (weight gradient, no transposed copies) -> splits used.
+    bias_slab (optional, f32 [>= splits, n_out]): also bias_slab[s][n] = sum_{m in split s} dy[m][n] from the same pass (the bias gradient's partial sums)."""
+    _chk(dy, torch.bfloat16, "dy"); _chk(x, torch.bfloat16, "x"); _chk(slab, torch.float32, "slab"); _chk(bias_slab, torch.float32, "bias_slab")
     dev = dy.device
     if dev not in _zero_row:
         _zero_row[dev] = torch.zeros(512, dtype=torch.bfloat16, device=dev)
     used = torch.zeros(1, dtype=torch.int32)
     _lib.call("owl_gemm_tn_slab_bf16", stream(), dy, dy.shape[-1], x, x.shape[-1], _zero_row[dev], slab, rows, n_out, n_in,
-              int(splits), used, int(variant))
+              int(splits), used, int(variant), bias_slab)
     return int(used.item())
 
 

@@ -415,6 +415,27 @@ def test_gemm_tn_slab_weight_gradient(rows, n_out, n_in, splits):
     cs2 = torch.zeros(n_out, device=DEV)
     ops.colsum_bf16(dy, cs2, rows, n_out)
     assert torch.equal(cs, cs2)                         # bitwise repeatable
+    # round 6: the column sums of dY (the bias gradient) out of the SAME pass -- one partial per split and feature, from the MFMA fragments (v_dot2c against (1, 1)):
+    # the weight slabs keep their bits, the partials add up to the column sums (every split's token range, pad rows and the zero-filled tail excluded)
+    from owl_vit_object_detection_amd import _lib
+    slab4 = torch.zeros_like(slab); bslab = torch.full((splits, n_out), 9.0, device=DEV)
+    assert ops.gemm_tn_slab(dy, x, slab4, rows, n_out, n_in, splits, bias_slab=bslab) == ns
+    assert torch.equal(slab4[: ns * n_out * n_in], slab[: ns * n_out * n_in])
+    ref_b = dy[:rows].double().sum(0)
+    assert (bslab[:ns].double().sum(0) - ref_b).abs().max().item() <= 1e-3 * rows ** 0.5 + 1e-3
+    assert bool((bslab[ns:] == 9.0).all())
+    per = ((rows + 63) // 64 + ns - 1) // ns * 64          # tokens per split (K-tiles of 64)
+    for s_ in (0, ns - 1):
+        part = dy[s_ * per: min(rows, (s_ + 1) * per)].double().sum(0)
+        assert (bslab[s_].double() - part).abs().max().item() <= 1e-3 * per ** 0.5 + 1e-3, s_
+    db = torch.ones(n_out, device=DEV)
+    _lib.call("owl_slab_reduce", ops.stream(), bslab, db, n_out, n_out, ns, 1)
+    assert (db.double() - 1.0 - ref_b).abs().max().item() <= 1e-3 * rows ** 0.5 + 1e-3
+    bslab2 = torch.zeros_like(bslab)
+    ops.gemm_tn_slab(dy, x, slab4, rows, n_out, n_in, splits, bias_slab=bslab2)
+    assert torch.equal(bslab2[:ns], bslab[:ns])            # bitwise repeatable
+    with pytest.raises(_lib.OwlLibError, match="ping-pong kernel only"):
+        ops.gemm_tn_slab(dy, x, slab4, rows, n_out, n_in, splits, variant=1, bias_slab=bslab2)
 
 
 @pytest.mark.parametrize("R,C", [(73984, 768), (1000, 512), (37, 4), (2312, 1024)])

@@ -1,0 +1,21 @@
+#!/bin/bash
+# round 6, GPU call 11: bias gradients out of the dW GEMM's own pass -- kernel + model tests, then same-box A/B through the Python switch (two processes alternated)
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+timeout 120 python tools/debug_bias_fold.py 2>&1 | grep "rows" ; timeout 1500 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py tests/test_determinism_gpu.py tests/test_headline_gpu.py tests/test_training_gpu.py tests/test_autograd_contract_gpu.py -x -q -m gpu > gpurun_out/r6_c11_tests.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/r6_c11_tests.log
+: > gpurun_out/r6_bias_fold_ab.log
+for round in 1 2 3; do
+  for v in 0 1; do
+    python bench.py --no-cpu-baseline --no-compare --steps 20 --warmup 3 --windows 7 --fold-bias $v 2>/dev/null | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); c = d['config']
+print('round $round fold-bias $v:', d['value'], 'img/s', d['ms_per_step'], 'ms; windows', c['window_values'])" >> gpurun_out/r6_bias_fold_ab.log
+  done
+done
+python bench.py --arch owlvit-large-patch14 --batch 16 --steps 6 --warmup 2 --windows 3 --no-cpu-baseline --no-compare --fold-bias 0 2>/dev/null | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); print('L/14 fold-bias 0:', d['value'], d['ms_per_step'])" >> gpurun_out/r6_bias_fold_ab.log
+python bench.py --arch owlvit-large-patch14 --batch 16 --steps 6 --warmup 2 --windows 3 --no-cpu-baseline --no-compare --fold-bias 1 2>/dev/null | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); print('L/14 fold-bias 1:', d['value'], d['ms_per_step'])" >> gpurun_out/r6_bias_fold_ab.log
+cat gpurun_out/r6_bias_fold_ab.log
