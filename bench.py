@@ -123,10 +123,12 @@ def parse():
     ap.add_argument("--pretranspose", type=int, choices=(0, 1), default=0,
                     help="0 (default, = the product): the backward makes its weight transposes itself; 1: the forward launches them on their own stream "
                          "(models.OwlViT.pretranspose; measured no faster: A/B, profiles/r06_tail.md)")
+    ap.add_argument("--tn-small-n", type=int, choices=(0, 1), default=1, help="1 (default): the class head's 32 x Dt prompt-gradient product on the TN kernel (autograd.TN_SMALL_N); 0: transposes + NT split-K (A/B)")
     ap.add_argument("--fold-bias", type=int, choices=(0, 1), default=1,
                     help="1 (default, = the product): bias gradients out of the dW GEMM's own pass (autograd.FOLD_BIAS_COLSUM); 0: the separate column-sum kernel (A/B)")
-    ap.add_argument("--ablate", default="", help="TIMING ONLY (results are wrong, the line says so): comma list of launches to skip -- colsum (the bias-gradient column sums of "
-                                                "the dW chain), slab_reduce (the split-K reductions): an upper bound on what folding them into the dW GEMM could buy (profiles/r06_tail.md)")
+    ap.add_argument("--ablate", default="", help="TIMING ONLY (results are wrong, the line says so): comma list of work to skip -- colsum (bias-gradient column-sum launches; only with --fold-bias 0), "
+                                                "slab_reduce (split-K reductions), transposes (the backward's weight transposes), dqhat (the class head's prompt-gradient product), loss (matcher + "
+                                                "loss chain replaced by two means), castimg (images resident as bf16): upper bounds on what removing each could buy (profiles/r06_tail.md)")
     ap.add_argument("--encoder-streams", type=int, default=2,
                     help="sub-batches of the encoder forward / dX-only backward, one HIP stream each (OwlViT(encoder_streams=...)); 1 = one stream "
                          "(what the rocprofv3 profiles are taken with: kernel durations are then exclusive)")
@@ -304,11 +306,19 @@ def main():
     model.pretranspose = bool(args.pretranspose)
     from owl_vit_object_detection_amd import autograd as _autograd
     _autograd.FOLD_BIAS_COLSUM = bool(args.fold_bias)
+    _autograd.TN_SMALL_N = bool(args.tn_small_n)
     ablate = [a for a in args.ablate.split(",") if a]
+    ablate_names = set(ablate)
     if ablate:
         from owl_vit_object_detection_amd import _lib as _L, autograd as _AG
         if "colsum" in ablate:
             ops.colsum_bf16 = lambda *a, **k: None
+        if "transposes" in ablate:                      # the backward's weight transposes
+            ops.transpose_bf16 = lambda src, dst, *a, **k: dst
+        if "dqhat" in ablate:                           # the prompt-gradient product of the class head (explicit transposes + NT split-K GEMM): no-ops
+            ops.transpose_colsum = lambda *a, **k: None
+            _g0 = ops.gemm
+            ops.gemm = lambda epi, *a, **k: (None if epi == ops.EPI_SLAB_F32 else _g0(epi, *a, **k))
         if "slab_reduce" in ablate:
             _orig_call = _L.call
             _AG._lib = type("LibNoSlabReduce", (), {"call": staticmethod(lambda name, *a: None if name == "owl_slab_reduce" else _orig_call(name, *a)),
@@ -316,6 +326,9 @@ def main():
     slow_tiles = torch.zeros(1, dtype=torch.int32, device=dev)      # attention forward: (wave, key tile) pairs that left the fast path (csrc/attention_fwd.hip)
     ops.ATTN_SLOW_TILES = slow_tiles
     batches = synth_batches(cfg, B, dev, rank)
+    if "castimg" in ablate_names:
+        for bt in batches:
+            bt["img"] = bt["img"].to(torch.bfloat16)
     scales = synth.class_scales(cfg, [l for l in batches[0]["labels_np"]])
     crit = PushPullLoss(cfg.n_classes, scales)
     opt = FusedAdamW(model, lr=3e-6, weight_decay=0.1)            # ref config.yaml:10,12
@@ -385,6 +398,11 @@ def main():
             return None
         opt.zero_grad()
         pred_boxes, _, pred_sims, _ = model(img)
+        if "loss" in ablate_names:
+            loss = pred_boxes.mean() + pred_sims.mean()
+            loss.backward()
+            dp.sync_and_step()
+            return loss.detach()
         if mode == "lists":
             losses = crit(pred_sims, bt["labels"], pred_boxes, bt["boxes"])       # ref main.py:83
         else:

@@ -14,6 +14,7 @@ import torch
 from . import _lib, ops
 
 
+TN_SMALL_N = True          # round 6: dW products with fewer than 256 output rows (the 32 x Dt prompt gradient) on the TN kernel too; False = explicit transposes + NT split-K (A/B)
 FOLD_BIAS_COLSUM = True    # round 6: bias gradients of the TN-kernel Linears come out of the dW GEMM's own pass (csrc/gemm_tn.hip); False = the separate colsum_bf16 pass (A/B: bench.py --fold-bias 0)
 
 
@@ -177,10 +178,12 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
         """grad_w[n_out, n_in] (+)= dy[rows, n_out]^T x[rows, n_in];  grad_b += colsum(dy).
         Token-major operand copies (transposes) -> split-K GEMM into f32 slabs -> deterministic slab reduction.
         Pad columns [rows, rows_pad) of the scratch stay zero: never written, buffers start zeroed."""
-        if n_out % 256 == 0 and n_in % 256 == 0:
+        # (round 6: also the class head's 32 x Dt prompt-gradient product -- one 256-wide n tile of which 32 rows are kept; it used to go through two explicit
+        #  transposes + the NT split-K kernel: 92 us against ~30, bench.py --tn-small-n 0 / 1, profiles/r06_tail.md)
+        if n_in % 256 == 0 and (n_out % 256 == 0 or (TN_SMALL_N and n_out % 8 == 0 and n_out <= 64 and bw["tn_all"] and grad_b is None)):
             # TN kernel: reads dy / x where they lie (LDS transpose-reads), no token-major copies.  The bias gradient (column sums of dy) comes out of the
             # same pass as per-split partial sums (round 6: it was a second read of dy by a kernel of its own) and is added up like the weight slabs
-            tiles = (n_out // 256) * (n_in // 256)
+            tiles = ((n_out + 255) // 256) * (n_in // 256)
             bs = bw["bslab2" if slab == "slab2" else "bslab"] if (grad_b is not None and FOLD_BIAS_COLSUM) else None
             if grad_b is not None and bs is None:          # (A/B switch off: the column-sum kernel of rounds 2-5)
                 ops.colsum_bf16(dy, grad_b, rows, n_out, partials=bw[part])

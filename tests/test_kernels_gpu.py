@@ -386,7 +386,7 @@ def test_transpose_colsum(R, C):
 
 
 @pytest.mark.parametrize("rows,n_out,n_in,splits", [(73984, 768, 768, 28), (2312, 3072, 768, 9), (4624, 768, 3072, 7), (1000, 256, 512, 3),
-                                                      (64, 256, 256, 1), (73728, 512, 768, 42)])
+                                                      (64, 256, 256, 1), (73728, 512, 768, 42), (73728, 32, 512, 128), (1000, 8, 256, 4), (300, 40, 512, 2)])
 def test_gemm_tn_slab_weight_gradient(rows, n_out, n_in, splits):
     """dW = dY^T X straight from the token-major operands (LDS transpose-reads) vs an f64 reference on a row sample and
     vs the explicit-transpose NT path; any `rows` (the last K-tile is zero-filled); deterministic."""

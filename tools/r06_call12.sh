@@ -1,0 +1,14 @@
+#!/bin/bash
+# round 6, GPU call 12: skip-ablation sweep (timing only): which pieces of the tail cost more than their own duration?
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+: > gpurun_out/r6_ablate_sweep.log
+for round in 1 2; do
+  for v in "" "transposes" "loss" "dqhat" "castimg" "slab_reduce" "transposes,loss,dqhat,castimg,slab_reduce"; do
+    python bench.py --no-cpu-baseline --no-compare --steps 20 --warmup 3 --windows 5 --ablate "$v" 2>/dev/null | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); c = d['config']
+print('round $round skipped [$v]:', d['value'], 'img/s', d['ms_per_step'], 'ms; windows', c['window_values'])" >> gpurun_out/r6_ablate_sweep.log
+  done
+done
+cat gpurun_out/r6_ablate_sweep.log
