@@ -123,6 +123,7 @@ def parse():
     ap.add_argument("--pretranspose", type=int, choices=(0, 1), default=0,
                     help="0 (default, = the product): the backward makes its weight transposes itself; 1: the forward launches them on their own stream "
                          "(models.OwlViT.pretranspose; measured no faster: A/B, profiles/r06_tail.md)")
+    ap.add_argument("--dw-items", type=int, default=256, help="work items per weight-gradient GEMM (autograd.DW_ITEMS; A/B)")
     ap.add_argument("--tn-small-n", type=int, choices=(0, 1), default=1, help="1 (default): the class head's 32 x Dt prompt-gradient product on the TN kernel (autograd.TN_SMALL_N); 0: transposes + NT split-K (A/B)")
     ap.add_argument("--fold-bias", type=int, choices=(0, 1), default=1,
                     help="1 (default, = the product): bias gradients out of the dW GEMM's own pass (autograd.FOLD_BIAS_COLSUM); 0: the separate column-sum kernel (A/B)")
@@ -307,6 +308,7 @@ def main():
     from owl_vit_object_detection_amd import autograd as _autograd
     _autograd.FOLD_BIAS_COLSUM = bool(args.fold_bias)
     _autograd.TN_SMALL_N = bool(args.tn_small_n)
+    _autograd.DW_ITEMS = int(args.dw_items)
     ablate = [a for a in args.ablate.split(",") if a]
     ablate_names = set(ablate)
     if ablate:

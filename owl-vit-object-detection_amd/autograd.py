@@ -14,6 +14,7 @@ import torch
 from . import _lib, ops
 
 
+DW_ITEMS = 256             # (tile, split) work items a weight-gradient GEMM is cut into: one per CU (bench.py --dw-items: fewer = less slab traffic and CUs left to the dX chain; measured, profiles/r06_tail.md)
 TN_SMALL_N = True          # round 6: dW products with fewer than 256 output rows (the 32 x Dt prompt gradient) on the TN kernel too; False = explicit transposes + NT split-K (A/B)
 FOLD_BIAS_COLSUM = True    # round 6: bias gradients of the TN-kernel Linears come out of the dW GEMM's own pass (csrc/gemm_tn.hip); False = the separate colsum_bf16 pass (A/B: bench.py --fold-bias 0)
 
@@ -187,7 +188,7 @@ def backward_impl(model, B, d_boxes, d_sims, sims):
             bs = bw["bslab2" if slab == "slab2" else "bslab"] if (grad_b is not None and FOLD_BIAS_COLSUM) else None
             if grad_b is not None and bs is None:          # (A/B switch off: the column-sum kernel of rounds 2-5)
                 ops.colsum_bf16(dy, grad_b, rows, n_out, partials=bw[part])
-            ns = ops.gemm_tn_slab(dy, x, bw[slab], rows, n_out, n_in, max(1, 256 // tiles), bias_slab=bs)
+            ns = ops.gemm_tn_slab(dy, x, bw[slab], rows, n_out, n_in, max(1, min(DW_ITEMS, 256) // tiles), bias_slab=bs)          # (the slab scratch is sized for 256 items)
             _lib.call("owl_slab_reduce", ops.stream(), bw[slab], grad_w, n_out * n_in, n_out * n_in, ns, accumulate)
             if bs is not None:
                 _lib.call("owl_slab_reduce", ops.stream(), bs, grad_b, n_out, n_out, ns, 1)

@@ -1,0 +1,14 @@
+#!/bin/bash
+# round 6, GPU call 14: work items per weight-gradient GEMM (256 = one per CU ships): fewer items = less slab traffic, CUs left to the dX chain -- same-box A/B
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+: > gpurun_out/r6_dw_items_ab.log
+for round in 1 2; do
+  for v in 256 192 128 96; do
+    python bench.py --no-cpu-baseline --no-compare --steps 20 --warmup 3 --windows 7 --dw-items $v 2>/dev/null | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); c = d['config']
+print('round $round dw-items $v:', d['value'], 'img/s', d['ms_per_step'], 'ms; windows', c['window_values'])" >> gpurun_out/r6_dw_items_ab.log
+  done
+done
+cat gpurun_out/r6_dw_items_ab.log
