@@ -420,6 +420,78 @@ __global__ __launch_bounds__(512) void class_sims_bwd_kernel(const float* __rest
     }
 }
 
+// The same kernel for Dt = 256 NI (the model widths: 512, 768), rows software-pipelined: the per-row chain above (head loads -> wave reduction -> row
+// loads -> stores) leaves the memory system idle between its two load phases; here every load a row needs (its e row: NI float4 per lane; the
+// class gradients, arg-max prompts and sims of lanes < C; the saved 1/norm) is issued THREE rows ahead into one of four register sets used in
+// rotation.  The arithmetic per row and its order are those of class_sims_bwd_kernel: same bits (tests/test_kernels_gpu.py compares the two).
+template <int NI>
+__global__ __launch_bounds__(512) void class_sims_bwd_pf_kernel(const float* __restrict__ dsims, const float* __restrict__ sims,
+                                                                const unsigned char* __restrict__ argmax, const float* __restrict__ inv_norm,
+                                                                const float* __restrict__ e, const float* __restrict__ qhat, bf16_t* de,
+                                                                bf16_t* G, bf16_t* e_bf16, int64_t rows, int C, int rows_per_wave) {
+    constexpr int Dt = 256 * NI;
+    extern __shared__ __attribute__((aligned(16))) float lq[];     // qhat [32][Dt]
+    for (int i = threadIdx.x; i < 32 * (Dt >> 2); i += 512) ((float4*)lq)[i] = ((const float4*)qhat)[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t row0 = ((int64_t)blockIdx.x * 8 + w) * rows_per_wave;
+    const int64_t row1 = min(rows, row0 + rows_per_wave);
+    if (row0 >= row1) return;
+    struct RowIn { float4 ev[NI]; float ds, sm, inv; int am; };
+    auto fetch = [&](int64_t r, RowIn& x) {
+        r = min(r, row1 - 1);                                      // unconditional (a branch around loads costs a vmcnt(0)); the surplus fetches are dropped
+#pragma unroll
+        for (int i = 0; i < NI; i++) x.ev[i] = ((const float4*)(e + r * Dt))[lane + 64 * i];
+        x.inv = inv_norm[r];
+        const int64_t ci = r * C + (lane < C ? lane : 0);
+        x.ds = dsims[ci]; x.am = (int)argmax[ci]; x.sm = sims[ci];
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto process = [&](int64_t r, const RowIn& x) {
+        const float inv = x.inv;
+        int jsel = 0; float gcls = 0.f, gs = 0.f;
+        if (lane < C) {
+            jsel = 3 * lane + x.am;
+            gcls = x.ds * inv;
+            gs = x.ds * x.sm;
+        }
+        gs = wave_sum(gs);
+        const int c = lane / 3;
+        const int jc = __shfl(jsel, c < C ? c : 0, 64);
+        const float gc = __shfl(gcls, c < C ? c : 0, 64);
+        if (lane < 32) G[r * 32 + lane] = f2bf((c < C && jc == lane) ? gc : 0.f);
+        const float nrm = 1.0f / inv - 1e-6f;
+        const float coef_e = gs * inv / nrm;
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            const int k4 = lane + 64 * i;
+            const float4 ev = x.ev[i];
+            float4 d = make_float4(-coef_e * ev.x, -coef_e * ev.y, -coef_e * ev.z, -coef_e * ev.w);
+            for (int cc = 0; cc < C; cc++) {
+                const int j = __builtin_amdgcn_readlane(jsel, cc);
+                const float g = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gcls), cc));
+                const float4 q = ((const float4*)(lq + j * Dt))[k4];
+                d.x += g * q.x; d.y += g * q.y; d.z += g * q.z; d.w += g * q.w;
+            }
+            uint2 o; o.x = pack_bf2(d.x, d.y); o.y = pack_bf2(d.z, d.w);
+            ((uint2*)(de + r * Dt))[k4] = o;
+            uint2 eb; eb.x = pack_bf2(ev.x, ev.y); eb.y = pack_bf2(ev.z, ev.w);
+            ((uint2*)(e_bf16 + r * Dt))[k4] = eb;
+        }
+    };
+    RowIn x0, x1, x2, x3;
+    fetch(row0, x0); fetch(row0 + 1, x1); fetch(row0 + 2, x2);
+    for (int64_t r = row0; r < row1; r += 4) {
+        fetch(r + 3, x3); process(r, x0);
+        if (r + 1 >= row1) break;
+        fetch(r + 4, x0); process(r + 1, x1);
+        if (r + 2 >= row1) break;
+        fetch(r + 5, x1); process(r + 2, x2);
+        if (r + 3 >= row1) break;
+        fetch(r + 6, x2); process(r + 3, x3);
+    }
+}
+
 // dQ from dqhat: qhat = Q/|Q| + 1e-6  ->  dQ = (dqhat - (dqhat . Qn) Qn) / |Q|,  Qn = Q/|Q|
 __global__ __launch_bounds__(64) void qhat_bwd_kernel(const float* __restrict__ dqhat, const float* __restrict__ q, float* dq, int Dt) {
     const int j = blockIdx.x, lane = threadIdx.x;
@@ -444,7 +516,21 @@ OWL_API int owl_class_sims_bwd(void* stream, const float* dsims, const float* si
     OWL_ONCE_PER_DEVICE(attr_done, (void)hipFuncSetAttribute((const void*)class_sims_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     int rpw = (int)((rows + 8 * 512 - 1) / (8 * 512));           // aim at >= 512 workgroups ...
     rpw = rpw < 2 ? 2 : (rpw > 18 ? 18 : rpw);                   // ... with 16..144 rows each
-    hipLaunchKernelGGL(class_sims_bwd_kernel, dim3((unsigned)((rows + 8 * rpw - 1) / (8 * rpw))), dim3(512), shmem, (hipStream_t)stream, dsims, sims, argmax,
+    const dim3 grid((unsigned)((rows + 8 * rpw - 1) / (8 * rpw)));
+    if (Dt == 512 || Dt == 768) {                                // the model widths: rows software-pipelined (same bits)
+        static unsigned long long attr_pf = 0;
+        OWL_ONCE_PER_DEVICE(attr_pf, ((void)hipFuncSetAttribute((const void*)class_sims_bwd_pf_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024),
+                                      (void)hipFuncSetAttribute((const void*)class_sims_bwd_pf_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)));
+        if (Dt == 512)
+            hipLaunchKernelGGL(class_sims_bwd_pf_kernel<2>, grid, dim3(512), shmem, (hipStream_t)stream, dsims, sims, argmax, inv_norm, e, qhat32,
+                               (bf16_t*)de_bf16, (bf16_t*)g_bf16, (bf16_t*)e_bf16, rows, (int)C, rpw);
+        else
+            hipLaunchKernelGGL(class_sims_bwd_pf_kernel<3>, grid, dim3(512), shmem, (hipStream_t)stream, dsims, sims, argmax, inv_norm, e, qhat32,
+                               (bf16_t*)de_bf16, (bf16_t*)g_bf16, (bf16_t*)e_bf16, rows, (int)C, rpw);
+        OWL_LAUNCH_CHECK();
+        return 0;
+    }
+    hipLaunchKernelGGL(class_sims_bwd_kernel, grid, dim3(512), shmem, (hipStream_t)stream, dsims, sims, argmax,
                        inv_norm, e, qhat32, (bf16_t*)de_bf16, (bf16_t*)g_bf16, (bf16_t*)e_bf16, rows, (int)Dt, (int)C, rpw);
     OWL_LAUNCH_CHECK();
     return 0;

@@ -217,6 +217,7 @@ __device__ __forceinline__ void epi_tile_bf16(const GemmP& p, const f32x16& acc,
     constexpr bool TRANS = (EPI == EPI_TRANS_BF16);
     const int hi = lane >> 5;
     unsigned w[8];   // packed words, quad qd -> w[2*qd], w[2*qd+1]
+    unsigned aw[8] = {};   // the tile saved for / by the backward (p.aux) in the same quad layout: read (activation derivatives) or written (activations)
     if constexpr (TRANS) {
         const int64_t n = n_tile + (lane & 31);
         float bv = 0.f;
@@ -231,7 +232,6 @@ __device__ __forceinline__ void epi_tile_bf16(const GemmP& p, const f32x16& acc,
         const bool m_ok = !GUARD || m < p.M;
         const bf16_t* aux_row = (const bf16_t*)p.aux + m * p.ld_aux + n_tile + 4 * hi;
         const float* bias_p = lds_bias + 4 * hi;           // this tile's bias slice, staged in LDS
-        unsigned aw[8] = {};                               // preloaded pre-activations, back in the accumulator's quad layout
         if constexpr (EPI == EPI_DQGELU_BF16 || EPI == EPI_DGELU_BF16) {
             if (aux_pre) {
                 unsigned ax[4] = {aux_pre[0].x, aux_pre[0].y, aux_pre[1].x, aux_pre[1].y}, ay[4] = {aux_pre[0].z, aux_pre[0].w, aux_pre[1].z, aux_pre[1].w};
@@ -278,8 +278,12 @@ __device__ __forceinline__ void epi_tile_bf16(const GemmP& p, const f32x16& acc,
                     for (int e = 0; e < 4; e++) v[e] = gelu_f(v[e]);
                 }
                 if (p.aux) {                               // wave-uniform; saved for the backward (layers the backward passes through only)
-                    uint2 a; a.x = pack_bf2(sv[0], sv[1]); a.y = pack_bf2(sv[2], sv[3]);
-                    if (ok) *(uint2*)((bf16_t*)aux_row + 8 * qd) = a;
+                    if constexpr (EPI == EPI_QGELU_BF16) {  // stored below, paired like the output
+                        aw[2 * qd] = pack_bf2(sv[0], sv[1]); aw[2 * qd + 1] = pack_bf2(sv[2], sv[3]);
+                    } else {
+                        uint2 a; a.x = pack_bf2(sv[0], sv[1]); a.y = pack_bf2(sv[2], sv[3]);
+                        if (ok) *(uint2*)((bf16_t*)aux_row + 8 * qd) = a;
+                    }
                 }
             } else if constexpr (EPI == EPI_DQGELU_BF16 || EPI == EPI_DGELU_BF16) {
                 uint2 a = make_uint2(0u, 0u);
@@ -291,6 +295,26 @@ __device__ __forceinline__ void epi_tile_bf16(const GemmP& p, const f32x16& acc,
             }
             w[2 * qd] = pack_bf2(v[0], v[1]);
             w[2 * qd + 1] = pack_bf2(v[2], v[3]);
+        }
+    }
+    if constexpr (!TRANS && EPI == EPI_QGELU_BF16) {
+        // The tile saved for the backward leaves in the OUTPUT's lane pairing: two 16-byte stores per lane (round 6; it used to leave as four 8-byte
+        // stores straight from the accumulator layout: twice the store instructions of the output itself, and behind them the two-phase kernel waited
+        // for every acknowledgement -- fc1 of a layer the backward passes through took 497 us against 333).  Same bytes at the same addresses.
+        // (erf-GELU, the box head's two 768-wide layers, keeps the direct form: paired it measured 127.5 -> 129.3 us.)
+        if (p.aux) {                                       // wave-uniform
+            unsigned ax[4] = {aw[0], aw[1], aw[4], aw[5]}, ay[4] = {aw[2], aw[3], aw[6], aw[7]};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                auto r = __builtin_amdgcn_permlane32_swap(ax[k], ay[k], false, false);
+                ax[k] = r[0]; ay[k] = r[1];
+            }
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+            const int64_t m = m_tile + (lane & 31);
+            bf16_t* arow = (bf16_t*)p.aux + m * p.ld_aux + n_tile + 8 * hi;
+            const u32x4_t s0 = {ax[0], ax[1], ay[0], ay[1]}, s1 = {ax[2], ax[3], ay[2], ay[3]};
+            if (!GUARD || (m < p.M && n_tile + 8 * hi < p.N)) *(u32x4_t*)arow = s0;
+            if (!GUARD || (m < p.M && n_tile + 16 + 8 * hi < p.N)) *(u32x4_t*)(arow + 16) = s1;
         }
     }
     // pair quads (0,1) and (2,3) across the half-waves: X = even quad word, Y = odd quad word;

@@ -303,6 +303,8 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
                 case 5: q_wait<5>(); break;
                 case 20: q_wait<20>(); break;
                 case 21: q_wait<21>(); break;
+                case 36: q_wait<36>(); break;
+                case 37: q_wait<37>(); break;
                 default: q_wait<0>(); break;
             }
             pending_stores = 0;
@@ -326,9 +328,16 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmP p) {
         const bool inner = (cm0 + QBM <= p.M) && (cn0 + QBN <= p.N);
         // The next tile's K-tile 1 goes into the buffer the last K-tile just left (its A rows: both groups are past LOAD B).  Its A pieces are
         // requested HERE, ahead of the epilogue's stores, so that the counted wait of the next LOAD B can leave the stores in flight.
-        // (Only where the epilogue issues a known number of stores and no loads: plain bf16 epilogues on interior tiles.)
+        // (Only where the epilogue issues a known number of stores and no loads: plain bf16 epilogues on interior tiles -- 2 stores per 32 x 32 tile = 16.)
+        // Round 6: also where the quick-GELU epilogue saves its tile for the backward (16 more stores, paired like the output: gemm_common.h); before, that
+        // launch waited for vmcnt(4) -- every store acknowledged -- ahead of each tile's first MFMA: fc1 of a layer the backward passes through 362.7 ->
+        // 358.0 us as the mean of the step's twelve launches (one with the saved tile), L/14 552.7 -> 509.7 (13 of 24).  Measured and left as they were
+        // (profiles/r06_epilogue_waits.md): the same for every other epilogue on interior tiles (f32 outputs, patch embedding, accumulating forms: -0.4 ...
+        // -1.6 us per launch; dX through quick-GELU' +4 us: its saved-tile loads queue behind the early A pieces), erf-GELU with its saved tile (+1.8 us).
+        // A bias epilogue with aux set is the trace build's stamp buffer.
         constexpr bool PLAIN_EPI = (EPI == EPI_BIAS_BF16 || EPI == EPI_QGELU_BF16 || EPI == EPI_GELU_BF16);
-        if (PLAIN_EPI && inner && !p.aux && a_item < item_end) { stage_A(); a_early = true; pending_stores = 16; }
+        constexpr bool AUX_COUNTED = (EPI == EPI_QGELU_BF16);
+        if (PLAIN_EPI && inner && (AUX_COUNTED || !p.aux) && a_item < item_end) { stage_A(); a_early = true; pending_stores = (AUX_COUNTED && p.aux) ? 32 : 16; }
         const float* lbias = (const float*)(lds + Q_BIAS_OFF + tile_parity * 1024) + wc * 64;
         // (trace, K-tile selector 15: the stamps record the epilogue instead -- 0 start, 1 bias values in registers, 2..5 row block i converted and its
         //  stores issued, 6 = 5 again)

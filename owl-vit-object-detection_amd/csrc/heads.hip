@@ -29,20 +29,25 @@ OWL_API int owl_query_normalize(void* stream, const float* queries, float* qhat3
 }
 
 // ---- class sims ---------------------------------------------------------------------------------
-// block = 4 waves, each wave 32 rows.  qhat [32][Dt] f32 lives in LDS (row stride Dt+4 words).
-__global__ __launch_bounds__(256) void class_sims_kernel(const float* __restrict__ e, const float* __restrict__ qhat,
+// block = blockDim.x / 64 waves, each wave 32 rows.  qhat [32][Dt] f32 lives in LDS (row stride Dt+4 words).
+// A lane's row is 2 KiB away from its neighbour's, so every load instruction touches 64 lines and the kernel lives on loads in flight:
+// the e operand is fetched eight float4 (half of a lane's 64-float share of a 128-wide k chunk) AHEAD of the MFMAs that consume it,
+// into two register blocks used alternately (round 6: 4 loads in flight per lane -> 8..16; arithmetic and its order unchanged, so the
+// results are bit for bit those of the plain loop).  The host sizes the workgroup so that one workgroup per CU covers the rows.
+__global__ __launch_bounds__(640) void class_sims_kernel(const float* __restrict__ e, const float* __restrict__ qhat,
                                                          float* sims, unsigned char* argmax, float* inv_norm,
                                                          int64_t rows, int Dt, int C) {
     extern __shared__ __attribute__((aligned(16))) float lq[];
     const int ldq = Dt + 4;
-    float* lnorm = lq + 32 * ldq;   // [4 waves][32]
-    for (int i = threadIdx.x; i < 32 * (Dt >> 2); i += 256) {
+    const int NT = blockDim.x, nw = NT >> 6;
+    float* lnorm = lq + 32 * ldq;   // [nw waves][32]
+    for (int i = threadIdx.x; i < 32 * (Dt >> 2); i += NT) {
         const int j = i / (Dt >> 2), k4 = i - j * (Dt >> 2);
         *(float4*)(lq + j * ldq + k4 * 4) = ((const float4*)(qhat + (int64_t)j * Dt))[k4];
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hi = lane >> 5;
-    const int64_t r0 = ((int64_t)blockIdx.x * 4 + w) * 32;
+    const int64_t r0 = ((int64_t)blockIdx.x * nw + w) * 32;
     int64_t row = r0 + (lane & 31);
     const bool valid = row < rows;
     if (!valid) row = rows - 1;
@@ -52,23 +57,50 @@ __global__ __launch_bounds__(256) void class_sims_kernel(const float* __restrict
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.f;
     float ss = 0.f;
-    // contraction split: lanes hi=0 take k in [c*128, c*128+64), hi=1 take [c*128+64, c*128+128)
-    for (int c0 = 0; c0 < Dt; c0 += 128) {
+    // contraction split: lanes hi=0 take k in [c*128, c*128+64), hi=1 take [c*128+64, c*128+128); block = half of such a share (8 float4)
+    const int nblk = 2 * ((Dt + 127) >> 7);
+    auto kbase = [&](int blk, float& msk) {
+        const int c0 = (blk >> 1) << 7;
         // no divergence around MFMAs: a half-chunk past Dt (Dt % 128 == 64) feeds zeros instead
         const bool act = (c0 + hi * 64) < Dt;
-        const int kb = act ? c0 + hi * 64 : 0;
-        const float msk = act ? 1.f : 0.f;
-#pragma unroll 4
-        for (int s4 = 0; s4 < 16; s4++) {
-            float4 a = *(const float4*)(er + kb + s4 * 4);
-            const float4 b = *(const float4*)(qr + kb + s4 * 4);
+        msk = act ? 1.f : 0.f;
+        return (act ? c0 + hi * 64 : 0) + (blk & 1) * 32;
+    };
+    auto fetch = [&](int blk, float4 (&buf)[8]) {
+        float m;
+        const float* p = er + kbase(blk, m);
+#pragma unroll
+        for (int s = 0; s < 8; s++) buf[s] = *(const float4*)(p + s * 4);
+        __builtin_amdgcn_sched_barrier(0);      // the loads stay AHEAD of the MFMAs of the other block (hipcc otherwise sinks them to their first use)
+    };
+    auto consume = [&](int blk, const float4 (&buf)[8]) {
+        float msk;
+        const float* q = qr + kbase(blk, msk);
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            float4 a = buf[s];
+            const float4 b = *(const float4*)(q + s * 4);
             a.x *= msk; a.y *= msk; a.z *= msk; a.w *= msk;
-            ss += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+            {
+                // separately rounded products and sums, in this order: the bits the kernel has always produced.  Left to -ffp-contract=fast hipcc fuses
+                // these or not depending on the code AROUND them (the plain loop: not fused; this pipelined form: fused), and 1 / norm moves by an ulp.
+#pragma clang fp contract(off)
+                const float t = ((a.x * a.x + a.y * a.y) + a.z * a.z) + a.w * a.w;
+                ss = ss + t;
+            }
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
         }
+    };
+    float4 bufA[8], bufB[8];
+    fetch(0, bufA);
+    for (int blk = 0; blk < nblk; blk += 2) {       // nblk is even
+        fetch(blk + 1, bufB);
+        consume(blk, bufA);
+        fetch(min(blk + 2, nblk - 1), bufA);        // unconditional (the last one re-reads a block and is dropped): a branch here makes hipcc wait for vmcnt(0)
+        consume(blk + 1, bufB);
     }
     ss += __shfl_xor(ss, 32, 64);
     const float inv = 1.0f / (sqrtf(ss) + 1e-6f);
@@ -95,14 +127,26 @@ __global__ __launch_bounds__(256) void class_sims_kernel(const float* __restrict
     }
 }
 
+// waves per workgroup: one workgroup per CU when the rows allow it (B/16 batch 32: 2304 waves = 9 per CU exactly), four waves at small batch (batch 1: 18 workgroups; one-wave
+// workgroups spend longer filling their 64 KiB query table than computing: 46.6 against 35.6 us from cold caches), at most 10 (two workgroups of 66 KiB LDS fit a CU)
+static int class_sims_waves(int64_t rows) {
+    const int64_t total = (rows + 31) / 32;
+    const int64_t w = (total + 255) / 256;
+    return (int)(w < 4 ? 4 : (w > 10 ? 10 : w));
+}
+
 OWL_API int owl_class_sims_fwd(void* stream, const float* e, const float* qhat32, float* sims, unsigned char* argmax,
                                   float* inv_norm, int64_t rows, int64_t Dt, int64_t C) {
     OWL_CHECK_ARG(e && qhat32 && sims, "owl_class_sims_fwd: null pointer");
+    OWL_CHECK_ARG(rows >= 1, "owl_class_sims_fwd: rows >= 1 required");
     OWL_CHECK_ARG(Dt % 64 == 0 && 3 * C <= 32 && C >= 1, "owl_class_sims_fwd: Dt %% 64 == 0 and 3*C <= 32 required (Dt=%lld C=%lld)", (long long)Dt, (long long)C);
-    const size_t shmem = (size_t)(32 * (Dt + 4) + 128) * sizeof(float);
+    const int nw = class_sims_waves(rows);
+    const size_t shmem = (size_t)(32 * (Dt + 4) + 32 * nw) * sizeof(float);
+    OWL_CHECK_ARG(shmem <= 160 * 1024, "owl_class_sims_fwd: Dt=%lld too large for the LDS-resident query table", (long long)Dt);
     static unsigned long long attr_done = 0;
     OWL_ONCE_PER_DEVICE(attr_done, (void)hipFuncSetAttribute((const void*)class_sims_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(class_sims_kernel, dim3((unsigned)((rows + 127) / 128)), dim3(256), shmem, (hipStream_t)stream, e, qhat32, sims, argmax, inv_norm, rows, (int)Dt, (int)C);
+    const int64_t total = (rows + 31) / 32;
+    hipLaunchKernelGGL(class_sims_kernel, dim3((unsigned)((total + nw - 1) / nw)), dim3(64 * nw), shmem, (hipStream_t)stream, e, qhat32, sims, argmax, inv_norm, rows, (int)Dt, (int)C);
     OWL_LAUNCH_CHECK();
     return 0;
 }

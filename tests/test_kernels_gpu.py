@@ -317,6 +317,40 @@ def test_class_sims(Dt, C):
     report("inv_norm", inv, 1 / (torch.linalg.norm(e, dim=-1) + 1e-6), 1e-6, 1e-5)
 
 
+@pytest.mark.parametrize("rows,Dt,C", [(300, 64, 4), (300, 512, 10), (2304, 512, 10), (1000, 768, 10), (73728, 512, 10), (37, 768, 3)])
+def test_class_sims_forward_backward_match_torch_autograd(rows, Dt, C):
+    """Class head tail (ref src/models.py:24-38) forward AND backward against torch autograd of the same f32 expression: sims / argmax / saved 1/norm, then
+    de (bf16), the routed upstream G (bf16 [rows, 32]) and the bf16 copy of e.  Ragged row counts (partial last wave / workgroup), the generic backward
+    kernel (Dt = 64) and the software-pipelined one (the model widths 512 / 768), one workgroup per CU at the headline row count."""
+    e = rnd(rows, Dt, scale=0.7, seed=1)
+    Q = rnd(3 * C, Dt, seed=4)
+    qhat = torch.zeros(32, Dt, device=DEV); qn = torch.zeros(32, device=DEV)
+    ops.query_normalize(Q, qhat, qn, 3 * C, Dt)
+    sims = torch.zeros(rows, C, device=DEV); am = torch.zeros(rows, C, dtype=torch.uint8, device=DEV); inv = torch.zeros(rows, device=DEV)
+    ops.class_sims(e, qhat, sims, am, inv, rows, Dt, C)
+    er = e.clone().requires_grad_(True)
+    qh = qhat[: 3 * C].clone().requires_grad_(True)
+    s_all = (er / (torch.linalg.norm(er, dim=-1, keepdim=True) + 1e-6)) @ qh.t()
+    ref = F.max_pool1d(s_all[None], 3, 3)[0]
+    report("sims", sims, ref.detach(), 2e-5, 1e-4)
+    assert torch.equal(am.long(), s_all.detach().view(rows, C, 3).argmax(-1))
+    dsims = rnd(rows, C, seed=7)
+    ref.backward(dsims)
+    de = torch.full((rows, Dt), 7.0, device=DEV, dtype=torch.bfloat16); G = torch.full((rows, 32), 7.0, device=DEV, dtype=torch.bfloat16)
+    eb = torch.full((rows, Dt), 7.0, device=DEV, dtype=torch.bfloat16)
+    ops.class_sims_bwd(dsims, sims, am, inv, e, qhat, de, G, eb, rows, Dt, C)
+    assert torch.equal(eb, e.bfloat16())
+    report("de", de, er.grad, 2e-3 * float(er.grad.abs().max()), 8e-3)
+    # G[r, j] = dsims[r, c] * inv[r] where j is class c's arg-max prompt, 0 elsewhere; dqhat = G^T e reproduces autograd's prompt gradient
+    Gref = torch.zeros(rows, 32, device=DEV)
+    Gref.scatter_(1, (3 * torch.arange(C, device=DEV)[None] + am.long()), dsims * inv[:, None])
+    report("G", G, Gref, 1e-6, 8e-3)
+    report("dqhat", G.float().t()[: 3 * C] @ eb.float(), qh.grad, 2e-2 * float(qh.grad.abs().max()), 2e-2)
+    de2 = torch.zeros_like(de); G2 = torch.zeros_like(G); eb2 = torch.zeros_like(eb)
+    ops.class_sims_bwd(dsims, sims, am, inv, e, qhat, de2, G2, eb2, rows, Dt, C)
+    assert torch.equal(de, de2) and torch.equal(G, G2) and torch.equal(eb, eb2)
+
+
 def test_box_final():
     B, P, D = 2, 36, 128
     rows = B * P

@@ -1,0 +1,14 @@
+#!/bin/bash
+# round 6, GPU call 17: the tile an activation epilogue saves for the backward stored in the output's lane pairing (2 x 16 B per lane and tile instead of 4 x 8 B) behind a counted wait -- old / new library, bits + time; then the GEMM tests
+cd "$(dirname "$0")/.."
+[ -f ab_libs/libowlhip_old.so.bin ] && [ -f ab_libs/libowlhip_new.so.bin ] || { echo "needs ab_libs/libowlhip_{old,new}.so.bin"; exit 1; }
+mkdir -p gpurun_out
+L=gpurun_out/r6_fc1_aux_ab.log; : > $L
+for round in 1 2; do for v in old new; do
+  cp ab_libs/libowlhip_$v.so.bin owl-vit-object-detection_amd/libowlhip.so
+  echo "== $v (round $round)" >> $L
+  python tools/fc1_aux_bench.py 2>&1 | grep -v amdgpu.ids >> $L
+done; done
+cp ab_libs/libowlhip_new.so.bin owl-vit-object-detection_amd/libowlhip.so
+python -m pytest tests/test_kernels_gpu.py tests/test_determinism_gpu.py -q -x 2>&1 | tail -5 >> $L
+cat $L
