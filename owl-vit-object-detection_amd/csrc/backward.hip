@@ -63,27 +63,37 @@ OWL_API int owl_rowreduce_workspace_bytes(int64_t groups, int64_t rows_per_group
 // DXSUM: also the column sums of dx (= the bias gradient of the linear layer whose output this residual position is: saves that
 // layer's separate column-sum pass over the f32 dx).
 // ---------------------------------------------------------------------------------------------------
-template <bool DY_BF16, bool DXSUM = false>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy_, const float* __restrict__ x,
-                                                     const float2* __restrict__ stats, const float* __restrict__ gamma,
-                                                     const float* dres, float* dx, float* part, int64_t rows,
-                                                     int D, int rows_per_block, bf16_t* dx_bf16) {
-    __shared__ float red[DXSUM ? 3 : 2][4][LN_MAXV * 256 + 4];
+// NV: D = 256 NV exactly (the model widths: 3 = 768, 4 = 1024; 0 = any D <= 1024 with per-lane bounds).  Round 6: at D = 768 the accumulators and the
+// LDS reduction buffers are sized for 3 vectors per lane, not 4 -- 132 -> <= 128 registers and 49 -> 37 KiB, i.e. four workgroups per CU where three fitted --,
+// and the residual gradient's row is requested with the row's other operands instead of behind the two wave reductions (one load phase per row, not two).
+// Same operations in the same order.
+template <bool DY_BF16, bool DXSUM, int NV, bool HAS_DX>
+__device__ __forceinline__ void ln_bwd_body(const void* __restrict__ dy_, const float* __restrict__ x,
+                                            const float2* __restrict__ stats, const float* __restrict__ gamma,
+                                            const float* dres, float* dx, float* part, int64_t rows,
+                                            int D, int rows_per_block, bf16_t* dx_bf16, float (&red)[DXSUM ? 3 : 2][4][(NV ? NV : LN_MAXV) * 256 + 4]) {
+    // Every product-sum below is written out (fmaf where one rounding is meant, separate operations elsewhere) with contraction off: the three
+    // instantiations per form (any D / 768 / 1024) and any later compiler then produce the same bits -- left to -ffp-contract=fast hipcc picks a
+    // different fusion per instantiation (which product of a sum it folds depends on the basic-block structure around it).
+#pragma clang fp contract(off)
+    constexpr int V = NV ? NV : LN_MAXV;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nvec = D >> 2;
-    float4 ag[LN_MAXV], ab[LN_MAXV], ad[DXSUM ? LN_MAXV : 1];
+    float4 ag[V], ab[V], ad[DXSUM ? V : 1];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; i++) { ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0); if (DXSUM) ad[DXSUM ? i : 0] = make_float4(0, 0, 0, 0); }
+    for (int i = 0; i < V; i++) { ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0); if (DXSUM) ad[DXSUM ? i : 0] = make_float4(0, 0, 0, 0); }
     const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r_end = min(rows, r_begin + rows_per_block);
+    const bool with_res = HAS_DX && dres;                      // (wave-uniform)
     for (int64_t row = r_begin + w; row < r_end; row += 4) {
         const float2 st = stats[row];
-        float4 xh[LN_MAXV], gd[LN_MAXV];
+        float4 xh[V], gd[V], rs[HAS_DX ? V : 1];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; i++) {
+        for (int i = 0; i < V; i++) {
             const int idx = lane + i * 64;
-            if (idx < nvec) {
+            if constexpr (HAS_DX) rs[i] = make_float4(0, 0, 0, 0);
+            if (NV || idx < nvec) {
                 const float4 xv = ld_stream_f4(x + row * D + 4 * idx);          // saved activation, upstream gradient, residual gradient: all dead after this
                 float4 dyv;
                 if constexpr (DY_BF16) {
@@ -92,26 +102,28 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                 } else {
                     dyv = ld_stream_f4((const float*)dy_ + row * D + 4 * idx);
                 }
+                if constexpr (HAS_DX) { if (with_res) rs[i] = ld_stream_f4(dres + row * D + 4 * idx); }
                 const float4 g = ((const float4*)gamma)[idx];
                 xh[i] = make_float4((xv.x - st.x) * st.y, (xv.y - st.x) * st.y, (xv.z - st.x) * st.y, (xv.w - st.x) * st.y);
                 gd[i] = make_float4(dyv.x * g.x, dyv.y * g.y, dyv.z * g.z, dyv.w * g.w);
-                s1 += gd[i].x + gd[i].y + gd[i].z + gd[i].w;
-                s2 += gd[i].x * xh[i].x + gd[i].y * xh[i].y + gd[i].z * xh[i].z + gd[i].w * xh[i].w;
-                ag[i].x += dyv.x * xh[i].x; ag[i].y += dyv.y * xh[i].y; ag[i].z += dyv.z * xh[i].z; ag[i].w += dyv.w * xh[i].w;
+                s1 += ((gd[i].x + gd[i].y) + gd[i].z) + gd[i].w;
+                s2 += fmaf(gd[i].w, xh[i].w, fmaf(gd[i].z, xh[i].z, fmaf(gd[i].y, xh[i].y, gd[i].x * xh[i].x)));
+                ag[i].x = fmaf(dyv.x, xh[i].x, ag[i].x); ag[i].y = fmaf(dyv.y, xh[i].y, ag[i].y);
+                ag[i].z = fmaf(dyv.z, xh[i].z, ag[i].z); ag[i].w = fmaf(dyv.w, xh[i].w, ag[i].w);
                 ab[i].x += dyv.x; ab[i].y += dyv.y; ab[i].z += dyv.z; ab[i].w += dyv.w;
             }
         }
         s1 = wave_sum(s1) / (float)D; s2 = wave_sum(s2) / (float)D;
-        if (dx) {
+        if constexpr (HAS_DX) {
 #pragma unroll
-            for (int i = 0; i < LN_MAXV; i++) {
+            for (int i = 0; i < V; i++) {
                 const int idx = lane + i * 64;
-                if (idx < nvec) {
-                    float4 o = make_float4(st.y * (gd[i].x - s1 - xh[i].x * s2), st.y * (gd[i].y - s1 - xh[i].y * s2),
-                                           st.y * (gd[i].z - s1 - xh[i].z * s2), st.y * (gd[i].w - s1 - xh[i].w * s2));
+                if (NV || idx < nvec) {
+                    float4 o = make_float4(st.y * fmaf(-xh[i].x, s2, gd[i].x - s1), st.y * fmaf(-xh[i].y, s2, gd[i].y - s1),
+                                           st.y * fmaf(-xh[i].z, s2, gd[i].z - s1), st.y * fmaf(-xh[i].w, s2, gd[i].w - s1));
                     if (dres) {
-                        const float4 r = ld_stream_f4(dres + row * D + 4 * idx);
-                        o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+                        const float4 r = rs[HAS_DX ? i : 0];
+                        o.x = o.x + r.x; o.y = o.y + r.y; o.z = o.z + r.z; o.w = o.w + r.w;
                     }
                     st_stream_f4(dx + row * D + 4 * idx, o);          // f32 gradient stream: next read by the LayerNorm backward two GEMMs later
                     if constexpr (DXSUM) { float4& a = ad[DXSUM ? i : 0]; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
@@ -126,9 +138,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     if (!part) return;
     // reduce the 4 waves' partials through LDS; this workgroup's sums go to part[blockIdx.x][{dgamma, dbeta}][D]
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; i++) {
+    for (int i = 0; i < V; i++) {
         const int idx = lane + i * 64;
-        if (idx < nvec) {
+        if (NV || idx < nvec) {
             *(float4*)&red[0][w][idx * 4] = ag[i]; *(float4*)&red[1][w][idx * 4] = ab[i];
             if constexpr (DXSUM) *(float4*)&red[2][w][idx * 4] = ad[DXSUM ? i : 0];
         }
@@ -140,6 +152,36 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
 #pragma unroll
         for (int k = 0; k < NS; k++) mine[k * D + c] = red[k][0][c] + red[k][1][c] + red[k][2][c] + red[k][3][c];
     }
+}
+
+template <bool DY_BF16, bool DXSUM, int NV, bool HAS_DX>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy_, const float* __restrict__ x, const float2* __restrict__ stats,
+                                                     const float* __restrict__ gamma, const float* dres, float* dx, float* part, int64_t rows,
+                                                     int D, int rows_per_block, bf16_t* dx_bf16) {
+    __shared__ float red[DXSUM ? 3 : 2][4][(NV ? NV : LN_MAXV) * 256 + 4];
+    ln_bwd_body<DY_BF16, DXSUM, NV, HAS_DX>(dy_, x, stats, gamma, dres, dx, part, rows, D, rows_per_block, dx_bf16, red);
+}
+// D = 768: four waves per SIMD (the plain bound leaves the column-sum form at 134 registers, six over)
+template <bool DY_BF16, bool DXSUM, bool HAS_DX>
+__global__ __launch_bounds__(256, 4) void ln_bwd_kernel_768(const void* __restrict__ dy_, const float* __restrict__ x, const float2* __restrict__ stats,
+                                                            const float* __restrict__ gamma, const float* dres, float* dx, float* part, int64_t rows,
+                                                            int D, int rows_per_block, bf16_t* dx_bf16) {
+    __shared__ float red[DXSUM ? 3 : 2][4][3 * 256 + 4];
+    ln_bwd_body<DY_BF16, DXSUM, 3, HAS_DX>(dy_, x, stats, gamma, dres, dx, part, rows, D, rows_per_block, dx_bf16, red);
+}
+
+template <bool DY_BF16, bool DXSUM, bool HAS_DX>
+static void ln_bwd_launch2(dim3 grid, hipStream_t s, const void* dy, const float* x, const float2* stats, const float* gamma, const float* dres, float* dx,
+                           float* part, int64_t rows, int D, int rpb, bf16_t* dx_bf16) {
+    if (D == 768) hipLaunchKernelGGL((ln_bwd_kernel_768<DY_BF16, DXSUM, HAS_DX>), grid, dim3(256), 0, s, dy, x, stats, gamma, dres, dx, part, rows, D, rpb, dx_bf16);
+    else if (D == 1024) hipLaunchKernelGGL((ln_bwd_kernel<DY_BF16, DXSUM, 4, HAS_DX>), grid, dim3(256), 0, s, dy, x, stats, gamma, dres, dx, part, rows, D, rpb, dx_bf16);
+    else hipLaunchKernelGGL((ln_bwd_kernel<DY_BF16, DXSUM, 0, HAS_DX>), grid, dim3(256), 0, s, dy, x, stats, gamma, dres, dx, part, rows, D, rpb, dx_bf16);
+}
+template <bool DY_BF16, bool DXSUM>
+static void ln_bwd_launch(dim3 grid, hipStream_t s, const void* dy, const float* x, const float2* stats, const float* gamma, const float* dres, float* dx,
+                          float* part, int64_t rows, int D, int rpb, bf16_t* dx_bf16) {
+    if (dx) ln_bwd_launch2<DY_BF16, DXSUM, true>(grid, s, dy, x, stats, gamma, dres, dx, part, rows, D, rpb, dx_bf16);
+    else if constexpr (!DXSUM) ln_bwd_launch2<DY_BF16, false, false>(grid, s, dy, x, stats, gamma, dres, dx, part, rows, D, rpb, dx_bf16);     // (column sums of dx come with dx)
 }
 
 OWL_API int owl_layernorm_bwd(void* stream, const void* dy, int dy_bf16, const float* x, const float* stats, const float* gamma,
@@ -159,12 +201,9 @@ OWL_API int owl_layernorm_bwd(void* stream, const void* dy, int dy_bf16, const f
         OWL_CHECK_ARG(partials && partials_floats >= (int64_t)nblk * ns * D, "owl_layernorm_bwd: parameter gradients need %lld floats of partial-sum scratch (owl_rowreduce_workspace_bytes)", (long long)nblk * ns * D);
         part = partials;
     }
-    if (dx_colsum)
-        hipLaunchKernelGGL((ln_bwd_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, dy, x, (const float2*)stats, gamma, dres, dx, part, rows, (int)D, rpb, (bf16_t*)dx_bf16);
-    else if (dy_bf16)
-        hipLaunchKernelGGL(ln_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dy, x, (const float2*)stats, gamma, dres, dx, part, rows, (int)D, rpb, (bf16_t*)dx_bf16);
-    else
-        hipLaunchKernelGGL(ln_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dy, x, (const float2*)stats, gamma, dres, dx, part, rows, (int)D, rpb, (bf16_t*)dx_bf16);
+    if (dx_colsum) ln_bwd_launch<true, true>(grid, (hipStream_t)stream, dy, x, (const float2*)stats, gamma, dres, dx, part, rows, (int)D, rpb, (bf16_t*)dx_bf16);
+    else if (dy_bf16) ln_bwd_launch<true, false>(grid, (hipStream_t)stream, dy, x, (const float2*)stats, gamma, dres, dx, part, rows, (int)D, rpb, (bf16_t*)dx_bf16);
+    else ln_bwd_launch<false, false>(grid, (hipStream_t)stream, dy, x, (const float2*)stats, gamma, dres, dx, part, rows, (int)D, rpb, (bf16_t*)dx_bf16);
     OWL_LAUNCH_CHECK();
     if (!part) return 0;
     ReduceOuts outs{}; outs.o[0] = dgamma; outs.o[1] = dbeta; outs.o[2] = dx_colsum;

@@ -1,0 +1,14 @@
+#!/bin/bash
+# round 6, GPU call 20: LayerNorm backward sized for the row width (D = 768: 3 vectors per lane, four workgroups per CU), residual-gradient row requested with the others -- old / new library, bits + time
+cd "$(dirname "$0")/.."
+[ -f ab_libs/libowlhip_old.so.bin ] && [ -f ab_libs/libowlhip_new.so.bin ] || { echo "needs ab_libs/libowlhip_{old,new}.so.bin"; exit 1; }
+mkdir -p gpurun_out
+L=gpurun_out/r6_ln_bwd_ab.log; : > $L
+for round in 1 2; do for v in old new; do
+  cp ab_libs/libowlhip_$v.so.bin owl-vit-object-detection_amd/libowlhip.so
+  echo "== $v (round $round)" >> $L
+  python tools/ln_bwd_bench.py 2>&1 | grep -v amdgpu.ids >> $L
+done; done
+cp ab_libs/libowlhip_new.so.bin owl-vit-object-detection_amd/libowlhip.so
+python -m pytest tests/test_kernels_gpu.py -q -x -k "layernorm or ln" 2>&1 | tail -3 >> $L
+cat $L
