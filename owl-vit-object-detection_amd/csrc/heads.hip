@@ -179,10 +179,102 @@ __global__ __launch_bounds__(256) void box_final_kernel(const bf16_t* __restrict
     }
 }
 
+// The same arithmetic for D <= 1024 with a wave walking MANY rows (round 6): the lane's slice of the four weight rows lives in registers (it was re-read from
+// the L1 for every row: 128 bytes per lane and row), the next two rows are requested while these two are worked on, and the four dot products meet in ONE
+// butterfly (lanes trade halves of their four partial sums at distances 32 and 16, then four plain steps: 7 shuffles per row instead of 24) that ends with
+// lanes 16 k .. 16 k + 15 holding output k -- each of those sums is formed pair by pair exactly as wave_sum forms it.  Lane layout, order of the products in
+// a lane and the tail expression are box_final_kernel's: same bits.
+template <int NC>
+__global__ __launch_bounds__(256) void box_final_rows_kernel(const bf16_t* __restrict__ h, const float* __restrict__ w2,
+                                                             const float* __restrict__ b2, const float* __restrict__ box_bias,
+                                                             float* boxes, float* sig_out, int64_t rows, int64_t P, int D, int rows_per_wave) {
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x & 63;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * rows_per_wave;
+    const int64_t row1 = min(rows, row0 + rows_per_wave);
+    if (row0 >= row1) return;
+    bool act[NC];
+    float wr[NC][4][8];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const int k = lane * 8 + 512 * c;
+        act[c] = k < D;
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            float4 lo = make_float4(0, 0, 0, 0), hi4 = lo;
+            if (act[c]) { lo = *(const float4*)(w2 + (int64_t)o * D + k); hi4 = *(const float4*)(w2 + (int64_t)o * D + k + 4); }
+            wr[c][o][0] = lo.x; wr[c][o][1] = lo.y; wr[c][o][2] = lo.z; wr[c][o][3] = lo.w;
+            wr[c][o][4] = hi4.x; wr[c][o][5] = hi4.y; wr[c][o][6] = hi4.z; wr[c][o][7] = hi4.w;
+        }
+    }
+    const int grp = lane >> 4;                          // the output this lane ends up holding
+    const float bias_k = b2[grp];
+    struct RowIn { us8 hv[NC]; float bb; };
+    auto fetch = [&](int64_t r, RowIn& x) {
+        r = min(r, row1 - 1);                           // unconditional (the surplus fetches are dropped)
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            x.hv[c] = us8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (act[c]) x.hv[c] = *(const us8*)(h + r * D + lane * 8 + 512 * c);
+        }
+        x.bb = box_bias[(r % P) * 4 + grp];
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto process = [&](int64_t r, const RowIn& x) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            if (act[c]) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const float xv = bf2f(x.hv[c][e]);
+                    a0 = fmaf(xv, wr[c][0][e], a0); a1 = fmaf(xv, wr[c][1][e], a1); a2 = fmaf(xv, wr[c][2][e], a2); a3 = fmaf(xv, wr[c][3][e], a3);
+                }
+            }
+        }
+        // distance 32: lanes < 32 go on with outputs (0, 1), the others with (2, 3); distance 16: bit 4 picks one of the pair
+        const bool up = lane & 32;
+        float v0 = up ? a2 : a0, v1 = up ? a3 : a1;
+        v0 += __shfl_xor(up ? a0 : a2, 32, 64); v1 += __shfl_xor(up ? a1 : a3, 32, 64);
+        const bool odd = lane & 16;
+        float v = odd ? v1 : v0;
+        v += __shfl_xor(odd ? v0 : v1, 16, 64);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        const float sg = 1.f / (1.f + expf(-(v + bias_k + x.bb)));
+        const float cx = __shfl(sg, 0, 64), cy = __shfl(sg, 16, 64), bw = __shfl(sg, 32, 64), bh = __shfl(sg, 48, 64);
+        if (lane == 0) {
+            if (sig_out) *(float4*)(sig_out + r * 4) = make_float4(cx, cy, bw, bh);
+            *(float4*)(boxes + r * 4) = make_float4(cx - 0.5f * bw, cy - 0.5f * bh, cx + 0.5f * bw, cy + 0.5f * bh);
+        }
+    };
+    RowIn x0, x1, x2;
+    fetch(row0, x0); fetch(row0 + 1, x1);
+    for (int64_t r = row0; r < row1; r += 3) {
+        fetch(r + 2, x2); process(r, x0);
+        if (r + 1 >= row1) break;
+        fetch(r + 3, x0); process(r + 1, x1);
+        if (r + 2 >= row1) break;
+        fetch(r + 4, x1); process(r + 2, x2);
+    }
+}
+
 OWL_API int owl_box_final_fwd(void* stream, const void* h_bf16, const float* w2, const float* b2, const float* box_bias,
                                  float* boxes, float* sig_out, int64_t rows, int64_t P, int64_t D) {
     OWL_CHECK_ARG(h_bf16 && w2 && b2 && box_bias && boxes, "owl_box_final_fwd: null pointer");
     OWL_CHECK_ARG(D % 8 == 0, "owl_box_final_fwd: D %% 8");
+    if (D <= 1024) {
+        // rows per wave: 16 at large batch (the weight slice is loaded once per wave), fewer when that would leave CUs idle (batch 1: 2304 rows -> 2)
+        int64_t rpw = (rows + 4095) / 4096;
+        rpw = rpw < 1 ? 1 : (rpw > 16 ? 16 : rpw);
+        const dim3 grid((unsigned)((rows + 4 * rpw - 1) / (4 * rpw)));
+        if (D <= 512)
+            hipLaunchKernelGGL(box_final_rows_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h_bf16, w2, b2, box_bias, boxes, sig_out, rows, P, (int)D, (int)rpw);
+        else
+            hipLaunchKernelGGL(box_final_rows_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h_bf16, w2, b2, box_bias, boxes, sig_out, rows, P, (int)D, (int)rpw);
+        OWL_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(box_final_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)h_bf16, w2, b2, box_bias, boxes, sig_out, rows, P, (int)D);
     OWL_LAUNCH_CHECK();
