@@ -101,13 +101,27 @@ __global__ __launch_bounds__(512) void hungarian_kernel(const float* __restrict_
             const double min_val = s_min, ui = u[i];
             const float* crow = cb + (int64_t)i * P;
             Cand c; c.val = INFINITY; c.first = 0x7fffffff; c.ulast = -1;
-            for (int it = tid; it < nrem; it += NT) {
-                const int j = remaining[it];
-                const double r = min_val + (double)crow[j] - ui - v[j];
-                double sj = spc[j];
-                if (r < sj) { path[j] = i; spc[j] = r; sj = r; }
-                Cand m; m.val = sj; m.first = it; m.ulast = (row4col[j] == -1) ? it : -1;
-                c = cand_merge(c, m);
+            // a thread's columns of this scan, eight at a time with every cost-row element requested before the first is used (round 6: the plain loop paid
+            // one L2 round trip per column and thread, five in a row at P = 2304 -- most of a step's time); same columns in the same order
+            constexpr int SK = 8;
+            for (int base = 0; base < nrem; base += SK * NT) {
+                int jj[SK]; float cc[SK];
+#pragma unroll
+                for (int k = 0; k < SK; k++) { const int it = base + tid + k * NT; jj[k] = remaining[it < nrem ? it : 0]; }
+#pragma unroll
+                for (int k = 0; k < SK; k++) cc[k] = crow[jj[k]];
+#pragma unroll
+                for (int k = 0; k < SK; k++) {
+                    const int it = base + tid + k * NT;
+                    if (it < nrem) {
+                        const int j = jj[k];
+                        const double r = min_val + (double)cc[k] - ui - v[j];
+                        double sj = spc[j];
+                        if (r < sj) { path[j] = i; spc[j] = r; sj = r; }
+                        Cand m; m.val = sj; m.first = it; m.ulast = (row4col[j] == -1) ? it : -1;
+                        c = cand_merge(c, m);
+                    }
+                }
             }
             // wave reduce, then across the 8 waves
 #pragma unroll

@@ -1,0 +1,22 @@
+#!/bin/bash
+# round 6, GPU call 24: the session's kernel changes together (class head tail, saved-tile store, LayerNorm backward, box_final, cast, hungarian scan) -- headline bench and L/14 with the
+# library of the session's start / the new one alternated
+cd "$(dirname "$0")/.."
+[ -f ab_libs/libowlhip_old.so.bin ] && [ -f ab_libs/libowlhip_new.so.bin ] || { echo "needs ab_libs/libowlhip_{old,new}.so.bin"; exit 1; }
+mkdir -p gpurun_out
+L=gpurun_out/r6_tail2_ab.log; : > $L
+line() { python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); c = d['config']
+print('$1:', d['value'], 'img/s', d['ms_per_step'], 'ms; windows', c['window_values'])"; }
+for round in 1 2 3; do for v in old new; do
+  cp ab_libs/libowlhip_$v.so.bin owl-vit-object-detection_amd/libowlhip.so
+  python bench.py --no-cpu-baseline --no-compare --steps 20 --warmup 3 --windows 7 2>/dev/null | tail -1 | line "round $round $v B/16" >> $L
+done; done
+for round in 1 2; do for v in old new; do
+  cp ab_libs/libowlhip_$v.so.bin owl-vit-object-detection_amd/libowlhip.so
+  python bench.py --arch owlvit-large-patch14 --batch 16 --steps 6 --warmup 2 --windows 3 --no-cpu-baseline --no-compare 2>/dev/null | tail -1 | line "round $round $v L/14" >> $L
+  python bench.py --batch 1 --no-cpu-baseline --no-compare --steps 50 --warmup 5 2>/dev/null | tail -1 | line "round $round $v B/16 batch 1" >> $L
+done; done
+cp ab_libs/libowlhip_new.so.bin owl-vit-object-detection_amd/libowlhip.so
+cat $L
