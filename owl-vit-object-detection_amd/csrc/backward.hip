@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     __shared__ float red[DXSUM ? 3 : 2][4][(NV ? NV : LN_MAXV) * 256 + 4];
     ln_bwd_body<DY_BF16, DXSUM, NV, HAS_DX>(dy_, x, stats, gamma, dres, dx, part, rows, D, rows_per_block, dx_bf16, red);
 }
-// D = 768: four waves per SIMD (the plain bound leaves the column-sum form at 134 registers, six over)
+// D = 768: four waves per SIMD
 template <bool DY_BF16, bool DXSUM, bool HAS_DX>
 __global__ __launch_bounds__(256, 4) void ln_bwd_kernel_768(const void* __restrict__ dy_, const float* __restrict__ x, const float2* __restrict__ stats,
                                                             const float* __restrict__ gamma, const float* dres, float* dx, float* part, int64_t rows,
@@ -173,7 +173,11 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_kernel_768(const void* __restri
 template <bool DY_BF16, bool DXSUM, bool HAS_DX>
 static void ln_bwd_launch2(dim3 grid, hipStream_t s, const void* dy, const float* x, const float2* stats, const float* gamma, const float* dres, float* dx,
                            float* part, int64_t rows, int D, int rpb, bf16_t* dx_bf16) {
-    if (D == 768) hipLaunchKernelGGL((ln_bwd_kernel_768<DY_BF16, DXSUM, HAS_DX>), grid, dim3(256), 0, s, dy, x, stats, gamma, dres, dx, part, rows, D, rpb, dx_bf16);
+    if (D == 768) {
+        // (the column-sum form needs 134 registers: bounded to four waves per SIMD it spills 5 -- it runs at three, without the bound)
+        if constexpr (DXSUM) hipLaunchKernelGGL((ln_bwd_kernel<DY_BF16, true, 3, HAS_DX>), grid, dim3(256), 0, s, dy, x, stats, gamma, dres, dx, part, rows, D, rpb, dx_bf16);
+        else hipLaunchKernelGGL((ln_bwd_kernel_768<DY_BF16, false, HAS_DX>), grid, dim3(256), 0, s, dy, x, stats, gamma, dres, dx, part, rows, D, rpb, dx_bf16);
+    }
     else if (D == 1024) hipLaunchKernelGGL((ln_bwd_kernel<DY_BF16, DXSUM, 4, HAS_DX>), grid, dim3(256), 0, s, dy, x, stats, gamma, dres, dx, part, rows, D, rpb, dx_bf16);
     else hipLaunchKernelGGL((ln_bwd_kernel<DY_BF16, DXSUM, 0, HAS_DX>), grid, dim3(256), 0, s, dy, x, stats, gamma, dres, dx, part, rows, D, rpb, dx_bf16);
 }
