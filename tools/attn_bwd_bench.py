@@ -14,7 +14,7 @@ def run(B, H, T, iters=10):
     do = torch.zeros_like(o); do[:M] = (torch.randn(M, D, device=DEV) * 0.1).bfloat16()
     doT = torch.zeros(B * D * Tp + 256, device=DEV, dtype=torch.bfloat16); doT[: B * D * Tp].view(B, D, Tp)[:] = do[:M].view(B, Tp, D).transpose(1, 2)
     dvec = torch.zeros(B, H, Tp, device=DEV); dqkv = torch.zeros_like(qkv)
-    f = lambda: _lib.call("owl_attention_bwd_bf16", ops.stream(), qkv, do, o, lse, dvec, dqkv, B, H, T, Tp, 0.125)
+    f = lambda: _lib.call("owl_attention_bwd_bf16", ops.stream(), qkv, do, o, lse, dvec, dqkv, B, H, T, Tp, 0.125, 0)
     for _ in range(3): f()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

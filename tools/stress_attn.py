@@ -21,7 +21,7 @@ for (B, H, T, iters) in [(32, 12, 2305, 100), (4, 16, 3601, 60), (3, 12, 577, 10
         o = torch.zeros(ops.pad_rows(M), D, device=DEV, dtype=torch.bfloat16); lse = torch.zeros(B, H, Tp, device=DEV)
         ops.attention_fwd_vrow(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, o, D, lse, B, H, T, Tp, 0.125)      # the variant the model runs
         dvec = torch.zeros(B, H, Tp, device=DEV); dqkv = torch.zeros_like(qkv)
-        _lib.call("owl_attention_bwd_bf16", ops.stream(), qkv, do, o, lse, dvec, dqkv, B, H, T, Tp, 0.125)
+        _lib.call("owl_attention_bwd_bf16", ops.stream(), qkv, do, o, lse, dvec, dqkv, B, H, T, Tp, 0.125, 0)
         return o, lse, dqkv
 
     ref = run()

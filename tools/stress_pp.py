@@ -61,4 +61,25 @@ for arch, B in (("owlvit-large-patch14", 8), ("owlvit-base-patch16", 16)):
             bad += 1; print("MISMATCH patch embed", arch, it)
     torch.cuda.synchronize()
     print("patch embed", arch, "done", flush=True)
+# round 6: the quick-GELU epilogue WITH the tile it saves for the backward (paired 16-byte stores behind a counted wait: vmcnt(36 / 37) instead of vmcnt(4) at each
+# tile's first K-tile) -- output and saved tile against the single-phase kernel, B/16 and L/14 fc1 shapes
+for (Mq, N, K) in ((32 * 2312, 3072, 768), (16 * 3608, 4096, 1024)):
+    A = torch.randn(ops.pad_rows(Mq), K, device=DEV).bfloat16(); W = (torch.randn(N, K, device=DEV) * 0.05).bfloat16(); bias = torch.randn(N, device=DEV)
+    big = torch.empty(256 * 1024 * 1024, device=DEV, dtype=torch.uint8)
+    def runq(tile):
+        ops.GEMM_TILE = tile
+        out = torch.zeros(ops.pad_rows(Mq), N, device=DEV, dtype=torch.bfloat16); aux = torch.zeros(ops.pad_rows(Mq), N, device=DEV, dtype=torch.bfloat16)
+        ops.gemm(ops.EPI_QGELU_BF16, A, W, out, bias=bias, aux=aux, M=Mq)
+        ops.GEMM_TILE = 0
+        return out, aux
+    ro, ra = runq(256)
+    s2 = torch.cuda.Stream()
+    for it in range(100):
+        with torch.cuda.stream(s2):
+            big.add_(1)
+        go, ga = runq(TILE)
+        if not (torch.equal(go, ro) and torch.equal(ga, ra)):
+            bad += 1; print("MISMATCH qgelu + saved tile", Mq, N, K, it)
+    torch.cuda.synchronize()
+    print("qgelu + saved tile", Mq, N, K, "done", flush=True)
 print("mismatches:", bad)
