@@ -16,6 +16,6 @@ done
 cp $R/gpurun_out/r6_traffic.json $R/profiles/r06_traffic.json
 cd $R
 echo "== traffic"; cat gpurun_out/r6_traffic.json
-timeout 1800 python -m pytest tests -m gpu -q 2>&1 | tail -4 | tee gpurun_out/r6_final_tests.log
+timeout 1800 python -m pytest tests -m gpu -q > gpurun_out/r6_final_tests_full.log 2>&1; grep -E "passed|failed|error" gpurun_out/r6_final_tests_full.log | tail -3 | tee gpurun_out/r6_final_tests.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee gpurun_out/r6_final_smoke.log
 python bench.py --steps 20 --warmup 3 2> gpurun_out/r6_final_bench.err | tee gpurun_out/r6_final_bench.json | cut -c1-700
