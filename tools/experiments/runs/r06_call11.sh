@@ -1,6 +1,9 @@
 #!/bin/bash
+# ARCHIVED (end of round 6): the record of a gpurun call of this round, kept as it was run.  Paths (tools/..., ab_libs/...) are those of that moment; some copy untracked
+# library builds (ab_libs/*.so.bin) over the shipped libowlhip.so, some use bench.py flags that were removed after the measurement.  It refuses to run unless OWL_RUN_ARCHIVED=1.
+if [ "${OWL_RUN_ARCHIVED:-0}" != "1" ]; then echo "$0: archived record of a past gpurun call (see tools/experiments/README.md); set OWL_RUN_ARCHIVED=1 to run it anyway" >&2; exit 1; fi
 # round 6, GPU call 11: bias gradients out of the dW GEMM's own pass -- kernel + model tests, then same-box A/B through the Python switch (two processes alternated)
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../../.."
 mkdir -p gpurun_out
 timeout 120 python tools/debug_bias_fold.py 2>&1 | grep "rows" ; timeout 1500 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py tests/test_determinism_gpu.py tests/test_headline_gpu.py tests/test_training_gpu.py tests/test_autograd_contract_gpu.py -x -q -m gpu > gpurun_out/r6_c11_tests.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/r6_c11_tests.log
 : > gpurun_out/r6_bias_fold_ab.log

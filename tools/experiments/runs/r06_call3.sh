@@ -1,6 +1,9 @@
 #!/bin/bash
+# ARCHIVED (end of round 6): the record of a gpurun call of this round, kept as it was run.  Paths (tools/..., ab_libs/...) are those of that moment; some copy untracked
+# library builds (ab_libs/*.so.bin) over the shipped libowlhip.so, some use bench.py flags that were removed after the measurement.  It refuses to run unless OWL_RUN_ARCHIVED=1.
+if [ "${OWL_RUN_ARCHIVED:-0}" != "1" ]; then echo "$0: archived record of a past gpurun call (see tools/experiments/README.md); set OWL_RUN_ARCHIVED=1 to run it anyway" >&2; exit 1; fi
 # round 6, GPU call 3: stored quick-GELU derivative (kernel tests, model tests, determinism), attention-backward overlap A/B, bench B/16 + L/14
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../../.."
 mkdir -p gpurun_out
 timeout 1500 python -m pytest tests/test_kernels_gpu.py tests/test_determinism_gpu.py tests/test_model_gpu.py tests/test_headline_gpu.py tests/test_training_gpu.py -x -q -m gpu > gpurun_out/r6_c3_tests.log 2>&1; echo "tests rc=$?"; tail -5 gpurun_out/r6_c3_tests.log
 timeout 600 python tools/attn_bwd_overlap_ab.py > gpurun_out/r6_attn_bwd_overlap.log 2>&1; echo "overlap rc=$?"; cat gpurun_out/r6_attn_bwd_overlap.log | cut -c1-260

@@ -1,6 +1,9 @@
 #!/bin/bash
+# ARCHIVED (end of round 6): the record of a gpurun call of this round, kept as it was run.  Paths (tools/..., ab_libs/...) are those of that moment; some copy untracked
+# library builds (ab_libs/*.so.bin) over the shipped libowlhip.so, some use bench.py flags that were removed after the measurement.  It refuses to run unless OWL_RUN_ARCHIVED=1.
+if [ "${OWL_RUN_ARCHIVED:-0}" != "1" ]; then echo "$0: archived record of a past gpurun call (see tools/experiments/README.md); set OWL_RUN_ARCHIVED=1 to run it anyway" >&2; exit 1; fi
 # round 6, GPU call 6: pre-transposed weights -- bit-equality tests, then same-box A/B of the train step (two processes alternated, 9 windows of 20 steps each)
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../../.."
 mkdir -p gpurun_out
 timeout 900 python -m pytest tests/test_determinism_gpu.py tests/test_training_gpu.py tests/test_autograd_contract_gpu.py tests/test_ddp_rccl_gpu.py -x -q -m gpu > gpurun_out/r6_c6_tests.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/r6_c6_tests.log
 : > gpurun_out/r6_pretranspose_ab.log
