@@ -112,7 +112,7 @@ int owl_merge_ln_fwd(void* stream, const float* x, const void* delta_bf16, float
 int owl_query_normalize(void* stream, const float* queries, float* qhat32, float* qnorm, int64_t nq, int64_t Dt);
 /* sims = max over 3 prompts of (e/(|e|+1e-6)) . qhat (ref src/models.py:25-36); f32 MFMA            */
 int owl_class_sims_fwd(void* stream, const float* e, const float* qhat32, float* sims, unsigned char* argmax, float* inv_norm, int64_t rows, int64_t Dt, int64_t C);
-/* dense2 + box bias + sigmoid + center_to_corners (HF5:998, 1071-1104; ref src/models.py:70-73)   */
+/* dense2 + box bias + sigmoid + center_to_corners (HF5:998, 1071-1104; ref src/models.py:70-73); D % 8 == 0, D <= 1024 */
 int owl_box_final_fwd(void* stream, const void* h_bf16, const float* w2, const float* b2, const float* box_bias, float* boxes, float* sig_out, int64_t rows, int64_t P, int64_t D);
 
 /* ---- Hungarian-matched push-pull loss, fully on device (no host sync) --------------------------------

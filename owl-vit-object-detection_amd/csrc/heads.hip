@@ -152,38 +152,13 @@ OWL_API int owl_class_sims_fwd(void* stream, const float* e, const float* qhat32
 }
 
 // ---- box final ------------------------------------------------------------------------------------
-// one wave per row: 4 dot products over D (bf16 activations, f32 weights), + bias + box_bias[p],
-// sigmoid, cxcywh -> xyxy.  sig_out keeps sigma(.) for the backward.
-__global__ __launch_bounds__(256) void box_final_kernel(const bf16_t* __restrict__ h, const float* __restrict__ w2,
-                                                        const float* __restrict__ b2, const float* __restrict__ box_bias,
-                                                        float* boxes, float* sig_out, int64_t rows, int64_t P, int D) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    for (int k = lane * 8; k < D; k += 512) {
-        const us8 hv = *(const us8*)(h + row * D + k);
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const float x = bf2f(hv[e]);
-            a0 += x * w2[k + e]; a1 += x * w2[D + k + e]; a2 += x * w2[2 * D + k + e]; a3 += x * w2[3 * D + k + e];
-        }
-    }
-    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
-    if (lane == 0) {
-        const float* bb = box_bias + (row % P) * 4;
-        const float cx = 1.f / (1.f + expf(-(a0 + b2[0] + bb[0]))), cy = 1.f / (1.f + expf(-(a1 + b2[1] + bb[1])));
-        const float bw = 1.f / (1.f + expf(-(a2 + b2[2] + bb[2]))), bh = 1.f / (1.f + expf(-(a3 + b2[3] + bb[3])));
-        if (sig_out) *(float4*)(sig_out + row * 4) = make_float4(cx, cy, bw, bh);
-        *(float4*)(boxes + row * 4) = make_float4(cx - 0.5f * bw, cy - 0.5f * bh, cx + 0.5f * bw, cy + 0.5f * bh);
-    }
-}
-
-// The same arithmetic for D <= 1024 with a wave walking MANY rows (round 6): the lane's slice of the four weight rows lives in registers (it was re-read from
+// 4 dot products over D per row (bf16 activations, f32 weights), + bias + box_bias[p], sigmoid, cxcywh -> xyxy.  sig_out keeps sigma(.) for the
+// backward.  Lane l owns elements 8 l .. 8 l + 7 (+ 512 for D > 512) of the row and adds its products in that order (fmaf chains); the four sums
+// then meet across the wave pair by pair at distances 32, 16, ..., 1.
+// A wave walks MANY rows (round 6; one wave per row before -- 54 -> 38 us, same bits): the lane's slice of the four weight rows lives in registers (it was re-read from
 // the L1 for every row: 128 bytes per lane and row), the next two rows are requested while these two are worked on, and the four dot products meet in ONE
 // butterfly (lanes trade halves of their four partial sums at distances 32 and 16, then four plain steps: 7 shuffles per row instead of 24) that ends with
-// lanes 16 k .. 16 k + 15 holding output k -- each of those sums is formed pair by pair exactly as wave_sum forms it.  Lane layout, order of the products in
-// a lane and the tail expression are box_final_kernel's: same bits.
+// lanes 16 k .. 16 k + 15 holding output k -- each of those sums is formed pair by pair exactly as wave_sum forms it.
 template <int NC>
 __global__ __launch_bounds__(256) void box_final_rows_kernel(const bf16_t* __restrict__ h, const float* __restrict__ w2,
                                                              const float* __restrict__ b2, const float* __restrict__ box_bias,
@@ -262,21 +237,15 @@ __global__ __launch_bounds__(256) void box_final_rows_kernel(const bf16_t* __res
 OWL_API int owl_box_final_fwd(void* stream, const void* h_bf16, const float* w2, const float* b2, const float* box_bias,
                                  float* boxes, float* sig_out, int64_t rows, int64_t P, int64_t D) {
     OWL_CHECK_ARG(h_bf16 && w2 && b2 && box_bias && boxes, "owl_box_final_fwd: null pointer");
-    OWL_CHECK_ARG(D % 8 == 0, "owl_box_final_fwd: D %% 8");
-    if (D <= 1024) {
-        // rows per wave: 16 at large batch (the weight slice is loaded once per wave), fewer when that would leave CUs idle (batch 1: 2304 rows -> 2)
-        int64_t rpw = (rows + 4095) / 4096;
-        rpw = rpw < 1 ? 1 : (rpw > 16 ? 16 : rpw);
-        const dim3 grid((unsigned)((rows + 4 * rpw - 1) / (4 * rpw)));
-        if (D <= 512)
-            hipLaunchKernelGGL(box_final_rows_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h_bf16, w2, b2, box_bias, boxes, sig_out, rows, P, (int)D, (int)rpw);
-        else
-            hipLaunchKernelGGL(box_final_rows_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h_bf16, w2, b2, box_bias, boxes, sig_out, rows, P, (int)D, (int)rpw);
-        OWL_LAUNCH_CHECK();
-        return 0;
-    }
-    hipLaunchKernelGGL(box_final_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)h_bf16, w2, b2, box_bias, boxes, sig_out, rows, P, (int)D);
+    OWL_CHECK_ARG(D % 8 == 0 && D >= 8 && D <= 1024, "owl_box_final_fwd: D %% 8 == 0 and D <= 1024 required (the LayerNorm kernels' own limit)");
+    // rows per wave: 16 at large batch (the weight slice is loaded once per wave), fewer when that would leave CUs idle (batch 1: 2304 rows -> 1)
+    int64_t rpw = (rows + 4095) / 4096;
+    rpw = rpw < 1 ? 1 : (rpw > 16 ? 16 : rpw);
+    const dim3 grid((unsigned)((rows + 4 * rpw - 1) / (4 * rpw)));
+    if (D <= 512)
+        hipLaunchKernelGGL(box_final_rows_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h_bf16, w2, b2, box_bias, boxes, sig_out, rows, P, (int)D, (int)rpw);
+    else
+        hipLaunchKernelGGL(box_final_rows_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h_bf16, w2, b2, box_bias, boxes, sig_out, rows, P, (int)D, (int)rpw);
     OWL_LAUNCH_CHECK();
     return 0;
 }
