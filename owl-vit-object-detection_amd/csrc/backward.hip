@@ -64,9 +64,10 @@ OWL_API int owl_rowreduce_workspace_bytes(int64_t groups, int64_t rows_per_group
 // layer's separate column-sum pass over the f32 dx).
 // ---------------------------------------------------------------------------------------------------
 // NV: D = 256 NV exactly (the model widths: 3 = 768, 4 = 1024; 0 = any D <= 1024 with per-lane bounds).  Round 6: at D = 768 the accumulators and the
-// LDS reduction buffers are sized for 3 vectors per lane, not 4 -- 132 -> <= 128 registers and 49 -> 37 KiB, i.e. four workgroups per CU where three fitted --,
-// and the residual gradient's row is requested with the row's other operands instead of behind the two wave reductions (one load phase per row, not two).
-// Same operations in the same order.
+// LDS reduction buffers are sized for 3 vectors per lane, not 4 (116 -> 121 registers with the hoisted row below, 33 -> 25 KiB: four workgroups per CU under
+// ln_bwd_kernel_768's bound; the column-sum form needs 133 and runs at three waves per SIMD without it), the residual gradient's row is requested with
+// the row's other operands instead of behind the two wave reductions (one load phase per row, not two), and HAS_DX = false (parameter gradients only:
+// the trainable layer's LN1) drops everything the dx path keeps alive (66 registers).
 template <bool DY_BF16, bool DXSUM, int NV, bool HAS_DX>
 __device__ __forceinline__ void ln_bwd_body(const void* __restrict__ dy_, const float* __restrict__ x,
                                             const float2* __restrict__ stats, const float* __restrict__ gamma,
